@@ -1,0 +1,127 @@
+"""ctypes binding of the C ABI (include/fhe_string_amd.h).  No torch types cross it."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfhe_string_amd.so")
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "lwe_dim", "glwe_dim", "poly_size", "pbs_base_log", "pbs_level", "ks_base_log",
+        "ks_level", "message_bits", "carry_bits")] + [
+        ("lwe_noise_std", C.c_double), ("glwe_noise_std", C.c_double)]
+
+    def ct_words(self):
+        return self.glwe_dim * self.poly_size + 1
+
+
+class Stats(C.Structure):
+    _fields_ = [("pbs_count", C.c_uint64), ("pbs_launches", C.c_uint64), ("linear_count", C.c_uint64),
+                ("arena_capacity", C.c_uint64), ("arena_in_use", C.c_uint64),
+                ("last_ks_ms", C.c_double), ("last_br_ms", C.c_double),
+                ("total_ks_ms", C.c_double), ("total_br_ms", C.c_double)]
+
+
+class FheError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[fhes error {code}] {msg}")
+        self.code = code
+
+
+_P = C.c_void_p
+_PP = C.POINTER(Params)
+_i32p = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes)
+SIGNATURES = {
+    "fhes_params_default": (C.c_int, [_PP]),
+    "fhes_params_toy": (C.c_int, [_PP]),
+    "fhes_ct_words": (C.c_int64, [_PP]),
+    "fhes_bsk_words": (C.c_int64, [_PP]),
+    "fhes_ksk_words": (C.c_int64, [_PP]),
+    "fhes_last_error": (C.c_char_p, []),
+    "fhes_client_key_generate": (_P, [_PP, C.c_uint64, C.c_uint64]),
+    "fhes_client_key_destroy": (None, [_P]),
+    "fhes_client_key_params": (C.c_int, [_P, _PP]),
+    "fhes_client_key_num_blocks_char": (C.c_int32, [_P]),
+    "fhes_client_key_num_blocks_usize": (C.c_int32, [_P]),
+    "fhes_client_key_big_sk": (_P, [_P]),
+    "fhes_client_key_small_sk": (_P, [_P]),
+    "fhes_client_key_make_server_keys": (C.c_int, [_P, _P, _P]),
+    "fhes_client_encrypt_blocks": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "fhes_client_decrypt_blocks": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "fhes_ctx_create": (_P, [_PP, C.c_int32]),
+    "fhes_ctx_destroy": (None, [_P]),
+    "fhes_upload_keys": (C.c_int, [_P, _P, _P]),
+    "fhes_lut_register": (C.c_int32, [_P, _P, C.c_int32]),
+    "fhes_arena_alloc": (C.c_int32, [_P, C.c_int32]),
+    "fhes_arena_free": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "fhes_arena_upload": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "fhes_arena_download": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "fhes_pbs_batch": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "fhes_linear_batch": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "fhes_sync": (C.c_int, [_P]),
+    "fhes_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "fhes_reset_stats": (C.c_int, [_P]),
+    "fhes_set_timing": (C.c_int, [_P, C.c_int32]),
+    "fhes_set_kernel_variant": (C.c_int, [_P, C.c_int32]),
+    "fhes_debug_bsk_fourier": (C.c_int, [_P, _P]),
+    "fhes_debug_fft_tables": (C.c_int, [_PP, _P, _P]),
+    "fhes_debug_keyswitch": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "fhes_program_compile": (_P, [_PP, C.c_char_p, _P, C.c_int32, C.c_int32]),
+    "fhes_program_destroy": (None, [_P]),
+    "fhes_program_info": (C.c_int, [_P, _P]),
+    "fhes_program_export": (C.c_int, [_P] + [_P] * 10),
+    "fhes_program_run": (C.c_int, [_P, _P, _P, _P]),
+    "fhes_server_key_create": (_P, [_P, C.c_int32]),
+    "fhes_server_key_destroy": (None, [_P]),
+    "fhes_server_key_ctx": (_P, [_P]),
+    "fhes_string_encrypt": (_P, [_P, C.c_char_p, C.c_int64, _i32p]),
+    "fhes_string_trivial": (_P, [_P, C.c_char_p, _i32p]),
+    "fhes_usize_encrypt": (_P, [_P, C.c_uint64]),
+    "fhes_ct_destroy": (None, [_P]),
+    "fhes_ct_num_blocks": (C.c_int32, [_P]),
+    "fhes_string_decrypt": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "fhes_usize_decrypt": (C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
+    "fhes_bool_decrypt": (C.c_int, [_P, _P, _i32p]),
+    "fhes_string_op": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _i32p]),
+}
+
+_lib = None
+
+
+def load(strict=True):
+    """Loads the product library.  There is no fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FheError(-2, f"{LIB_PATH} not built; run `python -m fhe_string_amd.build` "
+                           "(the HIP extension is required, there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if strict:
+                raise
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        msg = load().fhes_last_error()
+        raise FheError(rc if rc is not None else -1, msg.decode() if msg else "unknown error")
+    return rc
+
+
+def check_ptr(p):
+    if not p:
+        msg = load().fhes_last_error()
+        raise FheError(-1, msg.decode() if msg else "unknown error")
+    return p

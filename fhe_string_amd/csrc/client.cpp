@@ -1,0 +1,336 @@
+// client.cpp -- client side of the API: parameters, CSPRNG, key generation,
+// block encryption / decryption.  Host CPU code, as in the reference, where
+// `generate_keys_with_params` (/root/reference/src/lib.rs:50-77) and `ClientKey`
+// (/root/reference/src/client_key.rs:15-62) are client-side and never on the
+// accelerated path.  The crypto itself is tfhe-rs's in the reference (not in the
+// container); this follows the published TFHE/CGGI scheme with the tfhe-rs 0.5
+// parameter set PARAM_MESSAGE_2_CARRY_2_KS_PBS.
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace fhes {
+
+std::string &last_error() {
+  static thread_local std::string e;
+  return e;
+}
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+bool params_valid(const fhes_params &p, std::string *why) {
+  auto bad = [&](const char *m) {
+    if (why) *why = m;
+    return false;
+  };
+  if (p.poly_size < 16 || (p.poly_size & (p.poly_size - 1))) return bad("poly_size must be a power of two >= 16");
+  if (p.glwe_dim < 1 || p.lwe_dim < 1) return bad("dimensions must be positive");
+  if (p.pbs_level < 1 || p.pbs_base_log < 1 || p.pbs_level * p.pbs_base_log > 63) return bad("bad PBS decomposition");
+  if (p.ks_level < 1 || p.ks_base_log < 1 || p.ks_level * p.ks_base_log > 63) return bad("bad KS decomposition");
+  if (p.message_bits < 1 || p.carry_bits < 0 || p.message_bits + p.carry_bits > 6) return bad("bad message/carry bits");
+  if ((1 << (p.message_bits + p.carry_bits)) > p.poly_size) return bad("plaintext space larger than polynomial");
+  return true;
+}
+
+// ---- ChaCha20-based CSPRNG ---------------------------------------------------------------
+class ChaCha {
+ public:
+  ChaCha(uint64_t seed, uint64_t stream) {
+    static const uint32_t sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int i = 0; i < 4; i++) st_[i] = sigma[i];
+    uint64_t x = seed;
+    for (int i = 0; i < 4; i++) {  // splitmix64 key expansion
+      x += 0x9E3779B97F4A7C15ull;
+      uint64_t z = x;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      st_[4 + 2 * i] = (uint32_t)z;
+      st_[5 + 2 * i] = (uint32_t)(z >> 32);
+    }
+    st_[12] = 0;
+    st_[13] = 0;
+    st_[14] = (uint32_t)stream;
+    st_[15] = (uint32_t)(stream >> 32);
+    pos_ = 16;
+  }
+  uint32_t next32() {
+    if (pos_ == 16) refill();
+    return out_[pos_++];
+  }
+  uint64_t next64() {
+    uint64_t lo = next32();
+    return lo | ((uint64_t)next32() << 32);
+  }
+  // standard normal via Box-Muller
+  double gauss() {
+    if (have_spare_) {
+      have_spare_ = false;
+      return spare_;
+    }
+    double u1 = ((double)(next64() >> 11) + 1.0) * 0x1p-53;  // (0,1]
+    double u2 = (double)(next64() >> 11) * 0x1p-53;          // [0,1)
+    double r = std::sqrt(-2.0 * std::log(u1));
+    double a = 6.283185307179586476925286766559 * u2;
+    spare_ = r * std::sin(a);
+    have_spare_ = true;
+    return r * std::cos(a);
+  }
+  // torus noise word with std-dev `std_rel` relative to the torus
+  uint64_t noise(double std_rel) {
+    double v = gauss() * std_rel * 0x1p64;
+    return (uint64_t)(int64_t)std::llrint(v);
+  }
+
+ private:
+  static uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+  void refill() {
+    uint32_t x[16];
+    memcpy(x, st_, sizeof x);
+#define QR(a, b, c, d)                                   \
+  x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);            \
+  x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);            \
+  x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);             \
+  x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+    for (int r = 0; r < 10; r++) {
+      QR(0, 4, 8, 12) QR(1, 5, 9, 13) QR(2, 6, 10, 14) QR(3, 7, 11, 15)
+      QR(0, 5, 10, 15) QR(1, 6, 11, 12) QR(2, 7, 8, 13) QR(3, 4, 9, 14)
+    }
+#undef QR
+    for (int i = 0; i < 16; i++) out_[i] = x[i] + st_[i];
+    if (++st_[12] == 0) ++st_[13];
+    pos_ = 0;
+  }
+  uint32_t st_[16], out_[16];
+  int pos_;
+  bool have_spare_ = false;
+  double spare_ = 0;
+};
+
+}  // namespace fhes
+
+using namespace fhes;
+
+struct fhes_client_key {
+  fhes_params p;
+  uint64_t l;             // maximum string length
+  int32_t nb_char;        // lib.rs:60-61
+  int32_t nb_usize;       // lib.rs:62
+  uint64_t seed;
+  uint64_t enc_counter;   // stream counter for encryption randomness
+  std::vector<uint64_t> big_sk, small_sk;  // 0/1 words
+};
+
+extern "C" {
+
+const char *fhes_last_error(void) { return last_error().c_str(); }
+
+int fhes_params_default(fhes_params *o) {
+  if (!o) return fail(FHES_ERR_INVALID, "null params");
+  // PARAM_MESSAGE_2_CARRY_2_KS_PBS, tfhe-rs 0.5 (named at /root/reference/src/lib.rs:45)
+  o->lwe_dim = 742;
+  o->glwe_dim = 1;
+  o->poly_size = 2048;
+  o->pbs_base_log = 23;
+  o->pbs_level = 1;
+  o->ks_base_log = 3;
+  o->ks_level = 5;
+  o->message_bits = 2;
+  o->carry_bits = 2;
+  o->lwe_noise_std = 0.000007069849454709433;
+  o->glwe_noise_std = 0.00000000000000029403601535432533;
+  return FHES_OK;
+}
+
+int fhes_params_toy(fhes_params *o) {
+  if (!o) return fail(FHES_ERR_INVALID, "null params");
+  o->lwe_dim = 32;
+  o->glwe_dim = 1;
+  o->poly_size = 256;
+  o->pbs_base_log = 23;
+  o->pbs_level = 1;
+  o->ks_base_log = 3;
+  o->ks_level = 5;
+  o->message_bits = 2;
+  o->carry_bits = 2;
+  o->lwe_noise_std = 0x1p-40;
+  o->glwe_noise_std = 0x1p-55;
+  return FHES_OK;
+}
+
+int64_t fhes_ct_words(const fhes_params *p) { return p ? (int64_t)p->glwe_dim * p->poly_size + 1 : -1; }
+int64_t fhes_bsk_words(const fhes_params *p) {
+  if (!p) return -1;
+  int64_t kp1 = p->glwe_dim + 1;
+  return (int64_t)p->lwe_dim * p->pbs_level * kp1 * kp1 * p->poly_size;
+}
+int64_t fhes_ksk_words(const fhes_params *p) {
+  if (!p) return -1;
+  return (int64_t)p->glwe_dim * p->poly_size * p->ks_level * (p->lwe_dim + 1);
+}
+
+static int ceil_ilog(uint64_t a, uint64_t b) {  // lib.rs:51-57
+  int l = 0;
+  uint64_t v = 1;
+  while (v < a) {
+    v *= b;
+    l++;
+  }
+  return l;
+}
+
+fhes_client_key *fhes_client_key_generate(const fhes_params *p, uint64_t l, uint64_t seed) {
+  std::string why;
+  if (!p || !params_valid(*p, &why)) {
+    fail(FHES_ERR_INVALID, "invalid parameters: %s", why.c_str());
+    return nullptr;
+  }
+  if (seed == 0) {
+    std::random_device rd;
+    seed = ((uint64_t)rd() << 32) ^ rd() ^ 0x5bd1e995u;
+  }
+  auto *ck = new fhes_client_key;
+  ck->p = *p;
+  ck->l = l;
+  const uint64_t msg_mod = 1ull << p->message_bits;
+  ck->nb_char = ceil_ilog(128, msg_mod);
+  ck->nb_usize = ceil_ilog(l + 1, msg_mod);
+  ck->seed = seed;
+  ck->enc_counter = 0;
+  Dims d(*p);
+  ChaCha g(seed, /*stream=*/1);
+  ck->big_sk.resize(d.big);
+  ck->small_sk.resize(d.n);
+  for (auto &b : ck->big_sk) b = g.next32() & 1u;
+  for (auto &b : ck->small_sk) b = g.next32() & 1u;
+  return ck;
+}
+
+void fhes_client_key_destroy(fhes_client_key *ck) { delete ck; }
+
+int fhes_client_key_params(const fhes_client_key *ck, fhes_params *out) {
+  if (!ck || !out) return fail(FHES_ERR_INVALID, "null argument");
+  *out = ck->p;
+  return FHES_OK;
+}
+int32_t fhes_client_key_num_blocks_char(const fhes_client_key *ck) { return ck ? ck->nb_char : -1; }
+int32_t fhes_client_key_num_blocks_usize(const fhes_client_key *ck) { return ck ? ck->nb_usize : -1; }
+const uint64_t *fhes_client_key_big_sk(const fhes_client_key *ck) { return ck ? ck->big_sk.data() : nullptr; }
+const uint64_t *fhes_client_key_small_sk(const fhes_client_key *ck) { return ck ? ck->small_sk.data() : nullptr; }
+
+int fhes_client_key_make_server_keys(const fhes_client_key *ck, uint64_t *bsk, uint64_t *ksk) {
+  if (!ck || !bsk || !ksk) return fail(FHES_ERR_INVALID, "null argument");
+  const Dims d(ck->p);
+  const int N = d.N, k = d.k, kp1 = k + 1, L = d.L, n = d.n;
+  // positions of the ones of each GLWE key polynomial
+  std::vector<std::vector<int>> ones(k);
+  for (int c = 0; c < k; c++)
+    for (int i = 0; i < N; i++)
+      if (ck->big_sk[(size_t)c * N + i]) ones[c].push_back(i);
+
+  // ---- bootstrapping key: GGSW(s_small[i]) rows --------------------------------------
+  const long rows = (long)n * L * kp1;
+  unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  auto bsk_worker = [&](unsigned tid) {
+    for (long row_id = tid; row_id < rows; row_id += nthreads) {
+      const int i = (int)(row_id / (L * kp1));
+      const int l = (int)((row_id / kp1) % L);
+      const int row = (int)(row_id % kp1);
+      uint64_t *glwe = bsk + (size_t)row_id * kp1 * N;  // [kp1][N]
+      ChaCha g(ck->seed, 0x100000000ull + (uint64_t)row_id);
+      uint64_t *body = glwe + (size_t)k * N;
+      for (int j = 0; j < N; j++) body[j] = g.noise(ck->p.glwe_noise_std);
+      for (int c = 0; c < k; c++) {
+        uint64_t *a = glwe + (size_t)c * N;
+        for (int j = 0; j < N; j++) a[j] = g.next64();
+        // body += a * S_c  (negacyclic, S_c binary)
+        for (int s : ones[c]) {
+          for (int j = 0; j < N - s; j++) body[j + s] += a[j];
+          for (int j = N - s; j < N; j++) body[j + s - N] -= a[j];
+        }
+      }
+      if (ck->small_sk[i]) {
+        const uint64_t g_l = 1ull << (64 - d.pbs_base_log * (l + 1));
+        glwe[(size_t)row * N] += g_l;
+      }
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; t++) th.emplace_back(bsk_worker, t);
+    for (auto &t : th) t.join();
+  }
+
+  // ---- keyswitching key: big -> small -------------------------------------------------
+  const long krows = (long)d.big * d.ks_level;
+  auto ksk_worker = [&](unsigned tid) {
+    for (long r = tid; r < krows; r += nthreads) {
+      const int i = (int)(r / d.ks_level), l = (int)(r % d.ks_level);
+      uint64_t *ct = ksk + (size_t)r * (n + 1);
+      ChaCha g(ck->seed, 0x200000000ull + (uint64_t)r);
+      uint64_t b = g.noise(ck->p.lwe_noise_std);
+      for (int j = 0; j < n; j++) {
+        ct[j] = g.next64();
+        if (ck->small_sk[j]) b += ct[j];
+      }
+      if (ck->big_sk[i]) b += 1ull << (64 - d.ks_base_log * (l + 1));
+      ct[n] = b;
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; t++) th.emplace_back(ksk_worker, t);
+    for (auto &t : th) t.join();
+  }
+  return FHES_OK;
+}
+
+int fhes_client_encrypt_blocks(fhes_client_key *ck, const uint8_t *values, int64_t count,
+                               uint64_t *out) {
+  if (!ck || !values || !out || count < 0) return fail(FHES_ERR_INVALID, "bad argument");
+  const Dims d(ck->p);
+  const int W = d.ct_words();
+  for (int64_t q = 0; q < count; q++) {
+    if (values[q] >= 2 * d.space()) return fail(FHES_ERR_INVALID, "block value %d out of range", values[q]);
+    ChaCha g(ck->seed, 0x300000000ull + ck->enc_counter++);
+    uint64_t *ct = out + (size_t)q * W;
+    uint64_t b = g.noise(ck->p.glwe_noise_std) + (uint64_t)values[q] * d.delta;
+    for (int j = 0; j < d.big; j++) {
+      ct[j] = g.next64();
+      if (ck->big_sk[j]) b += ct[j];
+    }
+    ct[d.big] = b;
+  }
+  return FHES_OK;
+}
+
+int fhes_client_decrypt_blocks(const fhes_client_key *ck, const uint64_t *cts, int64_t count,
+                               uint8_t *values) {
+  if (!ck || !cts || !values || count < 0) return fail(FHES_ERR_INVALID, "bad argument");
+  const Dims d(ck->p);
+  const int W = d.ct_words();
+  for (int64_t q = 0; q < count; q++) {
+    const uint64_t *ct = cts + (size_t)q * W;
+    uint64_t ph = ct[d.big];
+    for (int j = 0; j < d.big; j++)
+      if (ck->big_sk[j]) ph -= ct[j];
+    // round to the nearest multiple of delta; keep the padding bit
+    uint64_t v = (ph + d.delta / 2) >> (63 - d.bits);
+    values[q] = (uint8_t)(v & (uint64_t)(2 * d.space() - 1));
+  }
+  return FHES_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// engine.h -- device engine (Level 0/1 of the C ABI): HIP context, ciphertext arena,
+// key storage, LUT registry and the batched launches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+struct fhes_program;
+
+struct fhes_ctx {
+  fhes_params p;
+  fhes::Dims dims;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+
+  // ciphertext arena: u64 [capacity][ct_stride]
+  uint64_t *arena = nullptr;
+  int64_t capacity = 0;
+  int ct_stride = 0;
+  std::map<int32_t, int32_t> free_ranges;  // first -> count (coalesced)
+  int64_t in_use = 0;
+
+  // keys
+  bool keys_loaded = false;
+  uint64_t *ksk = nullptr;   // [big][ks_level][ks_stride]
+  int ks_stride = 0;
+  double2 *bsk_f = nullptr;  // canonical [n][2][2][M]
+  double2 *twist = nullptr, *tw = nullptr;
+
+  // LUT registry
+  uint64_t *lut_polys = nullptr;  // [lut_capacity][N]
+  int lut_capacity = 0;
+  std::vector<std::vector<uint64_t>> lut_tables;
+
+  // per-launch scratch
+  uint64_t *ks_out = nullptr;
+  int64_t ks_out_nodes = 0;
+  unsigned char *desc_buf = nullptr;  // staging for fhes_pbs_batch descriptors
+  size_t desc_cap = 0;
+
+  // stats / timing
+  fhes_stats stats{};
+  bool timing = false;
+  hipEvent_t ev[3]{};
+  int br_variant = 0;
+
+  explicit fhes_ctx(const fhes_params &pp) : p(pp), dims(pp) {}
+};
+
+namespace fhes {
+
+struct DevNodeArrays {  // device pointers
+  const int32_t *term_ptr, *term_idx;
+  const int64_t *term_coef;
+  const uint64_t *consts;
+  const int32_t *lut_ids, *out_idx, *slot_map;
+};
+
+int hip_fail(hipError_t e, const char *what);
+#define FHES_HIP(call)                                        \
+  do {                                                        \
+    hipError_t _e = (call);                                   \
+    if (_e != hipSuccess) return fhes::hip_fail(_e, #call);   \
+  } while (0)
+
+// launches keyswitch + blind rotate for nodes [first, first+count)
+int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count);
+int launch_linear(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count);
+int32_t arena_alloc_locked(fhes_ctx *ctx, int32_t count);
+int arena_free_locked(fhes_ctx *ctx, int32_t first, int32_t count);
+int32_t lut_register_locked(fhes_ctx *ctx, const uint64_t *table, int32_t n);
+
+}  // namespace fhes

@@ -1,0 +1,515 @@
+// engine.hip -- Level 0 of the C ABI: HIP context, arena, keys, LUTs, batched launches.
+// Reference boundary: the field `ServerKey.k` (/root/reference/src/server_key.rs:13); every
+// `k.k.<op>_parallelized` call of the reference becomes a set of nodes
+//     out = PBS_lut( sum coef*ct + const )
+// executed here in large batches (one keyswitch launch + one blind-rotate launch).
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "kernels.hip.h"
+
+namespace fhes {
+
+int hip_fail(hipError_t e, const char *what) {
+  return fail(FHES_ERR_NO_DEVICE, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+}
+
+void host_fft_tables(int N, std::vector<double> &twist, std::vector<double> &tw) {
+  const int M = N / 2;
+  twist.resize((size_t)2 * M);
+  tw.resize((size_t)M);  // M/2 complex
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int j = 0; j < M; j++) {
+    long double a = pi * (long double)j / (long double)N;
+    twist[2 * j] = (double)cosl(a);
+    twist[2 * j + 1] = (double)sinl(a);
+  }
+  for (int t = 0; t < M / 2; t++) {
+    long double a = -2.0L * pi * (long double)t / (long double)M;
+    tw[2 * t] = (double)cosl(a);
+    tw[2 * t + 1] = (double)sinl(a);
+  }
+  // exact values at the trivial angles
+  twist[0] = 1.0; twist[1] = 0.0;
+  tw[0] = 1.0; tw[1] = 0.0;
+  if (M >= 4) { tw[2 * (M / 4)] = 0.0; tw[2 * (M / 4) + 1] = -1.0; }
+}
+
+static bool kernels_support(const fhes_params &p, std::string *why) {
+  if (p.glwe_dim != 1) { *why = "HIP kernels support glwe_dim == 1 only"; return false; }
+  if (p.pbs_level != 1) { *why = "HIP kernels support pbs_level == 1 only"; return false; }
+  if (p.pbs_base_log != 23) { *why = "HIP kernels are instantiated for pbs_base_log == 23"; return false; }
+  if (p.poly_size != 2048 && p.poly_size != 256) { *why = "HIP kernels are instantiated for poly_size 2048 (and 256 for tests)"; return false; }
+  if (p.ks_level > dev::KS_MAXLV || p.ks_base_log > 7) { *why = "keyswitch decomposition too large"; return false; }
+  if (p.lwe_dim + 1 > 1024) { *why = "lwe_dim too large"; return false; }
+  return true;
+}
+
+// ---- arena (first-fit free list of handle ranges) -----------------------------------------
+int32_t arena_alloc_locked(fhes_ctx *ctx, int32_t count) {
+  if (count <= 0) return fail(FHES_ERR_INVALID, "arena_alloc: count must be positive");
+  for (auto it = ctx->free_ranges.begin(); it != ctx->free_ranges.end(); ++it) {
+    if (it->second >= count) {
+      const int32_t first = it->first, left = it->second - count;
+      ctx->free_ranges.erase(it);
+      if (left > 0) ctx->free_ranges[first + count] = left;
+      ctx->in_use += count;
+      return first;
+    }
+  }
+  return fail(FHES_ERR_OOM, "ciphertext arena exhausted (%lld slots; set FHES_ARENA_SLOTS)",
+              (long long)ctx->capacity);
+}
+
+int arena_free_locked(fhes_ctx *ctx, int32_t first, int32_t count) {
+  if (first < 0 || count <= 0 || (int64_t)first + count > ctx->capacity)
+    return fail(FHES_ERR_INVALID, "arena_free: bad range");
+  auto next = ctx->free_ranges.lower_bound(first);
+  if (next != ctx->free_ranges.end() && next->first < first + count)
+    return fail(FHES_ERR_INVALID, "arena_free: range overlaps a free range");
+  int32_t new_first = first, new_count = count;
+  if (next != ctx->free_ranges.begin()) {
+    auto prev = std::prev(next);
+    if (prev->first + prev->second > first) return fail(FHES_ERR_INVALID, "arena_free: double free");
+    if (prev->first + prev->second == first) {
+      new_first = prev->first;
+      new_count += prev->second;
+      ctx->free_ranges.erase(prev);
+    }
+  }
+  if (next != ctx->free_ranges.end() && next->first == first + count) {
+    new_count += next->second;
+    ctx->free_ranges.erase(next);
+  }
+  ctx->free_ranges[new_first] = new_count;
+  ctx->in_use -= count;
+  return FHES_OK;
+}
+
+// ---- LUT registry ------------------------------------------------------------------------
+int32_t lut_register_locked(fhes_ctx *ctx, const uint64_t *table, int32_t n) {
+  const Dims &d = ctx->dims;
+  if (!table || n != d.space()) return fail(FHES_ERR_INVALID, "lut_register: need %d entries", d.space());
+  std::vector<uint64_t> t(table, table + n);
+  for (auto &v : t)
+    if (v >= (uint64_t)d.space()) return fail(FHES_ERR_INVALID, "lut_register: value out of range");
+  for (size_t i = 0; i < ctx->lut_tables.size(); i++)
+    if (ctx->lut_tables[i] == t) return (int32_t)i;
+  if ((int)ctx->lut_tables.size() >= ctx->lut_capacity) return fail(FHES_ERR_OOM, "LUT registry full");
+  // accumulator body polynomial: box size N/space, shifted by half a box
+  const int N = d.N, box = N / d.space();
+  std::vector<uint64_t> poly(N);
+  for (int j = 0; j < N; j++) {
+    const int jj = j + box / 2;
+    poly[j] = (jj < N) ? t[jj / box] * d.delta : (uint64_t)0 - t[0] * d.delta;
+  }
+  const int32_t id = (int32_t)ctx->lut_tables.size();
+  hipError_t e = hipMemcpy(ctx->lut_polys + (size_t)id * N, poly.data(), sizeof(uint64_t) * N, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return hip_fail(e, "lut upload");
+  ctx->lut_tables.push_back(std::move(t));
+  return id;
+}
+
+// ---- launches ------------------------------------------------------------------------------
+static dev::NodeDesc make_desc(const DevNodeArrays &a, int32_t first, int32_t count) {
+  dev::NodeDesc d;
+  d.term_ptr = a.term_ptr; d.term_idx = a.term_idx; d.term_coef = a.term_coef;
+  d.consts = a.consts; d.lut_ids = a.lut_ids; d.out_idx = a.out_idx; d.slot_map = a.slot_map;
+  d.first = first; d.count = count;
+  return d;
+}
+
+static int ensure_ks_out(fhes_ctx *ctx, int64_t nodes) {
+  if (nodes <= ctx->ks_out_nodes) return FHES_OK;
+  if (ctx->ks_out) FHES_HIP(hipFree(ctx->ks_out));
+  ctx->ks_out = nullptr;
+  ctx->ks_out_nodes = 0;
+  const int64_t cap = std::max<int64_t>(nodes, 1024);
+  FHES_HIP(hipMalloc(&ctx->ks_out, (size_t)cap * ctx->ks_stride * sizeof(uint64_t)));
+  ctx->ks_out_nodes = cap;
+  return FHES_OK;
+}
+
+static int launch_keyswitch(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  const Dims &dm = ctx->dims;
+  FHES_HIP(hipMemsetAsync(ctx->ks_out, 0, (size_t)d.count * ctx->ks_stride * sizeof(uint64_t), ctx->stream));
+  const int tiles = (d.count + dev::KS_TB - 1) / dev::KS_TB;
+  const int max_splits = dm.big / dev::KS_IC;
+  int splits = 1;
+  while (splits < max_splits && tiles * splits < 1024) splits *= 2;
+  const int cps = dm.big / splits;
+  dim3 grid(tiles, splits), block(256);
+  const int jpt = ctx->ks_stride / 256;
+#define KS_LAUNCH(J)                                                                              \
+  hipLaunchKernelGGL((dev::keyswitch_kernel<J>), grid, block, 0, ctx->stream, d, ctx->arena,     \
+                     ctx->ct_stride, dm.big, ctx->ksk, dm.ks_level, dm.ks_base_log,              \
+                     ctx->ks_stride, dm.n, cps, ctx->ks_out)
+  switch (jpt) {
+    case 1: KS_LAUNCH(1); break;
+    case 2: KS_LAUNCH(2); break;
+    case 3: KS_LAUNCH(3); break;
+    case 4: KS_LAUNCH(4); break;
+    default: return fail(FHES_ERR_UNSUPPORTED, "ks_stride %d", ctx->ks_stride);
+  }
+#undef KS_LAUNCH
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
+template <int LOGN>
+static int launch_br_v1(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  constexpr int N = 1 << LOGN, M = N / 2;
+  const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)((ctx->dims.n + 1 + 3) & ~3) * 4;
+  auto kern = dev::blind_rotate_v1_kernel<LOGN, 23>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(d.count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
+                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_f,
+                     ctx->lut_polys, ctx->twist, ctx->tw);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
+int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count) {
+  if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
+  const int32_t kMaxChunk = 16384;
+  for (int32_t off = 0; off < count; off += kMaxChunk) {
+    const int32_t c = std::min(kMaxChunk, count - off);
+    int rc = ensure_ks_out(ctx, c);
+    if (rc) return rc;
+    dev::NodeDesc d = make_desc(a, first + off, c);
+    if (ctx->timing) FHES_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    rc = launch_keyswitch(ctx, d);
+    if (rc) return rc;
+    if (ctx->timing) FHES_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (ctx->dims.N == 2048) rc = launch_br_v1<11>(ctx, d);
+    else rc = launch_br_v1<8>(ctx, d);
+    if (rc) return rc;
+    if (ctx->timing) {
+      FHES_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+      FHES_HIP(hipEventSynchronize(ctx->ev[2]));
+      float ks = 0, br = 0;
+      FHES_HIP(hipEventElapsedTime(&ks, ctx->ev[0], ctx->ev[1]));
+      FHES_HIP(hipEventElapsedTime(&br, ctx->ev[1], ctx->ev[2]));
+      ctx->stats.last_ks_ms = ks; ctx->stats.last_br_ms = br;
+      ctx->stats.total_ks_ms += ks; ctx->stats.total_br_ms += br;
+    }
+    ctx->stats.pbs_count += (uint64_t)c;
+    ctx->stats.pbs_launches += 1;
+  }
+  return FHES_OK;
+}
+
+int launch_linear(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count) {
+  if (count <= 0) return FHES_OK;
+  dev::NodeDesc d = make_desc(a, first, count);
+  hipLaunchKernelGGL(dev::linear_kernel, dim3(count), dim3(256), 0, ctx->stream, d, ctx->arena,
+                     ctx->ct_stride, ctx->dims.big);
+  FHES_HIP(hipGetLastError());
+  ctx->stats.linear_count += (uint64_t)count;
+  return FHES_OK;
+}
+
+static int ensure_desc(fhes_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->desc_cap) return FHES_OK;
+  if (ctx->desc_buf) FHES_HIP(hipFree(ctx->desc_buf));
+  ctx->desc_buf = nullptr;
+  ctx->desc_cap = 0;
+  const size_t cap = std::max<size_t>(bytes * 2, 1 << 20);
+  FHES_HIP(hipMalloc(&ctx->desc_buf, cap));
+  ctx->desc_cap = cap;
+  return FHES_OK;
+}
+
+// copies host descriptor arrays into the ctx staging buffer and returns device views
+static int stage_desc(fhes_ctx *ctx, int32_t count, const int32_t *term_ptr, const int32_t *term_idx,
+                      const int64_t *term_coef, const uint64_t *consts, const int32_t *lut_ids,
+                      const int32_t *out, DevNodeArrays *a) {
+  if (count <= 0 || !term_ptr || !consts || !out) return fail(FHES_ERR_INVALID, "bad batch arguments");
+  const int32_t nt = term_ptr[count];
+  if (term_ptr[0] != 0 || nt < 0 || (nt > 0 && (!term_idx || !term_coef))) return fail(FHES_ERR_INVALID, "bad term arrays");
+  for (int32_t t = 0; t < nt; t++)
+    if (term_idx[t] < 0 || term_idx[t] >= ctx->capacity) return fail(FHES_ERR_INVALID, "term handle out of range");
+  for (int32_t j = 0; j < count; j++) {
+    if (out[j] < 0 || out[j] >= ctx->capacity) return fail(FHES_ERR_INVALID, "output handle out of range");
+    if (term_ptr[j + 1] < term_ptr[j]) return fail(FHES_ERR_INVALID, "term_ptr not monotone");
+    if (lut_ids && (lut_ids[j] < 0 || lut_ids[j] >= (int)ctx->lut_tables.size())) return fail(FHES_ERR_INVALID, "unknown lut id");
+  }
+  auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t o_tp = 0, o_ti = al(o_tp + 4 * (size_t)(count + 1)), o_tc = al(o_ti + 4 * (size_t)std::max(nt, 1)),
+               o_c = al(o_tc + 8 * (size_t)std::max(nt, 1)), o_l = al(o_c + 8 * (size_t)count),
+               o_o = al(o_l + 4 * (size_t)count), total = al(o_o + 4 * (size_t)count);
+  int rc = ensure_desc(ctx, total);
+  if (rc) return rc;
+  std::vector<unsigned char> h(total, 0);
+  memcpy(&h[o_tp], term_ptr, 4 * (size_t)(count + 1));
+  if (nt) { memcpy(&h[o_ti], term_idx, 4 * (size_t)nt); memcpy(&h[o_tc], term_coef, 8 * (size_t)nt); }
+  memcpy(&h[o_c], consts, 8 * (size_t)count);
+  if (lut_ids) memcpy(&h[o_l], lut_ids, 4 * (size_t)count);
+  memcpy(&h[o_o], out, 4 * (size_t)count);
+  FHES_HIP(hipStreamSynchronize(ctx->stream));  // staging buffer may still be in use
+  FHES_HIP(hipMemcpy(ctx->desc_buf, h.data(), total, hipMemcpyHostToDevice));
+  unsigned char *b = ctx->desc_buf;
+  a->term_ptr = (const int32_t *)(b + o_tp); a->term_idx = (const int32_t *)(b + o_ti);
+  a->term_coef = (const int64_t *)(b + o_tc); a->consts = (const uint64_t *)(b + o_c);
+  a->lut_ids = (const int32_t *)(b + o_l); a->out_idx = (const int32_t *)(b + o_o);
+  a->slot_map = nullptr;
+  return FHES_OK;
+}
+
+}  // namespace fhes
+
+using namespace fhes;
+
+extern "C" {
+
+fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
+  std::string why;
+  if (!p || !params_valid(*p, &why)) { fail(FHES_ERR_INVALID, "invalid parameters: %s", why.c_str()); return nullptr; }
+  if (!kernels_support(*p, &why)) { fail(FHES_ERR_UNSUPPORTED, "%s", why.c_str()); return nullptr; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    fail(FHES_ERR_NO_DEVICE, "no HIP device available (%s); this engine has no CPU fallback",
+         e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return nullptr;
+  }
+  if (device < 0 || device >= ndev) { fail(FHES_ERR_INVALID, "device %d out of range (%d devices)", device, ndev); return nullptr; }
+  auto *ctx = new fhes_ctx(*p);
+  ctx->device = device;
+  const Dims &d = ctx->dims;
+  auto bail = [&](hipError_t err, const char *what) -> fhes_ctx * {
+    hip_fail(err, what);
+    fhes_ctx_destroy(ctx);
+    return nullptr;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  for (auto &ev : ctx->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+
+  ctx->ct_stride = d.big + 16;
+  const char *env = getenv("FHES_ARENA_SLOTS");
+  ctx->capacity = env ? atoll(env) : (int64_t)1 << 18;
+  if (ctx->capacity < 64) ctx->capacity = 64;
+  if ((e = hipMalloc(&ctx->arena, (size_t)ctx->capacity * ctx->ct_stride * 8)) != hipSuccess) return bail(e, "hipMalloc(arena)");
+  ctx->free_ranges[0] = (int32_t)ctx->capacity;
+
+  ctx->ks_stride = ((d.n + 1 + 255) / 256) * 256;
+  ctx->lut_capacity = 256;
+  if ((e = hipMalloc(&ctx->lut_polys, (size_t)ctx->lut_capacity * d.N * 8)) != hipSuccess) return bail(e, "hipMalloc(luts)");
+
+  std::vector<double> twist, tw;
+  host_fft_tables(d.N, twist, tw);
+  if ((e = hipMalloc(&ctx->twist, twist.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(twist)");
+  if ((e = hipMalloc(&ctx->tw, tw.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(tw)");
+  if ((e = hipMemcpy(ctx->twist, twist.data(), twist.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy twist");
+  if ((e = hipMemcpy(ctx->tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy tw");
+  return ctx;
+}
+
+void fhes_ctx_destroy(fhes_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->bsk_f);
+  (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->lut_polys);
+  (void)hipFree(ctx->ks_out); (void)hipFree(ctx->desc_buf);
+  for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
+  if (!ctx || !bsk || !ksk) return fail(FHES_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  const Dims &d = ctx->dims;
+  // keyswitch key, rows padded to ks_stride words
+  {
+    const size_t rows = (size_t)d.big * d.ks_level;
+    std::vector<uint64_t> padded(rows * ctx->ks_stride, 0);
+    for (size_t r = 0; r < rows; r++)
+      memcpy(&padded[r * ctx->ks_stride], ksk + r * (d.n + 1), sizeof(uint64_t) * (d.n + 1));
+    if (!ctx->ksk) FHES_HIP(hipMalloc(&ctx->ksk, padded.size() * 8));
+    FHES_HIP(hipMemcpy(ctx->ksk, padded.data(), padded.size() * 8, hipMemcpyHostToDevice));
+  }
+  // bootstrapping key -> Fourier domain on the device
+  {
+    const size_t npoly = (size_t)d.n * 4;
+    uint64_t *tmp = nullptr;
+    FHES_HIP(hipMalloc(&tmp, npoly * d.N * 8));
+    FHES_HIP(hipMemcpy(tmp, bsk, npoly * d.N * 8, hipMemcpyHostToDevice));
+    if (!ctx->bsk_f) FHES_HIP(hipMalloc(&ctx->bsk_f, npoly * d.M * 16));
+    const size_t lds = (size_t)d.M * 16;
+    if (d.N == 2048)
+      hipLaunchKernelGGL((dev::bsk_to_fourier_kernel<11>), dim3(npoly), dim3(d.M / 8), lds, ctx->stream, tmp, ctx->bsk_f, ctx->twist, ctx->tw);
+    else
+      hipLaunchKernelGGL((dev::bsk_to_fourier_kernel<8>), dim3(npoly), dim3(d.M / 8), lds, ctx->stream, tmp, ctx->bsk_f, ctx->twist, ctx->tw);
+    FHES_HIP(hipGetLastError());
+    FHES_HIP(hipStreamSynchronize(ctx->stream));
+    FHES_HIP(hipFree(tmp));
+  }
+  ctx->keys_loaded = true;
+  return FHES_OK;
+}
+
+int32_t fhes_lut_register(fhes_ctx *ctx, const uint64_t *table, int32_t n) {
+  if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  return lut_register_locked(ctx, table, n);
+}
+
+int32_t fhes_arena_alloc(fhes_ctx *ctx, int32_t count) {
+  if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return arena_alloc_locked(ctx, count);
+}
+
+int fhes_arena_free(fhes_ctx *ctx, int32_t first, int32_t count) {
+  if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  FHES_HIP(hipStreamSynchronize(ctx->stream));  // slots may still be read by queued work
+  return arena_free_locked(ctx, first, count);
+}
+
+int fhes_arena_upload(fhes_ctx *ctx, int32_t first, int32_t count, const uint64_t *host) {
+  if (!ctx || !host || first < 0 || count <= 0 || (int64_t)first + count > ctx->capacity)
+    return fail(FHES_ERR_INVALID, "arena_upload: bad range");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  const size_t w = (size_t)ctx->dims.ct_words() * 8;
+  FHES_HIP(hipMemcpy2DAsync(ctx->arena + (size_t)first * ctx->ct_stride, (size_t)ctx->ct_stride * 8, host, w, w,
+                            count, hipMemcpyHostToDevice, ctx->stream));
+  FHES_HIP(hipStreamSynchronize(ctx->stream));
+  return FHES_OK;
+}
+
+int fhes_arena_download(fhes_ctx *ctx, int32_t first, int32_t count, uint64_t *host) {
+  if (!ctx || !host || first < 0 || count <= 0 || (int64_t)first + count > ctx->capacity)
+    return fail(FHES_ERR_INVALID, "arena_download: bad range");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  const size_t w = (size_t)ctx->dims.ct_words() * 8;
+  FHES_HIP(hipMemcpy2DAsync(host, w, ctx->arena + (size_t)first * ctx->ct_stride, (size_t)ctx->ct_stride * 8, w,
+                            count, hipMemcpyDeviceToHost, ctx->stream));
+  FHES_HIP(hipStreamSynchronize(ctx->stream));
+  return FHES_OK;
+}
+
+int fhes_pbs_batch(fhes_ctx *ctx, int32_t count, const int32_t *term_ptr, const int32_t *term_idx,
+                   const int64_t *term_coef, const uint64_t *consts, const int32_t *lut_ids,
+                   const int32_t *out_handles) {
+  if (!ctx || !lut_ids) return fail(FHES_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  DevNodeArrays a;
+  int rc = stage_desc(ctx, count, term_ptr, term_idx, term_coef, consts, lut_ids, out_handles, &a);
+  if (rc) return rc;
+  return launch_pbs(ctx, a, 0, count);
+}
+
+int fhes_linear_batch(fhes_ctx *ctx, int32_t count, const int32_t *term_ptr, const int32_t *term_idx,
+                      const int64_t *term_coef, const uint64_t *consts, const int32_t *out_handles) {
+  if (!ctx) return fail(FHES_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  DevNodeArrays a;
+  int rc = stage_desc(ctx, count, term_ptr, term_idx, term_coef, consts, nullptr, out_handles, &a);
+  if (rc) return rc;
+  return launch_linear(ctx, a, 0, count);
+}
+
+int fhes_sync(fhes_ctx *ctx) {
+  if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
+  FHES_HIP(hipSetDevice(ctx->device));
+  FHES_HIP(hipStreamSynchronize(ctx->stream));
+  return FHES_OK;
+}
+
+int fhes_get_stats(fhes_ctx *ctx, fhes_stats *out) {
+  if (!ctx || !out) return fail(FHES_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->stats.arena_capacity = (uint64_t)ctx->capacity;
+  ctx->stats.arena_in_use = (uint64_t)ctx->in_use;
+  *out = ctx->stats;
+  return FHES_OK;
+}
+
+int fhes_reset_stats(fhes_ctx *ctx) {
+  if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->stats = fhes_stats{};
+  return FHES_OK;
+}
+
+int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
+  if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
+  ctx->timing = enabled != 0;
+  return FHES_OK;
+}
+
+int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
+  if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
+  ctx->br_variant = v;
+  return FHES_OK;
+}
+
+int fhes_debug_bsk_fourier(fhes_ctx *ctx, double *out) {
+  if (!ctx || !out) return fail(FHES_ERR_INVALID, "null argument");
+  if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
+  FHES_HIP(hipSetDevice(ctx->device));
+  FHES_HIP(hipMemcpy(out, ctx->bsk_f, (size_t)ctx->dims.n * 4 * ctx->dims.M * 16, hipMemcpyDeviceToHost));
+  return FHES_OK;
+}
+
+int fhes_debug_fft_tables(const fhes_params *p, double *twist, double *tw) {
+  if (!p || !twist || !tw) return fail(FHES_ERR_INVALID, "null argument");
+  std::vector<double> a, b;
+  host_fft_tables(p->poly_size, a, b);
+  memcpy(twist, a.data(), a.size() * 8);
+  memcpy(tw, b.data(), b.size() * 8);
+  return FHES_OK;
+}
+
+int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles, uint32_t *a_tilde) {
+  if (!ctx || !in_handles || !a_tilde || count <= 0) return fail(FHES_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
+  std::vector<int32_t> tp(count + 1), ti(count), lut(count, 0), out(in_handles, in_handles + count);
+  std::vector<int64_t> tc(count, 1);
+  std::vector<uint64_t> cs(count, 0);
+  for (int i = 0; i <= count; i++) tp[i] = i;
+  for (int i = 0; i < count; i++) ti[i] = in_handles[i];
+  DevNodeArrays a;
+  int rc = stage_desc(ctx, count, tp.data(), ti.data(), tc.data(), cs.data(), nullptr, out.data(), &a);
+  if (rc) return rc;
+  rc = ensure_ks_out(ctx, count);
+  if (rc) return rc;
+  dev::NodeDesc d = make_desc(a, 0, count);
+  rc = launch_keyswitch(ctx, d);
+  if (rc) return rc;
+  std::vector<uint64_t> h((size_t)count * ctx->ks_stride);
+  FHES_HIP(hipStreamSynchronize(ctx->stream));
+  FHES_HIP(hipMemcpy(h.data(), ctx->ks_out, h.size() * 8, hipMemcpyDeviceToHost));
+  int lg = 0;
+  while ((1 << lg) < 2 * ctx->dims.N) lg++;
+  for (int c = 0; c < count; c++)
+    for (int j = 0; j <= ctx->dims.n; j++)
+      a_tilde[(size_t)c * (ctx->dims.n + 1) + j] =
+          (uint32_t)((((h[(size_t)c * ctx->ks_stride + j] >> (64 - lg - 1)) + 1) >> 1) & (uint64_t)(2 * ctx->dims.N - 1));
+  return FHES_OK;
+}
+
+}  // extern "C"

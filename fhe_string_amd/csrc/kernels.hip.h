@@ -1,0 +1,414 @@
+// kernels.hip.h -- gfx950 device code for the PBS hot path.
+//
+// Replaces, for the reference's `k.k.*_parallelized` call sites
+// (/root/reference/src/ciphertext/compare.rs:130-132, mod.rs:345-348, logic.rs:15,24,49,63),
+// what tfhe-rs executes per shortint lookup: keyswitch -> modulus switch -> blind
+// rotate (n CMUX with the external product in the f64 Fourier domain) -> sample
+// extract.  The arithmetic follows the canonical op sequence of DESIGN.md section 4
+// (same as oracle/tfhe_oracle.c), so outputs are bit-identical to the oracle:
+//   * radix-2 DIF forward / DIT inverse FFT of N/2 complex points, twiddles from
+//     tables, complex multiply = {mul, fma, mul, fma} exactly as written below;
+//   * -ffp-contract=off: every FMA is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fhes {
+namespace dev {
+
+// ------------------------------------------------------------------------------------------
+// canonical scalar helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 w) {
+  double2 r;
+  r.x = __builtin_fma(a.x, w.x, -(a.y * w.y));
+  r.y = __builtin_fma(a.x, w.y, a.y * w.x);
+  return r;
+}
+__device__ __forceinline__ double2 cmul_conj(double2 a, double2 w) {
+  double2 r;
+  r.x = __builtin_fma(a.x, w.x, a.y * w.y);
+  r.y = __builtin_fma(a.y, w.x, -(a.x * w.y));
+  return r;
+}
+// exact rint(y) mod 2^64 for |y| < 2^100
+__device__ __forceinline__ uint64_t torus_from_f64(double y) {
+  const double t = y * 0x1p-64;
+  const double kq = __builtin_floor(t + 0.5);
+  const double z = __builtin_fma(kq, -0x1p64, y);
+  const double r = __builtin_rint(z);
+  const double h = __builtin_floor(r * 0x1p-32);
+  const double l = __builtin_fma(h, -0x1p32, r);
+  const int hi = (int)h;
+  const unsigned lo = (unsigned)l;
+  return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)lo;
+}
+// correctly rounded int64 -> f64 (single rounding)
+__device__ __forceinline__ double i64_to_f64(uint64_t v) {
+  const int hi = (int)(v >> 32);
+  const unsigned lo = (unsigned)v;
+  return __builtin_fma((double)hi, 0x1p32, (double)lo);
+}
+// one-level closest-representable signed digit (base 2^BL) as f64
+template <int BL>
+__device__ __forceinline__ double digit1_f64(uint64_t x) {
+  const uint32_t v = (uint32_t)(((x >> (64 - BL - 1)) + 1) >> 1);
+  const int d = ((int)(v << (32 - BL))) >> (32 - BL);  // sign-extend BL bits
+  return (double)d;
+}
+// (X^a * p)[j] for a in [1, 2N), polynomial in LDS/global
+template <int N>
+__device__ __forceinline__ uint64_t rot_read(const uint64_t *p, int a, int j) {
+  const int s = (j - a) & (2 * N - 1);
+  const uint64_t v = p[s & (N - 1)];
+  return (s >= N) ? (uint64_t)0 - v : v;
+}
+
+// ------------------------------------------------------------------------------------------
+// FFT passes.  M = 2^LOGM complex points handled by TP = M/8 threads, 8 points per
+// thread.  A pass owns index bits [LO, LO+NB): it performs the radix-2 stages of those
+// bits in registers; passes exchange data through LDS.
+// ------------------------------------------------------------------------------------------
+template <int LOGM, int LO, int NB>
+__device__ __forceinline__ int fft_point(int q, int e) {
+  constexpr int LOGTP = LOGM - 3;
+  const int f = e & ((1 << NB) - 1), g = e >> NB;
+  const int rest = (g << LOGTP) | q;
+  return ((rest >> LO) << (LO + NB)) | (f << LO) | (rest & ((1 << LO) - 1));
+}
+
+template <int LOGM, bool FWD, int LO, int NB>
+__device__ __forceinline__ void fft_butterflies(double2 (&x)[8], int q,
+                                                const double2 *__restrict__ tw) {
+#pragma unroll
+  for (int st = 0; st < NB; ++st) {
+    const int fb = FWD ? (NB - 1 - st) : st;
+    const int beta = LO + fb;           // absolute index bit of this stage
+    const int sh = LOGM - 1 - beta;     // twiddle stride = 2^sh
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e & (1 << fb)) continue;
+      const int e1 = e | (1 << fb);
+      const double2 u = x[e], v = x[e1];
+      if (beta == 0) {  // twiddle index 0: exactly 1
+        x[e] = make_double2(u.x + v.x, u.y + v.y);
+        x[e1] = make_double2(u.x - v.x, u.y - v.y);
+      } else {
+        const int p = fft_point<LOGM, LO, NB>(q, e);
+        const double2 w = tw[(p & ((1 << beta) - 1)) << sh];
+        if (FWD) {
+          const double2 d = make_double2(u.x - v.x, u.y - v.y);
+          x[e] = make_double2(u.x + v.x, u.y + v.y);
+          x[e1] = cmul(d, w);
+        } else {
+          const double2 vv = cmul_conj(v, w);
+          x[e] = make_double2(u.x + vv.x, u.y + vv.y);
+          x[e1] = make_double2(u.x - vv.x, u.y - vv.y);
+        }
+      }
+    }
+  }
+}
+
+template <int LOGM>
+struct FftPlan {
+  static constexpr int NB_LAST = (LOGM % 3 == 0) ? 3 : (LOGM % 3);  // pass that owns bit 0
+  static constexpr int LO_FIRST = LOGM - 3;                          // first forward pass
+};
+
+// forward: x holds the points of pass (LO = HI-NB); ends with the spectrum in `buf`
+// (canonical bit-reversed order, position == in-place index) and a barrier.
+template <int LOGM, int HI>
+__device__ __forceinline__ void fft_forward(double2 (&x)[8], int q, double2 *buf,
+                                            const double2 *__restrict__ tw) {
+  constexpr int NB = HI >= 3 ? 3 : HI;
+  constexpr int LO = HI - NB;
+  fft_butterflies<LOGM, true, LO, NB>(x, q, tw);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) buf[fft_point<LOGM, LO, NB>(q, e)] = x[e];
+  __syncthreads();
+  if constexpr (LO > 0) {
+    constexpr int NB2 = LO >= 3 ? 3 : LO;
+    constexpr int LO2 = LO - NB2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = buf[fft_point<LOGM, LO2, NB2>(q, e)];
+    fft_forward<LOGM, LO>(x, q, buf, tw);
+  }
+}
+
+// inverse: x holds the spectrum points of pass (LO, NB); ends with natural-order data of
+// the pass (LOGM-3, 3) in registers (no trailing barrier).
+template <int LOGM, int LO, int NB>
+__device__ __forceinline__ void fft_inverse(double2 (&x)[8], int q, double2 *buf,
+                                            const double2 *__restrict__ tw) {
+  fft_butterflies<LOGM, false, LO, NB>(x, q, tw);
+  if constexpr (LO + NB < LOGM) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf[fft_point<LOGM, LO, NB>(q, e)] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = buf[fft_point<LOGM, LO + NB, 3>(q, e)];
+    fft_inverse<LOGM, LO + NB, 3>(x, q, buf, tw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: standard-domain BSK polynomial -> canonical Fourier spectrum
+// grid = number of polynomials, block = M/8 threads, dyn LDS = M * 16 bytes
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ void bsk_to_fourier_kernel(const uint64_t *__restrict__ bsk, double2 *__restrict__ out,
+                                      const double2 *__restrict__ twist,
+                                      const double2 *__restrict__ tw) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double2 *buf = reinterpret_cast<double2 *>(smem_raw);
+  const int q = threadIdx.x;
+  const uint64_t *poly = bsk + (size_t)blockIdx.x * N;
+  double2 x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);
+    const double2 a = make_double2(i64_to_f64(poly[p]), i64_to_f64(poly[p + M]));
+    x[e] = cmul(a, twist[p]);
+  }
+  fft_forward<LOGM, LOGM>(x, q, buf, tw);
+  double2 *dst = out + (size_t)blockIdx.x * M;
+  for (int p = q; p < M; p += blockDim.x) dst[p] = buf[p];
+}
+
+// ------------------------------------------------------------------------------------------
+// node descriptors shared by the batched kernels
+// ------------------------------------------------------------------------------------------
+struct NodeDesc {
+  const int32_t *term_ptr;   // [nodes+1]
+  const int32_t *term_idx;   // slot (or arena handle if slot_map == nullptr)
+  const int64_t *term_coef;
+  const uint64_t *consts;    // raw torus word added to the body
+  const int32_t *lut_ids;
+  const int32_t *out_idx;    // slot / handle
+  const int32_t *slot_map;   // optional slot -> arena handle
+  int32_t first;             // first node of this launch
+  int32_t count;             // nodes in this launch
+};
+
+__device__ __forceinline__ int32_t resolve(const NodeDesc &d, int32_t s) {
+  return d.slot_map ? d.slot_map[s] : s;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: batched keyswitch (big LWE -> small LWE) of linear combinations.
+// grid = (tiles of TB nodes, splits of the mask range); block = 256 threads.
+// Each thread accumulates JPT output words for TB ciphertexts; partial sums over the
+// mask split are combined with u64 atomics (integer adds commute: deterministic).
+// ks_out [count][ks_stride] must be zero on entry.
+// ------------------------------------------------------------------------------------------
+constexpr int KS_TB = 8;     // ciphertexts per block
+constexpr int KS_IC = 64;    // mask coefficients staged per chunk
+constexpr int KS_MAXLV = 8;  // ks_level limit
+
+template <int JPT>
+__global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64_t *__restrict__ arena,
+                                                        int ct_stride, int big,
+                                                        const uint64_t *__restrict__ ksk,
+                                                        int ks_level, int ks_base_log, int ks_stride,
+                                                        int n_small, int coeffs_per_split,
+                                                        uint64_t *__restrict__ ks_out) {
+  __shared__ __attribute__((aligned(8))) int8_t dig[KS_IC][KS_MAXLV][KS_TB];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int i_begin = blockIdx.y * coeffs_per_split;
+  const int i_end = i_begin + coeffs_per_split;
+  const int node0 = d.first + tile * KS_TB;
+  const int nodes_here = min(KS_TB, d.first + d.count - node0);
+  const int total = ks_level * ks_base_log;
+  const int B = 1 << ks_base_log;
+
+  uint64_t acc[KS_TB][JPT];
+#pragma unroll
+  for (int b = 0; b < KS_TB; ++b)
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) acc[b][q] = 0;
+
+  for (int chunk = i_begin; chunk < i_end; chunk += KS_IC) {
+    // stage the digits of KS_TB x KS_IC mask coefficients
+    for (int idx = tid; idx < KS_TB * KS_IC; idx += 256) {
+      const int b = idx / KS_IC, ii = idx % KS_IC;
+      uint64_t x = 0;
+      if (b < nodes_here) {
+        const int node = node0 + b;
+        for (int t = d.term_ptr[node]; t < d.term_ptr[node + 1]; ++t) {
+          const uint64_t *src = arena + (size_t)resolve(d, d.term_idx[t]) * ct_stride;
+          x += (uint64_t)d.term_coef[t] * src[chunk + ii];
+        }
+      }
+      uint32_t v = (uint32_t)((((x >> (64 - total - 1)) + 1) >> 1) & ((1ull << total) - 1));
+      for (int l = ks_level - 1; l >= 0; --l) {
+        int dd = (int)(v & (uint32_t)(B - 1));
+        v >>= ks_base_log;
+        if (dd >= B / 2) { dd -= B; v += 1; }
+        dig[ii][l][b] = (int8_t)dd;
+      }
+    }
+    __syncthreads();
+    for (int ii = 0; ii < KS_IC; ++ii) {
+      const uint64_t *krow = ksk + ((size_t)(chunk + ii) * ks_level) * ks_stride;
+      for (int l = 0; l < ks_level; ++l) {
+        uint64_t kv[JPT];
+#pragma unroll
+        for (int q = 0; q < JPT; ++q) kv[q] = krow[(size_t)l * ks_stride + tid + 256 * q];
+        const uint64_t packed = *reinterpret_cast<const uint64_t *>(&dig[ii][l][0]);
+#pragma unroll
+        for (int b = 0; b < KS_TB; ++b) {
+          const int64_t dd = (int64_t)(int8_t)(packed >> (8 * b));
+#pragma unroll
+          for (int q = 0; q < JPT; ++q) acc[b][q] -= (uint64_t)dd * kv[q];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int b = 0; b < KS_TB; ++b) {
+    if (b >= nodes_here) break;
+    const int node = node0 + b;
+    uint64_t *dst = ks_out + (size_t)(node - d.first) * ks_stride;
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) {
+      const int j = tid + 256 * q;
+      uint64_t v = acc[b][q];
+      if (j == n_small && blockIdx.y == 0) {  // body of the input combination
+        uint64_t body = d.consts[node];
+        for (int t = d.term_ptr[node]; t < d.term_ptr[node + 1]; ++t) {
+          const uint64_t *src = arena + (size_t)resolve(d, d.term_idx[t]) * ct_stride;
+          body += (uint64_t)d.term_coef[t] * src[big];
+        }
+        v += body;
+      }
+      if (j <= n_small && v != 0) atomicAdd(reinterpret_cast<unsigned long long *>(dst + j), (unsigned long long)v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: materialise linear combinations.  grid = nodes, block = 256.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_kernel(NodeDesc d, uint64_t *__restrict__ arena,
+                                                     int ct_stride, int big) {
+  const int node = d.first + blockIdx.x;
+  uint64_t *dst = arena + (size_t)resolve(d, d.out_idx[node]) * ct_stride;
+  const int t0 = d.term_ptr[node], t1 = d.term_ptr[node + 1];
+  for (int j = threadIdx.x; j <= big; j += blockDim.x) {
+    uint64_t x = (j == big) ? d.consts[node] : 0;
+    for (int t = t0; t < t1; ++t)
+      x += (uint64_t)d.term_coef[t] * arena[(size_t)resolve(d, d.term_idx[t]) * ct_stride + j];
+    dst[j] = x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2+K3 (variant 1): blind rotate + sample extract, one workgroup (2 * M/8 threads) per
+// ciphertext, k = 1, pbs_level = 1.  LDS: acc u64[2][N] | fbuf double2[2][M] | a_tilde.
+// ------------------------------------------------------------------------------------------
+template <int LOGN, int BL>
+__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) void blind_rotate_v1_kernel(NodeDesc d, uint64_t *__restrict__ arena, int ct_stride,
+                                       const uint64_t *__restrict__ ks_out, int ks_stride,
+                                       int n_small, const double2 *__restrict__ bsk_f,
+                                       const uint64_t *__restrict__ lut_polys,
+                                       const double2 *__restrict__ twist,
+                                       const double2 *__restrict__ tw) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
+  constexpr int NB0 = FftPlan<LOGM>::NB_LAST;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N]
+  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][M]
+  uint32_t *at = reinterpret_cast<uint32_t *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16);
+
+  const int tid = threadIdx.x;
+  const int r = tid / TP;  // polynomial handled by this half of the workgroup
+  const int q = tid % TP;
+  const int node = d.first + blockIdx.x;
+
+  // ---- modulus switch to Z_{2N} ----
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  for (int j = tid; j <= n_small; j += blockDim.x)
+    at[j] = (uint32_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  __syncthreads();
+
+  // ---- acc = (0, X^{-b~} * LUT) ----
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
+    for (int j = tid; j < N; j += blockDim.x) {
+      acc[j] = 0;
+      acc[N + j] = (t == 0) ? lut[j] : rot_read<N>(lut, t, j);
+    }
+  }
+  __syncthreads();
+
+  uint64_t *acc_r = acc + (size_t)r * N;
+  double2 *buf_r = fbuf + (size_t)r * M;
+  const double scale = 1.0 / (double)M;
+
+  for (int i = 0; i < n_small; ++i) {
+    const int a = (int)at[i];
+    if (a == 0) continue;  // X^0*acc - acc == 0: exact no-op (uniform branch)
+
+    // ---- diff -> digit -> twist, in the layout of the first forward pass ----
+    double2 x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);
+      const uint64_t d0 = rot_read<N>(acc_r, a, p) - acc_r[p];
+      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - acc_r[p + M];
+      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twist[p]);
+    }
+    fft_forward<LOGM, LOGM>(x, q, buf_r, tw);  // ends with a barrier: both spectra in fbuf
+
+    // ---- external product: O_r = D_0 * G[0][r] + D_1 * G[1][r] ----
+    const double2 *G = bsk_f + (size_t)i * 4 * M;  // [row][col][M]
+    double2 d0v[8], d1v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, 0, NB0>(q, e);
+      d0v[e] = fbuf[p];
+      d1v[e] = fbuf[M + p];
+    }
+    __syncthreads();  // every thread has its operands: fbuf may be overwritten
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, 0, NB0>(q, e);
+      const double2 g0 = G[(size_t)(0 * 2 + r) * M + p];
+      const double2 g1 = G[(size_t)(1 * 2 + r) * M + p];
+      double re = d0v[e].x * g0.x;
+      double im = d0v[e].x * g0.y;
+      re = __builtin_fma(-d0v[e].y, g0.y, re);
+      im = __builtin_fma(d0v[e].y, g0.x, im);
+      re = __builtin_fma(d1v[e].x, g1.x, re);
+      im = __builtin_fma(d1v[e].x, g1.y, im);
+      re = __builtin_fma(-d1v[e].y, g1.y, re);
+      im = __builtin_fma(d1v[e].y, g1.x, im);
+      x[e] = make_double2(re, im);
+    }
+    fft_inverse<LOGM, 0, NB0>(x, q, buf_r, tw);
+
+    // ---- untwist, round to the torus, accumulate ----
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);
+      const double2 v = cmul_conj(x[e], twist[p]);
+      acc_r[p] += torus_from_f64(v.x * scale);
+      acc_r[p + M] += torus_from_f64(v.y * scale);
+    }
+    __syncthreads();
+  }
+
+  // ---- sample extract (constant coefficient) ----
+  uint64_t *out = arena + (size_t)resolve(d, d.out_idx[node]) * ct_stride;
+  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
+  if (tid == 0) out[N] = acc[N];
+}
+
+}  // namespace dev
+}  // namespace fhes

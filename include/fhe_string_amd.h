@@ -1,0 +1,211 @@
+/*
+ * fhe_string_amd.h -- C ABI of the MI355X-native encrypted-string engine.
+ *
+ * This is the drop-in boundary for the reference's hot path.  In the reference
+ * (matthiasgeihs/fhe_string) every string operation is a circuit over the methods
+ * of `ServerKey.k : tfhe::integer::ServerKey` (/root/reference/src/server_key.rs:13);
+ * each of those methods bottoms out in batches of shortint programmable
+ * bootstraps.  The ABI has three levels:
+ *
+ *   Level 0  kernel boundary: device context, key upload, LUT registry, ciphertext
+ *            arena, `fhes_pbs_batch` (linear combination -> keyswitch -> blind
+ *            rotate -> sample extract) and `fhes_linear_batch`.
+ *            Replaces tfhe's `apply_lookup_table` as invoked under every
+ *            `k.k.*_parallelized` call site (e.g. compare.rs:130-132,
+ *            mod.rs:345-348, logic.rs:15,24,49,63).
+ *   Level 1  circuit submit: a compiled, level-scheduled program (static shapes)
+ *            executed with one batched launch pair per level.
+ *   Level 2  the reference's own API surface, 1:1:  generate_keys / ClientKey /
+ *            ServerKey / FheString / FheUsize / FheOption / FheStringSliceVector
+ *            (/root/reference/src/lib.rs:34-89 and Appendix C of SURVEY.md).
+ *
+ * All entry points are `extern "C"`, take plain pointers/sizes, return `int`
+ * status (0 = ok, negative = error; `fhes_last_error()` gives the message) or an
+ * opaque handle (NULL on error).  No exceptions cross the boundary.
+ * Homomorphic entry points FAIL (never fall back to the CPU) when no HIP device
+ * is present.
+ */
+#ifndef FHE_STRING_AMD_H
+#define FHE_STRING_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHES_OK 0
+#define FHES_ERR_INVALID -1      /* bad argument                                   */
+#define FHES_ERR_NO_DEVICE -2    /* no HIP device / HIP runtime failure            */
+#define FHES_ERR_UNSUPPORTED -3  /* parameter set not supported by the HIP kernels */
+#define FHES_ERR_OOM -4
+#define FHES_ERR_STATE -5        /* e.g. keys not uploaded                         */
+/* FheString::new validation errors (/root/reference/src/ciphertext/mod.rs:59-70) */
+#define FHES_ERR_NOT_ASCII -10
+#define FHES_ERR_HAS_TERMINATOR -11
+#define FHES_ERR_TOO_LONG -12
+#define FHES_ERR_PAD_TOO_LONG -13
+#define FHES_ERR_PAD_TOO_SHORT -14
+
+/* ---- parameters (tfhe ClassicPBSParameters; /root/reference/src/lib.rs:45,50) ---------- */
+typedef struct fhes_params {
+  int32_t lwe_dim;       /* n   */
+  int32_t glwe_dim;      /* k   */
+  int32_t poly_size;     /* N   */
+  int32_t pbs_base_log;
+  int32_t pbs_level;
+  int32_t ks_base_log;
+  int32_t ks_level;
+  int32_t message_bits;  /* log2(message_modulus) */
+  int32_t carry_bits;    /* log2(carry_modulus)   */
+  double lwe_noise_std;
+  double glwe_noise_std;
+} fhes_params;
+
+/* PARAM_MESSAGE_2_CARRY_2_KS_PBS (the set the reference fixes at lib.rs:45). */
+int fhes_params_default(fhes_params *out);
+/* Small set for CPU-only tests (N=256, n=48, tiny noise).  Not secure. */
+int fhes_params_toy(fhes_params *out);
+/* Words of one big-key LWE ciphertext (k*N + 1). */
+int64_t fhes_ct_words(const fhes_params *p);
+int64_t fhes_bsk_words(const fhes_params *p);
+int64_t fhes_ksk_words(const fhes_params *p);
+
+/* thread-local message of the last failing call on this thread */
+const char *fhes_last_error(void);
+
+/* ============================ client side (host CPU) ====================================
+ * Mirrors `generate_keys_with_params` (lib.rs:50-77) and `ClientKey`
+ * (client_key.rs:15-62).  Key generation and (de)encryption are client-side in the
+ * reference too and are not part of the accelerated path. */
+typedef struct fhes_client_key fhes_client_key;
+
+/* `l` = maximum string length (lib.rs:50); seed == 0 -> OS entropy. */
+fhes_client_key *fhes_client_key_generate(const fhes_params *p, uint64_t l, uint64_t seed);
+void fhes_client_key_destroy(fhes_client_key *ck);
+int fhes_client_key_params(const fhes_client_key *ck, fhes_params *out);
+int32_t fhes_client_key_num_blocks_char(const fhes_client_key *ck);   /* lib.rs:60-61 */
+int32_t fhes_client_key_num_blocks_usize(const fhes_client_key *ck);  /* lib.rs:62    */
+/* secret keys as 0/1 words (tests / oracle checks only) */
+const uint64_t *fhes_client_key_big_sk(const fhes_client_key *ck);    /* [k*N] */
+const uint64_t *fhes_client_key_small_sk(const fhes_client_key *ck);  /* [n]   */
+/* Server key material in the standard domain:
+ *   bsk u64 [n][pbs_level][k+1][k+1][N],  ksk u64 [k*N][ks_level][n+1]           */
+int fhes_client_key_make_server_keys(const fhes_client_key *ck, uint64_t *bsk, uint64_t *ksk);
+/* Encrypt `count` shortint blocks (values < 2^(message_bits+carry_bits)) under the
+ * big key; out is [count][k*N+1]. */
+int fhes_client_encrypt_blocks(fhes_client_key *ck, const uint8_t *values, int64_t count,
+                               uint64_t *out);
+/* Decode `count` blocks to their value in [0, 2^(message_bits+carry_bits+1)). */
+int fhes_client_decrypt_blocks(const fhes_client_key *ck, const uint64_t *cts, int64_t count,
+                               uint8_t *values);
+
+/* ============================ Level 0: device engine ==================================== */
+typedef struct fhes_ctx fhes_ctx;
+
+typedef struct fhes_stats {
+  uint64_t pbs_count;        /* bootstraps executed on the device                   */
+  uint64_t pbs_launches;     /* blind-rotate kernel launches                        */
+  uint64_t linear_count;     /* materialised linear combinations                    */
+  uint64_t arena_capacity;   /* ciphertext slots                                    */
+  uint64_t arena_in_use;
+  double last_ks_ms;         /* HIP-event duration of the last keyswitch launch     */
+  double last_br_ms;         /* HIP-event duration of the last blind-rotate launch  */
+  double total_ks_ms;        /* accumulated while timing is enabled                 */
+  double total_br_ms;
+} fhes_stats;
+
+fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device);
+void fhes_ctx_destroy(fhes_ctx *ctx);
+/* BSK is transformed to the Fourier domain on the device (kernel bsk_to_fourier). */
+int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk);
+/* Register f: [0,2^(msg+carry)) -> [0,2^(msg+carry)); returns lut id >= 0. */
+int32_t fhes_lut_register(fhes_ctx *ctx, const uint64_t *table, int32_t n_entries);
+/* Ciphertext arena: contiguous handle ranges of big-key LWE ciphertexts. */
+int32_t fhes_arena_alloc(fhes_ctx *ctx, int32_t count);
+int fhes_arena_free(fhes_ctx *ctx, int32_t first, int32_t count);
+int fhes_arena_upload(fhes_ctx *ctx, int32_t first, int32_t count, const uint64_t *host);
+int fhes_arena_download(fhes_ctx *ctx, int32_t first, int32_t count, uint64_t *host);
+/* out[j] = PBS_lut[j]( sum_t coef[t]*ct[idx[t]] + consts[j] )   (one batched launch pair)
+ * consts are raw torus words added to the body. */
+int fhes_pbs_batch(fhes_ctx *ctx, int32_t count, const int32_t *term_ptr,
+                   const int32_t *term_idx, const int64_t *term_coef, const uint64_t *consts,
+                   const int32_t *lut_ids, const int32_t *out_handles);
+int fhes_linear_batch(fhes_ctx *ctx, int32_t count, const int32_t *term_ptr,
+                      const int32_t *term_idx, const int64_t *term_coef, const uint64_t *consts,
+                      const int32_t *out_handles);
+int fhes_sync(fhes_ctx *ctx);
+int fhes_get_stats(fhes_ctx *ctx, fhes_stats *out);
+int fhes_reset_stats(fhes_ctx *ctx);
+/* enable per-launch HIP-event timing (used by bench.py for the roofline object) */
+int fhes_set_timing(fhes_ctx *ctx, int32_t enabled);
+/* kernel variant selection for A/B benchmarking: 0 = auto */
+int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t br_variant);
+/* test hooks: Fourier BSK in the oracle's canonical order [n][L][k+1][k+1][N/2][2];
+ * FFT tables twist[N/2][2], twiddle[N/4][2]. */
+int fhes_debug_bsk_fourier(fhes_ctx *ctx, double *out);
+int fhes_debug_fft_tables(const fhes_params *p, double *twist, double *twiddle);
+/* test hook: keyswitch+modswitch only; a_tilde out is [count][n+1] u32 */
+int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles,
+                         uint32_t *a_tilde);
+
+/* ============================ Level 1: compiled circuits ================================ */
+typedef struct fhes_program fhes_program;
+
+/* Compile a string operation for static shapes (host only, no device needed).
+ *   op: "find" "rfind" "contains" "starts_with" "ends_with" "eq" "ne" "lt" "le" "gt"
+ *       "ge" "is_empty" "len" "split" ... (see fhe_string_amd/csrc/circuit/ops.cpp)
+ *   shape: op-specific (slot counts of the operands), n_shape entries
+ *   num_blocks_usize: lib.rs:62 */
+fhes_program *fhes_program_compile(const fhes_params *p, const char *op, const int32_t *shape,
+                                   int32_t n_shape, int32_t num_blocks_usize);
+void fhes_program_destroy(fhes_program *prog);
+/* sizes: [0]=n_inputs [1]=n_outputs [2]=n_nodes [3]=n_levels [4]=n_terms [5]=n_luts
+ *        [6]=n_slots (inputs + node outputs) [7]=n_pbs */
+int fhes_program_info(const fhes_program *prog, int64_t info[8]);
+/* Export for execution elsewhere (tests run programs on the oracle / a plaintext model).
+ * Slot numbering: inputs are slots [0,n_inputs); node j writes slot out_idx[j]. */
+int fhes_program_export(const fhes_program *prog, int32_t *level_ptr, int32_t *term_ptr,
+                        int32_t *term_idx, int64_t *term_coef, uint64_t *consts,
+                        int32_t *lut_ids, int32_t *out_idx, uint64_t *lut_tables /*[n_luts][16]*/,
+                        int32_t *out_slots /*[n_outputs], -1 = trivial*/,
+                        uint64_t *out_trivial /*[n_outputs] message value if trivial*/);
+/* Run on the device: inputs are arena handles (n_inputs), outputs are freshly
+ * allocated arena handles (n_outputs). */
+int fhes_program_run(fhes_ctx *ctx, const fhes_program *prog, const int32_t *in_handles,
+                     int32_t *out_handles);
+
+/* ============================ Level 2: reference API mirror ============================= */
+typedef struct fhes_server_key fhes_server_key; /* ServerKey (server_key.rs:11-17) */
+typedef struct fhes_ct fhes_ct;                 /* radix ciphertext: FheString / FheUsize /
+                                                   BooleanBlock / RadixCiphertext payload */
+
+/* generate_keys_with_params's server half: builds BSK/KSK and uploads them. */
+fhes_server_key *fhes_server_key_create(const fhes_client_key *ck, int32_t device);
+void fhes_server_key_destroy(fhes_server_key *sk);
+fhes_ctx *fhes_server_key_ctx(fhes_server_key *sk);
+
+/* FheString::new (mod.rs:58-92).  pad < 0 means None.  Returns NULL and sets
+ * *status to one of FHES_ERR_NOT_ASCII.. on validation failure. */
+fhes_ct *fhes_string_encrypt(fhes_client_key *ck, const char *s, int64_t pad, int32_t *status);
+/* FheString::new_trivial (mod.rs:96-119) */
+fhes_ct *fhes_string_trivial(const fhes_server_key *sk, const char *s, int32_t *status);
+/* FheUsize::new (mod.rs:406) */
+fhes_ct *fhes_usize_encrypt(fhes_client_key *ck, uint64_t v);
+void fhes_ct_destroy(fhes_ct *ct);
+int32_t fhes_ct_num_blocks(const fhes_ct *ct);
+/* decrypt: FheString::decrypt (mod.rs:121-129) -> NUL-terminated into buf */
+int fhes_string_decrypt(const fhes_client_key *ck, fhes_ct *s, char *buf, int64_t buf_len);
+int fhes_usize_decrypt(const fhes_client_key *ck, fhes_ct *v, uint64_t *out);
+int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out);
+
+/* Generic operation dispatch: op names as in fhes_program_compile.  `args` are the
+ * ciphertext operands (self first), `iargs` clear integer arguments.  Results are
+ * returned in `outs` (caller destroys).  FheOption<T> returns {is_some, val}. */
+int fhes_string_op(fhes_server_key *sk, const char *op, fhes_ct *const *args, int32_t n_args,
+                   const int64_t *iargs, int32_t n_iargs, fhes_ct **outs, int32_t max_outs,
+                   int32_t *n_outs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,373 @@
+/*
+ * tfhe_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ * See tfhe_oracle.h for scope, parity status ("parity unpinned" at ciphertext
+ * level) and the reference call sites this restates.
+ *
+ * Build: gcc -O2 -mfma -mavx2 -ffp-contract=off -fopenmp -shared -fPIC
+ * (-ffp-contract=off is REQUIRED: every fused multiply-add below is an explicit
+ *  fma() so that the HIP kernels can reproduce the same IEEE-754 op sequence.)
+ */
+#include "tfhe_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  double re, im;
+} cplx;
+
+struct oracle_ctx {
+  oracle_params p;
+  int N, M, k, n, L;  /* M = N/2 complex points */
+  int big;            /* k*N */
+  cplx *twist;        /* [M]   exp(+i*pi*j/N)          */
+  cplx *tw;           /* [M/2] exp(-2*pi*i*t/M)        */
+  cplx *bsk_f;        /* [n][L][k+1][k+1][M]           */
+  uint64_t *ksk;      /* [big][ks_level][n+1]          */
+};
+
+/* ---- canonical complex arithmetic ------------------------------- */
+static inline cplx cmul(cplx a, cplx w) {
+  cplx r;
+  r.re = fma(a.re, w.re, -(a.im * w.im));
+  r.im = fma(a.re, w.im, a.im * w.re);
+  return r;
+}
+static inline cplx cmul_conj(cplx a, cplx w) { /* a * conj(w) */
+  cplx r;
+  r.re = fma(a.re, w.re, a.im * w.im);
+  r.im = fma(a.im, w.re, -(a.re * w.im));
+  return r;
+}
+
+/* DIF radix-2, natural order in, bit-reversed order out. */
+static void fft_fwd(const oracle_ctx *c, cplx *x) {
+  const int M = c->M;
+  for (int half = M / 2, stride = 1; half >= 1; half >>= 1, stride <<= 1) {
+    for (int b = 0; b < M; b += 2 * half) {
+      for (int j = 0; j < half; j++) {
+        cplx u = x[b + j], v = x[b + j + half];
+        cplx s = {u.re + v.re, u.im + v.im};
+        cplx d = {u.re - v.re, u.im - v.im};
+        x[b + j] = s;
+        x[b + j + half] = cmul(d, c->tw[j * stride]);
+      }
+    }
+  }
+}
+
+/* DIT radix-2, bit-reversed order in, natural order out (unscaled: M * identity). */
+static void fft_inv(const oracle_ctx *c, cplx *x) {
+  const int M = c->M;
+  for (int half = 1, stride = M / 2; half <= M / 2; half <<= 1, stride >>= 1) {
+    for (int b = 0; b < M; b += 2 * half) {
+      for (int j = 0; j < half; j++) {
+        cplx u = x[b + j];
+        cplx v = cmul_conj(x[b + j + half], c->tw[j * stride]);
+        cplx s = {u.re + v.re, u.im + v.im};
+        cplx d = {u.re - v.re, u.im - v.im};
+        x[b + j] = s;
+        x[b + j + half] = d;
+      }
+    }
+  }
+}
+
+/* exact: rint(y) mod 2^64 for |y| < 2^100 */
+static inline uint64_t torus_from_f64(double y) {
+  double t = y * 0x1p-64;
+  double kq = floor(t + 0.5);
+  double z = fma(kq, -0x1p64, y); /* in [-2^63, 2^63) */
+  double r = rint(z);
+  double h = floor(r * 0x1p-32); /* in [-2^31, 2^31) */
+  double l = fma(h, -0x1p32, r); /* in [0, 2^32)     */
+  int32_t hi = (int32_t)h;
+  uint32_t lo = (uint32_t)l;
+  return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)lo;
+}
+
+static void poly_fwd(const oracle_ctx *c, const int64_t *p, cplx *out) {
+  const int M = c->M;
+  for (int j = 0; j < M; j++) {
+    cplx a = {(double)p[j], (double)p[j + M]};
+    out[j] = cmul(a, c->twist[j]);
+  }
+  fft_fwd(c, out);
+}
+
+static void poly_inv(const oracle_ctx *c, cplx *spec, uint64_t *out) {
+  const int M = c->M;
+  const double scale = 1.0 / (double)M; /* power of two: exact */
+  fft_inv(c, spec);
+  for (int j = 0; j < M; j++) {
+    cplx r = cmul_conj(spec[j], c->twist[j]);
+    out[j] = torus_from_f64(r.re * scale);
+    out[j + M] = torus_from_f64(r.im * scale);
+  }
+}
+
+/* ---- context ------------------------------------------------------------------------------ */
+oracle_ctx *oracle_ctx_create(const oracle_params *p) {
+  if (!p || p->poly_size < 8 || (p->poly_size & (p->poly_size - 1))) return NULL;
+  if (p->glwe_dim < 1 || p->pbs_level < 1 || p->lwe_dim < 1) return NULL;
+  oracle_ctx *c = (oracle_ctx *)calloc(1, sizeof(*c));
+  c->p = *p;
+  c->N = p->poly_size;
+  c->M = c->N / 2;
+  c->k = p->glwe_dim;
+  c->n = p->lwe_dim;
+  c->L = p->pbs_level;
+  c->big = c->k * c->N;
+  c->twist = (cplx *)malloc(sizeof(cplx) * c->M);
+  c->tw = (cplx *)malloc(sizeof(cplx) * (c->M / 2));
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int j = 0; j < c->M; j++) {
+    long double a = pi * (long double)j / (long double)c->N;
+    c->twist[j].re = (double)cosl(a);
+    c->twist[j].im = (double)sinl(a);
+  }
+  for (int t = 0; t < c->M / 2; t++) {
+    long double a = -2.0L * pi * (long double)t / (long double)c->M;
+    c->tw[t].re = (double)cosl(a);
+    c->tw[t].im = (double)sinl(a);
+  }
+  /* exact values at the trivial angles, so that "multiply by 1 / by -i" may be
+   * skipped by an implementation without changing a single bit */
+  c->twist[0].re = 1.0; c->twist[0].im = 0.0;
+  c->tw[0].re = 1.0; c->tw[0].im = 0.0;
+  if (c->M >= 4) { c->tw[c->M / 4].re = 0.0; c->tw[c->M / 4].im = -1.0; }
+  return c;
+}
+
+void oracle_ctx_destroy(oracle_ctx *c) {
+  if (!c) return;
+  free(c->twist);
+  free(c->tw);
+  free(c->bsk_f);
+  free(c->ksk);
+  free(c);
+}
+
+int oracle_set_keys(oracle_ctx *c, const uint64_t *bsk, const uint64_t *ksk) {
+  const int kp1 = c->k + 1;
+  size_t npoly = (size_t)c->n * c->L * kp1 * kp1;
+  free(c->bsk_f);
+  free(c->ksk);
+  c->bsk_f = (cplx *)malloc(sizeof(cplx) * npoly * c->M);
+  size_t ksk_words = (size_t)c->big * c->p.ks_level * (c->n + 1);
+  c->ksk = (uint64_t *)malloc(sizeof(uint64_t) * ksk_words);
+  if (!c->bsk_f || !c->ksk) return -1;
+  memcpy(c->ksk, ksk, sizeof(uint64_t) * ksk_words);
+#pragma omp parallel for schedule(static)
+  for (long q = 0; q < (long)npoly; q++) {
+    /* BSK coefficients enter the FFT as signed 64-bit integers. */
+    poly_fwd(c, (const int64_t *)(bsk + (size_t)q * c->N), c->bsk_f + (size_t)q * c->M);
+  }
+  return 0;
+}
+
+const double *oracle_bsk_fourier(const oracle_ctx *c) { return (const double *)c->bsk_f; }
+const double *oracle_twist_table(const oracle_ctx *c) { return (const double *)c->twist; }
+const double *oracle_twiddle_table(const oracle_ctx *c) { return (const double *)c->tw; }
+
+void oracle_fft_forward_i64(const oracle_ctx *c, const int64_t *poly, double *spec) {
+  poly_fwd(c, poly, (cplx *)spec);
+}
+void oracle_fft_inverse_torus(const oracle_ctx *c, const double *spec, uint64_t *poly) {
+  cplx *tmp = (cplx *)malloc(sizeof(cplx) * c->M);
+  memcpy(tmp, spec, sizeof(cplx) * c->M);
+  poly_inv(c, tmp, poly);
+  free(tmp);
+}
+
+void oracle_negacyclic_mul_exact(const oracle_ctx *c, const int64_t *a, const uint64_t *b,
+                                 uint64_t *out) {
+  const int N = c->N;
+  for (int t = 0; t < N; t++) {
+    unsigned __int128 acc = 0;
+    for (int i = 0; i < N; i++) {
+      int j = t - i;
+      unsigned __int128 prod = (unsigned __int128)(__int128)a[i] *
+                               (unsigned __int128)(__int128)(int64_t)b[j < 0 ? j + N : j];
+      if (j < 0) acc -= prod; else acc += prod;
+    }
+    out[t] = (uint64_t)acc;
+  }
+}
+
+/* ---- LUT accumulator (tfhe shortint "generate_lookup_table") ------ */
+void oracle_make_lut_poly(const oracle_ctx *c, const uint64_t *f, uint64_t *poly) {
+  const int N = c->N;
+  const int bits = c->p.message_bits + c->p.carry_bits;
+  const int space = 1 << bits;          /* 16 */
+  const int box = N / space;            /* 128 */
+  const uint64_t delta = 1ull << (63 - bits); /* 2^59 */
+  for (int j = 0; j < N; j++) {
+    int jj = j + box / 2;
+    if (jj < N) poly[j] = f[jj / box] * delta;
+    else poly[j] = (uint64_t)0 - f[0] * delta;
+  }
+}
+
+/* ---- keyswitch ------------------------------------------------- */
+void oracle_keyswitch(const oracle_ctx *c, const uint64_t *in, uint64_t *out) {
+  const int n = c->n, big = c->big, lv = c->p.ks_level, bl = c->p.ks_base_log;
+  const int total = lv * bl;
+  for (int j = 0; j < n; j++) out[j] = 0;
+  out[n] = in[big];
+  const int64_t B = 1ll << bl;
+  for (int i = 0; i < big; i++) {
+    /* closest representable with `total` bits, then balanced digits LSB-first */
+    uint64_t v = ((in[i] >> (64 - total - 1)) + 1) >> 1;
+    v &= (1ull << total) - 1;
+    for (int l = lv - 1; l >= 0; l--) {
+      int64_t d = (int64_t)(v & (uint64_t)(B - 1));
+      v >>= bl;
+      if (d >= B / 2) { d -= B; v += 1; }
+      if (d == 0) continue;
+      const uint64_t *row = c->ksk + ((size_t)i * lv + l) * (n + 1);
+      const uint64_t du = (uint64_t)d;
+      for (int j = 0; j <= n; j++) out[j] -= du * row[j];
+    }
+  }
+}
+
+void oracle_modswitch(const oracle_ctx *c, const uint64_t *small, uint32_t *at) {
+  int log2n = 0;
+  while ((1 << log2n) < 2 * c->N) log2n++;
+  for (int j = 0; j <= c->n; j++)
+    at[j] = (uint32_t)((((small[j] >> (64 - log2n - 1)) + 1) >> 1) & (uint64_t)(2 * c->N - 1));
+}
+
+/* out = X^t * p  (t in [0, 2N)) in Z[X]/(X^N+1) */
+static void poly_rotate(int N, const uint64_t *p, int t, uint64_t *out) {
+  for (int j = 0; j < N; j++) {
+    int src = j - t;
+    int neg = 0;
+    while (src < 0) { src += N; neg ^= 1; }
+    out[j] = neg ? (uint64_t)0 - p[src] : p[src];
+  }
+}
+
+void oracle_blind_rotate(const oracle_ctx *c, const uint32_t *at, const uint64_t *lut,
+                         uint64_t *acc) {
+  const int N = c->N, M = c->M, k = c->k, kp1 = k + 1, L = c->L, n = c->n;
+  const int bl = c->p.pbs_base_log;
+  const int total = bl * L;
+  uint64_t *rot = (uint64_t *)malloc(sizeof(uint64_t) * N);
+  int64_t *dig = (int64_t *)malloc(sizeof(int64_t) * N * L);
+  cplx *D = (cplx *)malloc(sizeof(cplx) * M * kp1 * L);
+  cplx *O = (cplx *)malloc(sizeof(cplx) * M);
+  uint64_t *delta = (uint64_t *)malloc(sizeof(uint64_t) * N);
+  const int64_t B = 1ll << bl;
+
+  memset(acc, 0, sizeof(uint64_t) * N * k);
+  poly_rotate(N, lut, (2 * N - (int)at[n]) % (2 * N), acc + (size_t)k * N);
+
+  for (int i = 0; i < n; i++) {
+    const int a = (int)at[i];
+    if (a == 0) continue; /* diff == 0: exact no-op */
+    for (int cc = 0; cc < kp1; cc++) {
+      uint64_t *ac = acc + (size_t)cc * N;
+      poly_rotate(N, ac, a, rot);
+      for (int j = 0; j < N; j++) {
+        uint64_t x = rot[j] - ac[j];
+        uint64_t v = ((x >> (64 - total - 1)) + 1) >> 1;
+        v &= (1ull << total) - 1;
+        for (int l = L - 1; l >= 0; l--) {
+          int64_t d = (int64_t)(v & (uint64_t)(B - 1));
+          v >>= bl;
+          if (d >= B / 2) { d -= B; v += 1; }
+          dig[(size_t)l * N + j] = d;
+        }
+      }
+      for (int l = 0; l < L; l++) poly_fwd(c, dig + (size_t)l * N, D + ((size_t)cc * L + l) * M);
+    }
+    const cplx *G = c->bsk_f + (size_t)i * L * kp1 * kp1 * M; /* [L][row][col][M] */
+    for (int col = 0; col < kp1; col++) {
+      for (int m = 0; m < M; m++) {
+        double re = 0, im = 0;
+        int first = 1;
+        for (int row = 0; row < kp1; row++) {
+          for (int l = 0; l < L; l++) {
+            const cplx d = D[((size_t)row * L + l) * M + m];
+            const cplx g = G[(((size_t)l * kp1 + row) * kp1 + col) * M + m];
+            if (first) {
+              re = d.re * g.re;
+              im = d.re * g.im;
+              first = 0;
+            } else {
+              re = fma(d.re, g.re, re);
+              im = fma(d.re, g.im, im);
+            }
+            re = fma(-d.im, g.im, re);
+            im = fma(d.im, g.re, im);
+          }
+        }
+        O[m].re = re;
+        O[m].im = im;
+      }
+      poly_inv(c, O, delta);
+      uint64_t *ac = acc + (size_t)col * N;
+      /* NOTE: acc[col] is updated only after every diff of this iteration was taken
+       * (D holds them), so column order does not matter. */
+      for (int j = 0; j < N; j++) ac[j] += delta[j];
+    }
+  }
+  free(rot); free(dig); free(D); free(O); free(delta);
+}
+
+void oracle_sample_extract(const oracle_ctx *c, const uint64_t *glwe, uint64_t *out) {
+  const int N = c->N, k = c->k;
+  for (int cc = 0; cc < k; cc++) {
+    const uint64_t *a = glwe + (size_t)cc * N;
+    out[(size_t)cc * N] = a[0];
+    for (int j = 1; j < N; j++) out[(size_t)cc * N + j] = (uint64_t)0 - a[N - j];
+  }
+  out[(size_t)k * N] = glwe[(size_t)k * N];
+}
+
+void oracle_pbs(const oracle_ctx *c, const uint64_t *in, const uint64_t *lut, uint64_t *out) {
+  uint64_t *small = (uint64_t *)malloc(sizeof(uint64_t) * (c->n + 1));
+  uint32_t *at = (uint32_t *)malloc(sizeof(uint32_t) * (c->n + 1));
+  uint64_t *glwe = (uint64_t *)malloc(sizeof(uint64_t) * (c->k + 1) * c->N);
+  oracle_keyswitch(c, in, small);
+  oracle_modswitch(c, small, at);
+  oracle_blind_rotate(c, at, lut, glwe);
+  oracle_sample_extract(c, glwe, out);
+  free(small); free(at); free(glwe);
+}
+
+int oracle_exec_levels(const oracle_ctx *c, uint64_t *arena, size_t stride, int32_t n_levels,
+                       const int32_t *level_ptr, const int32_t *term_ptr,
+                       const int32_t *term_idx, const int64_t *term_coef,
+                       const uint64_t *consts, const int32_t *lut_ids,
+                       const uint64_t *lut_polys, const int32_t *out_idx, int32_t n_threads) {
+  const int W = c->big + 1;
+  if (n_threads < 1) n_threads = 1;
+  for (int lv = 0; lv < n_levels; lv++) {
+    const int lo = level_ptr[lv], hi = level_ptr[lv + 1];
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int j = lo; j < hi; j++) {
+      uint64_t *x = (uint64_t *)calloc((size_t)W, sizeof(uint64_t));
+      for (int t = term_ptr[j]; t < term_ptr[j + 1]; t++) {
+        const uint64_t *src = arena + (size_t)term_idx[t] * stride;
+        const uint64_t cf = (uint64_t)term_coef[t];
+        for (int q = 0; q < W; q++) x[q] += cf * src[q];
+      }
+      x[W - 1] += consts[j];
+      uint64_t *dst = arena + (size_t)out_idx[j] * stride;
+      if (lut_ids[j] < 0) memcpy(dst, x, sizeof(uint64_t) * W);
+      else oracle_pbs(c, x, lut_polys + (size_t)lut_ids[j] * c->N, dst);
+      free(x);
+    }
+  }
+  return 0;
+}
+
+uint64_t oracle_lwe_phase(const uint64_t *ct, const uint64_t *sk, int32_t dim) {
+  uint64_t acc = ct[dim];
+  for (int i = 0; i < dim; i++) acc -= ct[i] * sk[i];
+  return acc;
+}

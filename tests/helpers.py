@@ -1,0 +1,77 @@
+"""Shared test plumbing: key material, oracle context, encrypt/decrypt helpers."""
+import ctypes as C
+import functools
+
+import numpy as np
+
+from fhe_string_amd import _lib
+from fhe_string_amd._lib import Params, check, check_ptr
+from tests import oracle_lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class World:
+    """One key set (client key + standard-domain server keys) plus an oracle context."""
+
+    def __init__(self, which="toy", l=255, seed=0xF4E50000):
+        self.lib = _lib.load(strict=False)
+        self.orc = oracle_lib.load()
+        self.p = Params()
+        check(getattr(self.lib, "fhes_params_" + which)(C.byref(self.p)))
+        self.W = self.p.ct_words()
+        self.N = self.p.poly_size
+        self.n = self.p.lwe_dim
+        self.ck = check_ptr(self.lib.fhes_client_key_generate(C.byref(self.p), l, seed))
+        self.bsk = np.zeros(self.lib.fhes_bsk_words(C.byref(self.p)), dtype=np.uint64)
+        self.ksk = np.zeros(self.lib.fhes_ksk_words(C.byref(self.p)), dtype=np.uint64)
+        check(self.lib.fhes_client_key_make_server_keys(self.ck, ptr(self.bsk), ptr(self.ksk)))
+        self.oc = self.orc.oracle_ctx_create(C.addressof(self.p))
+        assert self.oc
+        assert self.orc.oracle_set_keys(self.oc, ptr(self.bsk), ptr(self.ksk)) == 0
+        self._ctx = None
+
+    # ---- client side ----
+    def encrypt(self, values):
+        v = np.ascontiguousarray(values, dtype=np.uint8)
+        out = np.zeros((len(v), self.W), dtype=np.uint64)
+        check(self.lib.fhes_client_encrypt_blocks(self.ck, ptr(v), len(v), ptr(out)))
+        return out
+
+    def decrypt(self, cts):
+        cts = np.ascontiguousarray(cts, dtype=np.uint64).reshape(-1, self.W)
+        out = np.zeros(len(cts), dtype=np.uint8)
+        check(self.lib.fhes_client_decrypt_blocks(self.ck, ptr(cts), len(cts), ptr(out)))
+        return out
+
+    # ---- oracle ----
+    def lut_poly(self, f):
+        t = np.array([f(x) for x in range(16)], dtype=np.uint64)
+        poly = np.zeros(self.N, dtype=np.uint64)
+        self.orc.oracle_make_lut_poly(self.oc, ptr(t), ptr(poly))
+        return t, poly
+
+    def oracle_pbs(self, ct, poly):
+        out = np.zeros(self.W, dtype=np.uint64)
+        ct = np.ascontiguousarray(ct)
+        self.orc.oracle_pbs(self.oc, ptr(ct), ptr(poly), ptr(out))
+        return out
+
+    # ---- device ----
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = check_ptr(self.lib.fhes_ctx_create(C.byref(self.p), 0))
+            check(self.lib.fhes_upload_keys(self._ctx, ptr(self.bsk), ptr(self.ksk)))
+        return self._ctx
+
+    def close(self):
+        if self._ctx is not None:
+            self.lib.fhes_ctx_destroy(self._ctx)
+            self._ctx = None
+
+
+@functools.lru_cache(maxsize=None)
+def world(which="toy", l=255, seed=0xF4E50000):
+    return World(which, l, seed)

@@ -1,0 +1,126 @@
+"""GPU parity of the Level-0 kernels against the CPU oracle (bit-exact), through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from fhe_string_amd._lib import check
+from tests.helpers import ptr, world
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["toy", "default"])
+def w(request, libs):
+    return world(request.param)
+
+
+def test_fft_tables_match_oracle(w):
+    M = w.N // 2
+    twist = np.zeros(2 * M)
+    tw = np.zeros(M)
+    check(w.lib.fhes_debug_fft_tables(C.byref(w.p), ptr(twist), ptr(tw)))
+    o_twist = np.ctypeslib.as_array(C.cast(w.orc.oracle_twist_table(w.oc), C.POINTER(C.c_double)), (2 * M,))
+    o_tw = np.ctypeslib.as_array(C.cast(w.orc.oracle_twiddle_table(w.oc), C.POINTER(C.c_double)), (M,))
+    assert np.array_equal(twist.view(np.uint64), o_twist.view(np.uint64))
+    assert np.array_equal(tw.view(np.uint64), o_tw.view(np.uint64))
+
+
+def test_bsk_fourier_bit_exact(w):
+    ctx = w.ctx()
+    cnt = w.n * 4 * (w.N // 2) * 2
+    dev = np.zeros(cnt)
+    check(w.lib.fhes_debug_bsk_fourier(ctx, ptr(dev)))
+    ref = np.ctypeslib.as_array(C.cast(w.orc.oracle_bsk_fourier(w.oc), C.POINTER(C.c_double)), (cnt,))
+    bad = np.nonzero(dev != ref)[0]   # numeric compare: -0.0 == +0.0
+    assert bad.size == 0, f"{bad.size} of {cnt} spectrum words differ, first at {bad[:8]}"
+
+
+def test_keyswitch_modswitch_bit_exact(w):
+    ctx = w.ctx()
+    vals = np.arange(16, dtype=np.uint8)
+    cts = w.encrypt(vals)
+    h = check(w.lib.fhes_arena_alloc(ctx, 16))
+    check(w.lib.fhes_arena_upload(ctx, h, 16, ptr(cts)))
+    handles = np.arange(h, h + 16, dtype=np.int32)
+    at = np.zeros((16, w.n + 1), dtype=np.uint32)
+    check(w.lib.fhes_debug_keyswitch(ctx, 16, ptr(handles), ptr(at)))
+    for i in range(16):
+        small = np.zeros(w.n + 1, dtype=np.uint64)
+        ref = np.zeros(w.n + 1, dtype=np.uint32)
+        w.orc.oracle_keyswitch(w.oc, ptr(cts[i]), ptr(small))
+        w.orc.oracle_modswitch(w.oc, ptr(small), ptr(ref))
+        assert np.array_equal(at[i], ref), f"ct {i}: {np.count_nonzero(at[i] != ref)} words differ"
+    check(w.lib.fhes_arena_free(ctx, h, 16))
+
+
+def test_pbs_batch_bit_exact_and_decrypts(w):
+    ctx = w.ctx()
+    count = 24 if w.N == 2048 else 64
+    rng = np.random.default_rng(7)
+    vals = rng.integers(0, 16, size=count).astype(np.uint8)
+    cts = w.encrypt(vals)
+    fns = [lambda x: (3 * x + 5) % 16, lambda x: 1 if x == 7 else 0, lambda x: x % 4, lambda x: x // 4]
+    tables, polys, ids = [], [], []
+    for f in fns:
+        t, poly = w.lut_poly(f)
+        tables.append(t)
+        polys.append(poly)
+        ids.append(check(w.lib.fhes_lut_register(ctx, ptr(t), 16)))
+    h_in = check(w.lib.fhes_arena_alloc(ctx, count))
+    h_out = check(w.lib.fhes_arena_alloc(ctx, count))
+    check(w.lib.fhes_arena_upload(ctx, h_in, count, ptr(cts)))
+    term_ptr = np.arange(count + 1, dtype=np.int32)
+    term_idx = np.arange(h_in, h_in + count, dtype=np.int32)
+    term_coef = np.ones(count, dtype=np.int64)
+    consts = np.zeros(count, dtype=np.uint64)
+    lut_sel = (np.arange(count) % len(fns)).astype(np.int32)
+    lut_ids = np.array([ids[i] for i in lut_sel], dtype=np.int32)
+    outs = np.arange(h_out, h_out + count, dtype=np.int32)
+    check(w.lib.fhes_pbs_batch(ctx, count, ptr(term_ptr), ptr(term_idx), ptr(term_coef), ptr(consts),
+                               ptr(lut_ids), ptr(outs)))
+    res = np.zeros((count, w.W), dtype=np.uint64)
+    check(w.lib.fhes_arena_download(ctx, h_out, count, ptr(res)))
+    dec = w.decrypt(res)
+    expect = np.array([fns[lut_sel[i]](int(vals[i])) for i in range(count)], dtype=np.uint8)
+    assert np.array_equal(dec, expect), f"decrypt mismatch: {dec} vs {expect}"
+    n_ref = count if w.N == 256 else 6   # the oracle takes ~80 ms per PBS at the real parameters
+    for i in range(n_ref):
+        ref = w.oracle_pbs(cts[i], polys[lut_sel[i]])
+        nbad = int(np.count_nonzero(ref != res[i]))
+        assert nbad == 0, f"ct {i}: {nbad} of {w.W} words differ from the oracle"
+    check(w.lib.fhes_arena_free(ctx, h_in, count))
+    check(w.lib.fhes_arena_free(ctx, h_out, count))
+
+
+def test_pbs_linear_combination_inputs(w):
+    """bivariate packing 4*x + y (+ constant) is folded into the keyswitch input"""
+    ctx = w.ctx()
+    xs = np.array([0, 1, 2, 3, 1, 2], dtype=np.uint8)
+    ys = np.array([3, 2, 1, 0, 1, 3], dtype=np.uint8)
+    cts = w.encrypt(np.concatenate([xs, ys]))
+    n = len(xs)
+    h = check(w.lib.fhes_arena_alloc(ctx, 3 * n))
+    check(w.lib.fhes_arena_upload(ctx, h, 2 * n, ptr(cts)))
+    t, poly = w.lut_poly(lambda v: 1 if (v // 4) == (v % 4) else 0)
+    lid = check(w.lib.fhes_lut_register(ctx, ptr(t), 16))
+    term_ptr = (2 * np.arange(n + 1)).astype(np.int32)
+    term_idx = np.stack([h + np.arange(n), h + n + np.arange(n)], axis=1).reshape(-1).astype(np.int32)
+    term_coef = np.tile(np.array([4, 1], dtype=np.int64), n)
+    consts = np.zeros(n, dtype=np.uint64)
+    lut_ids = np.full(n, lid, dtype=np.int32)
+    outs = (h + 2 * n + np.arange(n)).astype(np.int32)
+    check(w.lib.fhes_pbs_batch(ctx, n, ptr(term_ptr), ptr(term_idx), ptr(term_coef), ptr(consts),
+                               ptr(lut_ids), ptr(outs)))
+    res = np.zeros((n, w.W), dtype=np.uint64)
+    check(w.lib.fhes_arena_download(ctx, h + 2 * n, n, ptr(res)))
+    assert np.array_equal(w.decrypt(res), (xs == ys).astype(np.uint8))
+    for i in range(n if w.N == 256 else 2):
+        comb = 4 * cts[i] + cts[n + i]
+        assert np.array_equal(w.oracle_pbs(comb, poly), res[i])
+    # linear batch: materialise 4*x + y + 1*delta and decrypt
+    consts[:] = np.uint64(1) << np.uint64(59)
+    check(w.lib.fhes_linear_batch(ctx, n, ptr(term_ptr), ptr(term_idx), ptr(term_coef), ptr(consts), ptr(outs)))
+    check(w.lib.fhes_arena_download(ctx, h + 2 * n, n, ptr(res)))
+    assert np.array_equal(w.decrypt(res), (4 * xs + ys + 1).astype(np.uint8))
+    check(w.lib.fhes_arena_free(ctx, h, 3 * n))
