@@ -1,0 +1,291 @@
+"""Host-side mirror of the reference's public API (names and argument meaning as in
+/root/reference/src/lib.rs:34-89 and SURVEY.md Appendix C), over the C ABI.
+
+    ck, sk = generate_keys()
+    a = FheString.new(ck, "abcabc")              # == "abcabc".encrypt(&client_key, None)
+    b = FheString.new(ck, "ab")
+    a.find(sk, b).decrypt(ck)                    # -> 0
+"""
+import ctypes as C
+
+from . import _lib
+from ._lib import FheError, Params, check, check_ptr
+
+
+def _L():
+    return _lib.load()
+
+
+def default_params():
+    p = Params()
+    check(_L().fhes_params_default(C.byref(p)))
+    return p
+
+
+def toy_params():
+    p = Params()
+    check(_L().fhes_params_toy(C.byref(p)))
+    return p
+
+
+class ClientKey:
+    """client_key.rs:15-62"""
+
+    def __init__(self, params, l=255, seed=0):
+        self.params = params
+        self._h = check_ptr(_L().fhes_client_key_generate(C.byref(params), l, seed))
+        self.l = l
+
+    @property
+    def num_blocks_char(self):
+        return _L().fhes_client_key_num_blocks_char(self._h)
+
+    @property
+    def num_blocks_usize(self):
+        return _L().fhes_client_key_num_blocks_usize(self._h)
+
+    def decrypt_bool(self, b):
+        out = C.c_int32()
+        check(_L().fhes_bool_decrypt(self._h, b._h, C.byref(out)))
+        return bool(out.value)
+
+    def decrypt_usize(self, v):
+        out = C.c_uint64()
+        check(_L().fhes_usize_decrypt(self._h, v._h, C.byref(out)))
+        return out.value
+
+    def __del__(self):
+        try:
+            _L().fhes_client_key_destroy(self._h)
+        except Exception:
+            pass
+
+
+class ServerKey:
+    """server_key.rs:11-33; owns the device-resident bootstrapping / keyswitching keys."""
+
+    def __init__(self, client_key, device=0):
+        self._h = check_ptr(_L().fhes_server_key_create(client_key._h, device))
+        self.num_blocks_usize = client_key.num_blocks_usize
+        self.num_blocks_char = client_key.num_blocks_char
+
+    @property
+    def ctx(self):
+        return _L().fhes_server_key_ctx(self._h)
+
+    def stats(self):
+        st = _lib.Stats()
+        check(_L().fhes_get_stats(self.ctx, C.byref(st)))
+        return st
+
+    def reset_stats(self):
+        check(_L().fhes_reset_stats(self.ctx))
+
+    def sync(self):
+        check(_L().fhes_sync(self.ctx))
+
+    def close(self):
+        if self._h:
+            _L().fhes_server_key_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def generate_keys_with_params(params, l, seed=0, device=0):
+    """lib.rs:50-77"""
+    ck = ClientKey(params, l, seed)
+    return ck, ServerKey(ck, device)
+
+
+def generate_keys(seed=0, device=0):
+    """lib.rs:44-46"""
+    return generate_keys_with_params(default_params(), 255, seed, device)
+
+
+class _Ct:
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        try:
+            if self._h:
+                _L().fhes_ct_destroy(self._h)
+        except Exception:
+            pass
+
+    @property
+    def num_blocks(self):
+        return _L().fhes_ct_num_blocks(self._h)
+
+
+def _op(sk, name, *args, max_outs=4):
+    arr = (C.c_void_p * len(args))(*[a._h for a in args])
+    outs = (C.c_void_p * max_outs)()
+    n = C.c_int32()
+    check(_L().fhes_string_op(sk._h, name.encode(), arr, len(args), None, 0, outs, max_outs, C.byref(n)))
+    return [outs[i] for i in range(n.value)]
+
+
+class BooleanBlock(_Ct):
+    pass
+
+
+class FheUsize(_Ct):
+    """mod.rs:401-442"""
+
+    @staticmethod
+    def new(ck, v):
+        return FheUsize(check_ptr(_L().fhes_usize_encrypt(ck._h, v)))
+
+    def decrypt(self, ck):
+        return ck.decrypt_usize(self)
+
+
+class FheOption:
+    """mod.rs:358-399"""
+
+    def __init__(self, is_some, val):
+        self.is_some = is_some
+        self.val = val
+
+    def decrypt(self, ck):
+        if not ck.decrypt_bool(self.is_some):
+            return None
+        return self.val.decrypt(ck)
+
+
+class FheStringSliceVector:
+    """split.rs:21-28, decrypt at :208-226"""
+
+    def __init__(self, s, is_some, starts, ends, bu):
+        self.s, self._is_some, self._starts, self._ends, self._bu = s, is_some, starts, ends, bu
+
+    def decrypt(self, ck):
+        s_dec = self.s.decrypt(ck)
+        n = self._is_some.num_blocks
+        some = _decrypt_digits(ck, self._is_some)
+        st = _decrypt_digits(ck, self._starts)
+        en = _decrypt_digits(ck, self._ends)
+        bits = ck.params.message_bits
+        res = []
+        for i in range(n):
+            if not (some[i] & 1):
+                continue
+            a = sum(int(st[i * self._bu + k]) << (bits * k) for k in range(self._bu))
+            b = sum(int(en[i * self._bu + k]) << (bits * k) for k in range(self._bu))
+            res.append(s_dec[a:b] if a <= b <= len(s_dec) else "")  # get(start..end).unwrap_or_default()
+        return res
+
+
+def _decrypt_digits(ck, ct):
+    """message digits (mod message_modulus) of every block of `ct`"""
+    nb = ct.num_blocks
+    vals = (C.c_uint8 * nb)()
+    check(_L().fhes_ct_decrypt_blocks(ck._h, ct._h, vals))
+    M = 1 << ck.params.message_bits
+    return [v % M for v in vals]
+
+
+class FheString(_Ct):
+    """mod.rs:42-43 and the operation set of SURVEY.md Appendix C"""
+
+    @staticmethod
+    def new(ck, s, l=None):
+        st = C.c_int32()
+        h = _L().fhes_string_encrypt(ck._h, s.encode("latin-1"), -1 if l is None else l, C.byref(st))
+        if not h:
+            raise FheError(st.value, _L().fhes_last_error().decode())
+        return FheString(h)
+
+    @staticmethod
+    def new_trivial(sk, s):
+        st = C.c_int32()
+        h = _L().fhes_string_trivial(sk._h, s.encode("latin-1"), C.byref(st))
+        if not h:
+            raise FheError(st.value, _L().fhes_last_error().decode())
+        return FheString(h)
+
+    def decrypt(self, ck):
+        buf = C.create_string_buffer(self.num_blocks + 8)
+        check(_L().fhes_string_decrypt(ck._h, self._h, buf, len(buf)))
+        return buf.value.decode("latin-1")
+
+    def max_len(self, sk_or_ck):
+        return self.num_blocks // sk_or_ck.num_blocks_char - 1
+
+    # --- search.rs ---
+    def contains(self, k, s):
+        return BooleanBlock(_op(k, "contains", self, s)[0])
+
+    def find(self, k, s):
+        o = _op(k, "find", self, s)
+        return FheOption(BooleanBlock(o[0]), FheUsize(o[1]))
+
+    def rfind(self, k, s):
+        o = _op(k, "rfind", self, s)
+        return FheOption(BooleanBlock(o[0]), FheUsize(o[1]))
+
+    def starts_with(self, k, s):
+        return BooleanBlock(_op(k, "starts_with", self, s)[0])
+
+    def ends_with(self, k, s):
+        return BooleanBlock(_op(k, "ends_with", self, s)[0])
+
+    # --- compare.rs ---
+    def is_empty(self, k):
+        return BooleanBlock(_op(k, "is_empty", self)[0])
+
+    def eq(self, k, s):
+        return BooleanBlock(_op(k, "eq", self, s)[0])
+
+    def ne(self, k, s):
+        return BooleanBlock(_op(k, "ne", self, s)[0])
+
+    def lt(self, k, s):
+        return BooleanBlock(_op(k, "lt", self, s)[0])
+
+    def le(self, k, s):
+        return BooleanBlock(_op(k, "le", self, s)[0])
+
+    def gt(self, k, s):
+        return BooleanBlock(_op(k, "gt", self, s)[0])
+
+    def ge(self, k, s):
+        return BooleanBlock(_op(k, "ge", self, s)[0])
+
+    # --- mod.rs ---
+    def len(self, k):
+        return FheUsize(_op(k, "len", self)[0])
+
+    # --- split.rs ---
+    def _split(self, k, name, p):
+        o = _op(k, name, self, p)
+        return FheStringSliceVector(self, _Ct(o[0]), _Ct(o[1]), _Ct(o[2]), k.num_blocks_usize)
+
+    def split(self, k, p):
+        return self._split(k, "split", p)
+
+    def rsplit(self, k, p):
+        return self._split(k, "rsplit", p)
+
+    def split_inclusive(self, k, p):
+        return self._split(k, "split_inclusive", p)
+
+    def split_terminator(self, k, p):
+        return self._split(k, "split_terminator", p)
+
+    def rsplit_terminator(self, k, p):
+        return self._split(k, "rsplit_terminator", p)
+
+
+class StringEncryption:
+    """lib.rs:80-89: `"abc".encrypt(&client_key, pad)`"""
+
+    @staticmethod
+    def encrypt(s, k, l=None):
+        return FheString.new(k, s, l)

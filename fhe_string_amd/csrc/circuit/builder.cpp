@@ -1,0 +1,242 @@
+// builder.cpp -- see builder.h
+#include "builder.h"
+
+#include <algorithm>
+#include <stdexcept>
+
+namespace fhes {
+namespace circ {
+
+Builder::Builder(const fhes_params &p, int32_t n_inputs) : p_(p), n_inputs_(n_inputs) {}
+
+Blk Builder::input(int32_t i, uint32_t deg) const {
+  if (i < 0 || i >= n_inputs_) throw std::logic_error("input index out of range");
+  Blk b;
+  b.terms.push_back({i, 1});
+  b.deg = deg;
+  b.noise = 0.0;  // fresh big-key encryption noise is ~2^-36 of a PBS output's
+  return b;
+}
+
+Blk Builder::trivial(uint64_t v) const {
+  Blk b;
+  b.cst = (int64_t)v;
+  b.deg = (uint32_t)v;
+  return b;
+}
+
+static std::vector<Term> merge(const std::vector<Term> &a, int64_t ca, const std::vector<Term> &b, int64_t cb) {
+  std::vector<Term> out;
+  size_t i = 0, j = 0;
+  while (i < a.size() || j < b.size()) {
+    if (j == b.size() || (i < a.size() && a[i].slot < b[j].slot)) {
+      out.push_back({a[i].slot, a[i].coef * ca});
+      i++;
+    } else if (i == a.size() || b[j].slot < a[i].slot) {
+      out.push_back({b[j].slot, b[j].coef * cb});
+      j++;
+    } else {
+      const int64_t c = a[i].coef * ca + b[j].coef * cb;
+      if (c != 0) out.push_back({a[i].slot, c});
+      i++;
+      j++;
+    }
+  }
+  return out;
+}
+
+Blk Builder::add(const Blk &a, const Blk &b) const {
+  Blk r;
+  r.terms = merge(a.terms, 1, b.terms, 1);
+  r.cst = a.cst + b.cst;
+  r.deg = a.deg + b.deg;
+  r.noise = a.noise + b.noise;
+  return r;
+}
+
+Blk Builder::sub_raw(const Blk &a, const Blk &b) const {
+  Blk r;
+  r.terms = merge(a.terms, 1, b.terms, -1);
+  r.cst = a.cst - b.cst;
+  r.deg = a.deg;
+  r.noise = a.noise + b.noise;
+  return r;
+}
+
+Blk Builder::scale(const Blk &a, int64_t c) const {
+  if (c < 0) throw std::logic_error("scale: negative factor");
+  Blk r;
+  if (c == 0) return r;
+  r.terms = a.terms;
+  for (auto &t : r.terms) t.coef *= c;
+  r.cst = a.cst * c;
+  r.deg = a.deg * (uint32_t)c;
+  r.noise = a.noise * (double)(c * c);
+  return r;
+}
+
+Blk Builder::add_const(const Blk &a, int64_t c) const {
+  Blk r = a;
+  r.cst += c;
+  r.deg = (uint32_t)std::max<int64_t>(0, (int64_t)a.deg + c);
+  return r;
+}
+
+Blk Builder::not_bool(const Blk &a) const {
+  if (a.deg > 1) throw std::logic_error("not_bool: operand is not a boolean");
+  Blk r;
+  r.terms = a.terms;
+  for (auto &t : r.terms) t.coef = -t.coef;
+  r.cst = 1 - a.cst;
+  r.deg = 1;
+  r.noise = a.noise;
+  return r;
+}
+
+int32_t Builder::lut_id(const Table &t) {
+  auto it = lut_index_.find(t);
+  if (it != lut_index_.end()) return it->second;
+  const int32_t id = (int32_t)luts_.size();
+  luts_.push_back(t);
+  lut_index_[t] = id;
+  return id;
+}
+
+Blk Builder::pbs(const Blk &in, const std::function<uint64_t(uint64_t)> &f, bool signed_input) {
+  const int sp = space();
+  Table t{};
+  uint32_t full_max = 0;
+  for (int x = 0; x < 16; x++) {
+    const uint64_t v = x < sp ? f((uint64_t)x) : 0;
+    if (v >= (uint64_t)sp) throw std::logic_error("pbs: lookup value out of range");
+    t[x] = (uint8_t)v;
+    full_max = std::max(full_max, (uint32_t)v);
+  }
+  if (in.trivial()) {
+    if (signed_input) throw std::logic_error("pbs: signed lookup of a constant must be folded by the caller");
+    if (in.cst < 0 || in.cst >= sp) throw std::logic_error("pbs: constant out of range");
+    return trivial(t[in.cst]);
+  }
+  if (!signed_input && in.deg >= (uint32_t)sp) throw std::logic_error("pbs: input degree exceeds the plaintext space");
+  if (in.noise > kNoiseCap) throw std::logic_error("pbs: input noise exceeds the cap");
+  uint32_t out_deg = 0;
+  if (signed_input) out_deg = full_max;
+  else
+    for (uint32_t x = 0; x <= std::min<uint32_t>(in.deg, sp - 1); x++) out_deg = std::max(out_deg, (uint32_t)t[x]);
+
+  const int32_t lid = lut_id(t);
+  auto key = std::make_pair(lid, std::make_pair(in.terms, in.cst));
+  int32_t slot;
+  auto it = cse_.find(key);
+  if (it != cse_.end()) {
+    slot = it->second;
+  } else {
+    Node nd;
+    nd.lut = lid;
+    nd.terms = in.terms;
+    nd.cst = in.cst;
+    int32_t lvl = 0;
+    for (const auto &tm : in.terms)
+      if (tm.slot >= n_inputs_) lvl = std::max(lvl, nodes_[tm.slot - n_inputs_].level);
+    nd.level = lvl + 1;
+    slot = n_inputs_ + (int32_t)nodes_.size();
+    nodes_.push_back(std::move(nd));
+    cse_[key] = slot;
+  }
+  Blk r;
+  r.terms.push_back({slot, 1});
+  r.deg = out_deg;
+  r.noise = 1.0;
+  return r;
+}
+
+Blk Builder::clean(const Blk &a) {
+  const uint64_t m = (uint64_t)msg_mod();
+  return pbs(a, [m](uint64_t v) { return v % m; });
+}
+
+Blk Builder::tame(const Blk &a, int64_t coef) {
+  if (a.trivial()) return a;
+  if (a.noise * (double)(coef * coef) > kNoiseCap / 2) return clean(a);
+  return a;
+}
+
+Blk Builder::bivar(const Blk &x, const Blk &y, int shift,
+                   const std::function<uint64_t(uint64_t, uint64_t)> &g) {
+  const uint64_t lo_mask = (1ull << shift) - 1;
+  if (y.deg > lo_mask) throw std::logic_error("bivar: low operand does not fit its field");
+  const Blk xs = tame(x, 1ll << shift), ys = tame(y, 1);
+  Blk in = add(scale(xs, 1ll << shift), ys);
+  Blk r = pbs(in, [=](uint64_t v) { return g(v >> shift, v & lo_mask); });
+  // tighter degree: only (x <= x.deg, y <= y.deg) can occur
+  uint32_t dmax = 0;
+  for (uint64_t xv = 0; xv <= x.deg && (xv << shift) < (uint64_t)space(); xv++)
+    for (uint64_t yv = 0; yv <= std::min<uint64_t>(y.deg, lo_mask); yv++)
+      if (((xv << shift) | yv) < (uint64_t)space()) dmax = std::max<uint32_t>(dmax, (uint32_t)g(xv, yv));
+  if (!r.trivial()) r.deg = dmax;
+  return r;
+}
+
+Program Builder::finish(const std::vector<Blk> &outputs, const std::string &name) {
+  // 1. materialise outputs
+  std::vector<int32_t> out_slots;
+  for (const Blk &o : outputs) {
+    if (o.terms.size() == 1 && o.terms[0].coef == 1 && o.cst == 0) {
+      out_slots.push_back(o.terms[0].slot);
+    } else {
+      Node nd;
+      nd.lut = -1;
+      nd.terms = o.terms;
+      nd.cst = o.cst;
+      nd.level = 1 << 30;
+      out_slots.push_back(n_inputs_ + (int32_t)nodes_.size());
+      nodes_.push_back(std::move(nd));
+    }
+  }
+  // 2. dead-code elimination
+  std::vector<char> live(nodes_.size(), 0);
+  std::vector<int32_t> stack;
+  for (int32_t s : out_slots)
+    if (s >= n_inputs_) stack.push_back(s - n_inputs_);
+  while (!stack.empty()) {
+    const int32_t j = stack.back();
+    stack.pop_back();
+    if (live[j]) continue;
+    live[j] = 1;
+    for (const auto &t : nodes_[j].terms)
+      if (t.slot >= n_inputs_ && !live[t.slot - n_inputs_]) stack.push_back(t.slot - n_inputs_);
+  }
+  // 3. order by level (stable), renumber slots
+  std::vector<int32_t> order;
+  for (int32_t j = 0; j < (int32_t)nodes_.size(); j++)
+    if (live[j]) order.push_back(j);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int32_t a, int32_t b) { return nodes_[a].level < nodes_[b].level; });
+  std::vector<int32_t> new_slot(nodes_.size(), -1);
+  for (int32_t k = 0; k < (int32_t)order.size(); k++) new_slot[order[k]] = n_inputs_ + k;
+  auto remap = [&](int32_t s) { return s < n_inputs_ ? s : new_slot[s - n_inputs_]; };
+
+  Program prog;
+  prog.params = p_;
+  prog.n_inputs = n_inputs_;
+  prog.name = name;
+  prog.luts = luts_;
+  prog.level_ptr.push_back(0);
+  int32_t cur_level = -1;
+  for (int32_t k = 0; k < (int32_t)order.size(); k++) {
+    Node nd = nodes_[order[k]];
+    for (auto &t : nd.terms) t.slot = remap(t.slot);
+    std::sort(nd.terms.begin(), nd.terms.end());
+    if (cur_level != -1 && nd.level != cur_level) prog.level_ptr.push_back(k);
+    cur_level = nd.level;
+    if (nd.lut >= 0) prog.n_pbs++;
+    prog.nodes.push_back(std::move(nd));
+  }
+  prog.level_ptr.push_back((int32_t)order.size());
+  if (order.empty()) prog.level_ptr = {0};
+  for (int32_t s : out_slots) prog.out_slots.push_back(remap(s));
+  return prog;
+}
+
+}  // namespace circ
+}  // namespace fhes

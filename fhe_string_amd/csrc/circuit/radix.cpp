@@ -1,0 +1,436 @@
+// radix.cpp -- see radix.h.  Intended semantics of each tfhe::integer method: SURVEY.md
+// Appendix A; call sites in the reference: SURVEY.md section 2.3.
+#include "radix.h"
+
+#include <algorithm>
+#include <stdexcept>
+
+namespace fhes {
+namespace circ {
+
+static bool same_value(const Blk &a, const Blk &b) { return a.terms == b.terms && a.cst == b.cst; }
+
+static uint64_t ipow(uint64_t b, int e) {
+  uint64_t r = 1;
+  for (int i = 0; i < e; i++) {
+    if (r > (UINT64_MAX / b)) return UINT64_MAX;
+    r *= b;
+  }
+  return r;
+}
+
+Radix Ops::trivial_radix(uint64_t v, int nblocks) {
+  Radix r;
+  for (int i = 0; i < nblocks; i++) {
+    r.push_back(b.trivial(v % M));
+    v /= M;
+  }
+  return r;
+}
+
+Radix Ops::bool_to_radix(const Blk &x, int nblocks) {
+  Radix r;
+  r.push_back(x);
+  for (int i = 1; i < nblocks; i++) r.push_back(b.trivial(0));
+  return r;
+}
+
+// ---- boolean blocks ---------------------------------------------------------------------
+Blk Ops::bitand_(const Blk &x, const Blk &y) {
+  if (x.deg > 1 || y.deg > 1) throw std::logic_error("bitand: operands must be booleans");
+  if (x.trivial()) return x.cst ? y : b.trivial(0);
+  if (y.trivial()) return y.cst ? x : b.trivial(0);
+  if (same_value(x, y)) return x;
+  return b.bivar(x, y, 1, [](uint64_t p, uint64_t q) { return p & q; });
+}
+
+Blk Ops::bitor_(const Blk &x, const Blk &y) {
+  if (x.deg > 1 || y.deg > 1) throw std::logic_error("bitor: operands must be booleans");
+  if (x.trivial()) return x.cst ? b.trivial(1) : y;
+  if (y.trivial()) return y.cst ? b.trivial(1) : x;
+  if (same_value(x, y)) return x;
+  return b.bivar(x, y, 1, [](uint64_t p, uint64_t q) { return p | q; });
+}
+
+// chunks of booleans whose sum stays a valid lookup input
+static std::vector<std::vector<Blk>> bool_chunks(const std::vector<Blk> &v, int space) {
+  std::vector<std::vector<Blk>> out;
+  std::vector<Blk> cur;
+  double noise = 0;
+  for (const Blk &x : v) {
+    if ((int)cur.size() == space - 1 || noise + x.noise > Builder::kNoiseCap) {
+      out.push_back(cur);
+      cur.clear();
+      noise = 0;
+    }
+    cur.push_back(x);
+    noise += x.noise;
+  }
+  if (!cur.empty()) out.push_back(cur);
+  return out;
+}
+
+Blk Ops::all_true(std::vector<Blk> v) {
+  std::vector<Blk> w;
+  for (const Blk &x : v) {
+    if (x.deg > 1) throw std::logic_error("all_true: operand is not a boolean");
+    if (x.trivial()) {
+      if (!x.cst) return b.trivial(0);
+      continue;
+    }
+    w.push_back(x);
+  }
+  if (w.empty()) return b.trivial(1);
+  while (w.size() > 1) {
+    std::vector<Blk> next;
+    for (auto &chunk : bool_chunks(w, b.space())) {
+      if (chunk.size() == 1) { next.push_back(chunk[0]); continue; }
+      Blk s = chunk[0];
+      for (size_t i = 1; i < chunk.size(); i++) s = b.add(s, chunk[i]);
+      const uint64_t cnt = chunk.size();
+      next.push_back(b.pbs(s, [cnt](uint64_t x) { return x == cnt ? 1 : 0; }));
+    }
+    w = next;
+  }
+  return w[0];
+}
+
+Blk Ops::any_true(std::vector<Blk> v) {
+  std::vector<Blk> w;
+  for (const Blk &x : v) {
+    if (x.deg > 1) throw std::logic_error("any_true: operand is not a boolean");
+    if (x.trivial()) {
+      if (x.cst) return b.trivial(1);
+      continue;
+    }
+    w.push_back(x);
+  }
+  if (w.empty()) return b.trivial(0);
+  while (w.size() > 1) {
+    std::vector<Blk> next;
+    for (auto &chunk : bool_chunks(w, b.space())) {
+      if (chunk.size() == 1) { next.push_back(chunk[0]); continue; }
+      Blk s = chunk[0];
+      for (size_t i = 1; i < chunk.size(); i++) s = b.add(s, chunk[i]);
+      next.push_back(b.pbs(s, [](uint64_t x) { return x > 0 ? 1 : 0; }));
+    }
+    w = next;
+  }
+  return w[0];
+}
+
+// ---- comparisons -----------------------------------------------------------------------------
+Blk Ops::eq(const Radix &x, const Radix &y) {
+  if (x.size() != y.size()) throw std::logic_error("eq: operand sizes differ");
+  std::vector<Blk> e;
+  for (size_t i = 0; i < x.size(); i++) {
+    if (same_value(x[i], y[i])) continue;
+    if (x[i].trivial() && y[i].trivial()) {
+      e.push_back(b.trivial(x[i].cst == y[i].cst));
+    } else if (y[i].trivial()) {
+      const uint64_t c = (uint64_t)y[i].cst;
+      e.push_back(b.pbs(x[i], [c](uint64_t v) { return v == c ? 1 : 0; }));
+    } else if (x[i].trivial()) {
+      const uint64_t c = (uint64_t)x[i].cst;
+      e.push_back(b.pbs(y[i], [c](uint64_t v) { return v == c ? 1 : 0; }));
+    } else {
+      e.push_back(b.bivar(x[i], y[i], b.params().message_bits,
+                          [](uint64_t p, uint64_t q) { return p == q ? 1 : 0; }));
+    }
+  }
+  return all_true(e);
+}
+
+std::vector<Blk> Ops::pack_pairs(const Radix &x) {
+  std::vector<Blk> out;
+  for (size_t i = 0; i < x.size(); i += 2) {
+    if (x[i].deg >= (uint32_t)M) throw std::logic_error("pack_pairs: block not clean");
+    if (i + 1 < x.size()) {
+      if (x[i + 1].deg >= (uint32_t)M) throw std::logic_error("pack_pairs: block not clean");
+      out.push_back(b.add(b.tame(x[i], 1), b.scale(b.tame(x[i + 1], M), M)));
+    } else {
+      out.push_back(b.tame(x[i], 1));
+    }
+  }
+  return out;
+}
+
+Blk Ops::scalar_eq(const Radix &x, uint64_t c) {
+  if (c >= ipow(M, (int)x.size())) return b.trivial(0);
+  std::vector<Blk> e;
+  auto pairs = pack_pairs(x);
+  for (size_t j = 0; j < pairs.size(); j++) {
+    const uint64_t cj = (c / ipow(M, (int)(2 * j))) % (uint64_t)(M * M);
+    e.push_back(b.pbs(pairs[j], [cj](uint64_t v) { return v == cj ? 1 : 0; }));
+  }
+  return all_true(e);
+}
+
+Blk Ops::scalar_ne(const Radix &x, uint64_t c) {
+  if (c >= ipow(M, (int)x.size())) return b.trivial(1);
+  std::vector<Blk> e;
+  auto pairs = pack_pairs(x);
+  for (size_t j = 0; j < pairs.size(); j++) {
+    const uint64_t cj = (c / ipow(M, (int)(2 * j))) % (uint64_t)(M * M);
+    e.push_back(b.pbs(pairs[j], [cj](uint64_t v) { return v != cj ? 1 : 0; }));
+  }
+  return any_true(e);
+}
+
+// sign encoding: 0 = inferior, 1 = equal, 2 = superior
+static uint64_t sign_final(Cmp op, uint64_t s) {
+  switch (op) {
+    case Cmp::LT: return s == 0;
+    case Cmp::LE: return s != 2;
+    case Cmp::GT: return s == 2;
+    default: return s != 0;
+  }
+}
+static uint64_t sign_combine(uint64_t hi, uint64_t lo) { return hi != 1 ? hi : lo; }
+
+Blk Ops::reduce_signs(std::vector<Blk> signs, Cmp op) {
+  if (signs.empty()) return b.trivial(sign_final(op, 1));
+  if (signs.size() == 1) return b.pbs(signs[0], [op](uint64_t s) { return sign_final(op, std::min<uint64_t>(s, 2)); });
+  while (true) {
+    const bool last = signs.size() == 2;
+    std::vector<Blk> next;
+    for (size_t i = 0; i < signs.size(); i += 2) {
+      if (i + 1 == signs.size()) { next.push_back(signs[i]); continue; }
+      const Blk &lo = signs[i], &hi = signs[i + 1];
+      next.push_back(b.bivar(hi, lo, 2, [op, last](uint64_t h, uint64_t l) {
+        const uint64_t s = sign_combine(std::min<uint64_t>(h, 2), std::min<uint64_t>(l, 2));
+        return last ? sign_final(op, s) : s;
+      }));
+    }
+    if (last) return next[0];
+    signs = next;
+  }
+}
+
+Blk Ops::cmp(const Radix &x, const Radix &y, Cmp op) {
+  if (x.size() != y.size()) throw std::logic_error("cmp: operand sizes differ");
+  auto px = pack_pairs(x), py = pack_pairs(y);
+  std::vector<Blk> signs;
+  for (size_t j = 0; j < px.size(); j++) {
+    if (px[j].trivial() && py[j].trivial()) {
+      signs.push_back(b.trivial(px[j].cst < py[j].cst ? 0 : px[j].cst == py[j].cst ? 1 : 2));
+    } else if (py[j].trivial()) {
+      const uint64_t c = (uint64_t)py[j].cst;
+      signs.push_back(b.pbs(px[j], [c](uint64_t v) { return v < c ? 0 : v == c ? 1 : 2; }));
+    } else if (px[j].trivial()) {
+      const uint64_t c = (uint64_t)px[j].cst;
+      signs.push_back(b.pbs(py[j], [c](uint64_t v) { return c < v ? 0 : c == v ? 1 : 2; }));
+    } else if (same_value(px[j], py[j])) {
+      signs.push_back(b.trivial(1));
+    } else {
+      // x - y in (-16, 16) uses the padding bit: the lookup of a negative value returns
+      // -f(.), so f = [v != 0] yields {-1, 0, +1}; adding 1 gives the sign encoding.
+      Blk pxj = px[j], pyj = py[j];
+      if (pxj.noise + pyj.noise > Builder::kNoiseCap) throw std::logic_error("cmp: operands too noisy");
+      Blk diff = b.sub_raw(pxj, pyj);
+      Blk r = b.pbs(diff, [](uint64_t v) { return v != 0 ? 1 : 0; }, /*signed_input=*/true);
+      Blk s = b.add_const(r, 1);
+      s.deg = 2;
+      signs.push_back(s);
+    }
+  }
+  return reduce_signs(signs, op);
+}
+
+Blk Ops::scalar_cmp(const Radix &x, uint64_t c, Cmp op) {
+  if (c >= ipow(M, (int)x.size())) return b.trivial(op == Cmp::LT || op == Cmp::LE);
+  auto px = pack_pairs(x);
+  std::vector<Blk> signs;
+  for (size_t j = 0; j < px.size(); j++) {
+    const uint64_t cj = (c / ipow(M, (int)(2 * j))) % (uint64_t)(M * M);
+    signs.push_back(b.pbs(px[j], [cj](uint64_t v) { return v < cj ? 0 : v == cj ? 1 : 2; }));
+  }
+  return reduce_signs(signs, op);
+}
+
+// ---- selection ---------------------------------------------------------------------------------
+// when ? (c ? x : 0) : (c ? 0 : x)
+static Blk select_block(Builder &b, const Blk &c, const Blk &x, bool when) {
+  if (x.trivial()) {
+    if (x.cst == 0) return b.trivial(0);
+    return b.scale(when ? c : b.not_bool(c), x.cst);
+  }
+  if (x.deg >= (uint32_t)b.msg_mod()) throw std::logic_error("select: block not clean");
+  const int sh = b.params().message_bits;
+  return b.bivar(c, x, sh, [when](uint64_t cb, uint64_t xv) { return ((cb != 0) == when) ? xv : 0; });
+}
+
+Radix Ops::if_then_else(const Blk &c, const Radix &t, const Radix &f) {
+  if (t.size() != f.size()) throw std::logic_error("if_then_else: operand sizes differ");
+  if (c.deg > 1) throw std::logic_error("if_then_else: condition is not a boolean");
+  if (c.trivial()) return c.cst ? t : f;
+  Radix out;
+  for (size_t i = 0; i < t.size(); i++) {
+    if (same_value(t[i], f[i])) { out.push_back(t[i]); continue; }
+    Blk a = select_block(b, c, t[i], true), bb = select_block(b, c, f[i], false);
+    Blk r = b.add(a, bb);
+    r.deg = std::max(a.deg, bb.deg);  // the two addends are never non-zero together
+    out.push_back(r);
+  }
+  return out;
+}
+
+Radix Ops::zero_unless(const Blk &c, const Radix &x) {
+  if (c.deg > 1) throw std::logic_error("zero_unless: condition is not a boolean");
+  Radix out;
+  for (const Blk &xi : x) {
+    if (c.trivial()) out.push_back(c.cst ? xi : b.trivial(0));
+    else out.push_back(select_block(b, c, xi, true));
+  }
+  return out;
+}
+
+// ---- arithmetic --------------------------------------------------------------------------------
+Radix Ops::propagate(std::vector<Blk> s) {
+  Radix out;
+  Blk carry = b.trivial(0);
+  const uint64_t m = (uint64_t)M;
+  for (size_t i = 0; i < s.size(); i++) {
+    Blk t = b.add(s[i], carry);
+    if (t.deg < (uint32_t)M) {
+      out.push_back(t);
+      carry = b.trivial(0);
+      continue;
+    }
+    if (t.deg >= (uint32_t)b.space()) throw std::logic_error("propagate: degree overflow");
+    if (t.noise > Builder::kNoiseCap) throw std::logic_error("propagate: noise overflow");
+    out.push_back(b.pbs(t, [m](uint64_t v) { return v % m; }));
+    carry = (i + 1 < s.size()) ? b.pbs(t, [m](uint64_t v) { return v / m; }) : b.trivial(0);
+  }
+  return out;
+}
+
+Radix Ops::add(const Radix &x, const Radix &y) {
+  if (x.size() != y.size()) throw std::logic_error("add: operand sizes differ");
+  std::vector<Blk> s;
+  for (size_t i = 0; i < x.size(); i++) s.push_back(b.add(b.tame(x[i], 1), b.tame(y[i], 1)));
+  return propagate(s);
+}
+
+Radix Ops::sub(const Radix &x, const Radix &y) {
+  if (x.size() != y.size()) throw std::logic_error("sub: operand sizes differ");
+  // x - y = x + (~y) + 1 (mod M^B), digit-wise complement ~y_i = (M-1) - y_i
+  std::vector<Blk> s;
+  for (size_t i = 0; i < x.size(); i++) {
+    if (y[i].deg >= (uint32_t)M) throw std::logic_error("sub: block not clean");
+    Blk ny = b.sub_raw(b.trivial(M - 1), b.tame(y[i], 1));
+    ny.deg = M - 1;
+    Blk t = b.add(b.tame(x[i], 1), ny);
+    if (i == 0) t = b.add_const(t, 1);
+    s.push_back(t);
+  }
+  return propagate(s);
+}
+
+Radix Ops::scalar_add(const Radix &x, uint64_t c) {
+  std::vector<Blk> s;
+  for (size_t i = 0; i < x.size(); i++) {
+    s.push_back(b.add_const(b.tame(x[i], 1), (int64_t)(c % M)));
+    c /= M;
+  }
+  return propagate(s);
+}
+
+Radix Ops::scalar_sub(const Radix &x, uint64_t c) {
+  const uint64_t mod = ipow(M, (int)x.size());
+  return scalar_add(x, (mod - c % mod) % mod);
+}
+
+// column-wise reduction of arbitrary-degree terms to one clean block per column
+static Radix sum_columns(Ops &o, std::vector<std::vector<Blk>> cols) {
+  Builder &b = o.b;
+  const uint64_t m = (uint64_t)o.M;
+  const size_t B = cols.size();
+  while (true) {
+    bool work = false;
+    std::vector<std::vector<Blk>> carries(B);
+    for (size_t c = 0; c < B; c++) {
+      auto &col = cols[c];
+      if (col.empty()) { col.push_back(b.trivial(0)); continue; }
+      if (col.size() == 1 && col[0].deg < (uint32_t)o.M) continue;
+      work = true;
+      std::vector<Blk> next;
+      size_t i = 0;
+      while (i < col.size()) {
+        Blk s = b.tame(col[i], 1);
+        size_t j = i + 1;
+        while (j < col.size()) {
+          Blk t = b.tame(col[j], 1);
+          if (s.deg + t.deg >= (uint32_t)b.space() || s.noise + t.noise > Builder::kNoiseCap) break;
+          s = b.add(s, t);
+          j++;
+        }
+        if (s.deg >= (uint32_t)b.space()) throw std::logic_error("sum: term degree too large");
+        if (s.deg < (uint32_t)o.M) {
+          next.push_back(s);
+        } else {
+          next.push_back(b.pbs(s, [m](uint64_t v) { return v % m; }));
+          if (c + 1 < B) carries[c + 1].push_back(b.pbs(s, [m](uint64_t v) { return v / m; }));
+        }
+        i = j;
+      }
+      col = next;
+    }
+    for (size_t c = 0; c < B; c++)
+      for (auto &x : carries[c]) cols[c].push_back(x);
+    if (!work) break;
+  }
+  Radix out;
+  for (size_t c = 0; c < B; c++) out.push_back(cols[c][0]);
+  return out;
+}
+
+Radix Ops::sum(const std::vector<Radix> &v, int nblocks) {
+  std::vector<std::vector<Blk>> cols(nblocks);
+  for (const Radix &r : v) {
+    if ((int)r.size() != nblocks) throw std::logic_error("sum: operand sizes differ");
+    for (int c = 0; c < nblocks; c++) {
+      if (r[c].trivial() && r[c].cst == 0) continue;
+      cols[c].push_back(r[c]);
+    }
+  }
+  return sum_columns(*this, cols);
+}
+
+Radix Ops::scalar_mul(const Radix &x, uint64_t c) {
+  const int B = (int)x.size();
+  std::vector<std::vector<Blk>> cols(B);
+  for (int j = 0; j < B && c; j++, c /= M) {
+    const int64_t d = (int64_t)(c % M);
+    if (!d) continue;
+    for (int i = 0; i + j < B; i++) {
+      if (x[i].trivial() && x[i].cst == 0) continue;
+      cols[i + j].push_back(b.scale(b.tame(x[i], d), d));
+    }
+  }
+  return sum_columns(*this, cols);
+}
+
+Radix Ops::mul(const Radix &x, const Radix &y) {
+  if (x.size() != y.size()) throw std::logic_error("mul: operand sizes differ");
+  const int B = (int)x.size();
+  const uint64_t m = (uint64_t)M;
+  const int sh = b.params().message_bits;
+  std::vector<std::vector<Blk>> cols(B);
+  for (int i = 0; i < B; i++) {
+    for (int j = 0; i + j < B; j++) {
+      const Blk &p = x[i], &q = y[j];
+      if ((p.trivial() && p.cst == 0) || (q.trivial() && q.cst == 0)) continue;
+      if (p.trivial()) { cols[i + j].push_back(b.scale(b.tame(q, p.cst), p.cst)); continue; }
+      if (q.trivial()) { cols[i + j].push_back(b.scale(b.tame(p, q.cst), q.cst)); continue; }
+      if (p.deg >= m || q.deg >= m) throw std::logic_error("mul: block not clean");
+      cols[i + j].push_back(b.bivar(p, q, sh, [m](uint64_t a, uint64_t c) { return (a * c) % m; }));
+      if (p.deg * q.deg >= m && i + j + 1 < B)
+        cols[i + j + 1].push_back(b.bivar(p, q, sh, [m](uint64_t a, uint64_t c) { return (a * c) / m; }));
+    }
+  }
+  return sum_columns(*this, cols);
+}
+
+}  // namespace circ
+}  // namespace fhes

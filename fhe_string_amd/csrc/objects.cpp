@@ -1,0 +1,305 @@
+// objects.cpp -- Level 2 of the C ABI: the reference's API surface
+// (generate_keys / ClientKey / ServerKey / FheString / FheUsize / FheOption,
+// /root/reference/src/lib.rs:34-89) on top of Levels 0/1.  Ciphertext objects hold
+// host data (client side) and/or a handle range in the device arena (server side).
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace fhes;
+
+struct fhes_server_key {  // server_key.rs:11-17
+  fhes_params p;
+  fhes_ctx *ctx = nullptr;
+  int32_t msg_mod = 0, nb_char = 0, nb_usize = 0;
+  std::mutex mu;
+  std::map<std::string, fhes_program *> cache;
+};
+
+struct fhes_ct {
+  int32_t n_blocks = 0;
+  int64_t ct_words = 0;
+  std::vector<uint64_t> host;  // [n_blocks][ct_words] when present
+  fhes_ctx *ctx = nullptr;     // device residency
+  int32_t handle = -1;
+};
+
+static uint64_t ipow(uint64_t b, int e) {
+  uint64_t r = 1;
+  for (int i = 0; i < e; i++) r *= b;
+  return r;
+}
+
+static int ensure_device(fhes_server_key *sk, fhes_ct *c) {
+  if (c->handle >= 0) {
+    if (c->ctx != sk->ctx) return fail(FHES_ERR_INVALID, "ciphertext belongs to another server key");
+    return FHES_OK;
+  }
+  if (c->host.empty()) return fail(FHES_ERR_INVALID, "ciphertext has no data");
+  const int32_t h = fhes_arena_alloc(sk->ctx, c->n_blocks);
+  if (h < 0) return h;
+  int rc = fhes_arena_upload(sk->ctx, h, c->n_blocks, c->host.data());
+  if (rc) {
+    fhes_arena_free(sk->ctx, h, c->n_blocks);
+    return rc;
+  }
+  c->ctx = sk->ctx;
+  c->handle = h;
+  return FHES_OK;
+}
+
+static int ensure_host(fhes_ct *c) {
+  if (!c->host.empty()) return FHES_OK;
+  if (c->handle < 0 || !c->ctx) return fail(FHES_ERR_INVALID, "ciphertext has no data");
+  c->host.resize((size_t)c->n_blocks * c->ct_words);
+  int rc = fhes_arena_download(c->ctx, c->handle, c->n_blocks, c->host.data());
+  if (rc) c->host.clear();
+  return rc;
+}
+
+extern "C" {
+
+fhes_server_key *fhes_server_key_create(const fhes_client_key *ck, int32_t device) {
+  if (!ck) { fail(FHES_ERR_INVALID, "null client key"); return nullptr; }
+  auto *sk = new fhes_server_key;
+  fhes_client_key_params(ck, &sk->p);
+  sk->msg_mod = 1 << sk->p.message_bits;
+  sk->nb_char = fhes_client_key_num_blocks_char(ck);
+  sk->nb_usize = fhes_client_key_num_blocks_usize(ck);
+  sk->ctx = fhes_ctx_create(&sk->p, device);  // fails loudly without a HIP device
+  if (!sk->ctx) { delete sk; return nullptr; }
+  std::vector<uint64_t> bsk((size_t)fhes_bsk_words(&sk->p)), ksk((size_t)fhes_ksk_words(&sk->p));
+  int rc = fhes_client_key_make_server_keys(ck, bsk.data(), ksk.data());
+  if (rc == FHES_OK) rc = fhes_upload_keys(sk->ctx, bsk.data(), ksk.data());
+  if (rc != FHES_OK) { fhes_server_key_destroy(sk); return nullptr; }
+  return sk;
+}
+
+void fhes_server_key_destroy(fhes_server_key *sk) {
+  if (!sk) return;
+  for (auto &kv : sk->cache) fhes_program_destroy(kv.second);
+  fhes_ctx_destroy(sk->ctx);
+  delete sk;
+}
+
+fhes_ctx *fhes_server_key_ctx(fhes_server_key *sk) { return sk ? sk->ctx : nullptr; }
+
+// mod.rs:58-92
+fhes_ct *fhes_string_encrypt(fhes_client_key *ck, const char *s, int64_t pad, int32_t *status) {
+  int32_t dummy;
+  if (!status) status = &dummy;
+  *status = FHES_ERR_INVALID;
+  if (!ck || !s) { fail(FHES_ERR_INVALID, "null argument"); return nullptr; }
+  fhes_params p;
+  fhes_client_key_params(ck, &p);
+  const int Bc = fhes_client_key_num_blocks_char(ck), Bu = fhes_client_key_num_blocks_usize(ck);
+  const uint64_t M = 1ull << p.message_bits, max_len = ipow(M, Bu) - 1;  // mod.rs:240-244, 435-437
+  const size_t len = strlen(s);
+  for (size_t i = 0; i < len; i++)
+    if ((unsigned char)s[i] >= 128) { *status = fail(FHES_ERR_NOT_ASCII, "string is not ascii"); return nullptr; }
+  if (len > max_len) { *status = fail(FHES_ERR_TOO_LONG, "string length exceeds maximum length"); return nullptr; }
+  if (pad >= 0) {
+    if ((uint64_t)pad > max_len) { *status = fail(FHES_ERR_PAD_TOO_LONG, "pad length exceeds maximum length"); return nullptr; }
+    if ((uint64_t)pad < len) { *status = fail(FHES_ERR_PAD_TOO_SHORT, "string length exceeds pad length"); return nullptr; }
+  }
+  const size_t slots = (pad >= 0 ? (size_t)pad : len) + 1;  // chars + terminator (+ encrypted zero padding)
+  std::vector<uint8_t> blocks(slots * Bc, 0);
+  for (size_t i = 0; i < len; i++) {
+    uint64_t c = (unsigned char)s[i];
+    for (int k = 0; k < Bc; k++, c /= M) blocks[i * Bc + k] = (uint8_t)(c % M);
+  }
+  auto *ct = new fhes_ct;
+  ct->n_blocks = (int32_t)blocks.size();
+  ct->ct_words = fhes_ct_words(&p);
+  ct->host.resize(blocks.size() * ct->ct_words);
+  int rc = fhes_client_encrypt_blocks(ck, blocks.data(), (int64_t)blocks.size(), ct->host.data());
+  if (rc) { delete ct; *status = rc; return nullptr; }
+  *status = FHES_OK;
+  return ct;
+}
+
+// mod.rs:96-119: trivial (noise-free, mask-free) encryption
+fhes_ct *fhes_string_trivial(const fhes_server_key *sk, const char *s, int32_t *status) {
+  int32_t dummy;
+  if (!status) status = &dummy;
+  *status = FHES_ERR_INVALID;
+  if (!sk || !s) { fail(FHES_ERR_INVALID, "null argument"); return nullptr; }
+  const uint64_t M = (uint64_t)sk->msg_mod, max_len = ipow(M, sk->nb_usize) - 1;
+  const size_t len = strlen(s);
+  for (size_t i = 0; i < len; i++)
+    if ((unsigned char)s[i] >= 128) { *status = fail(FHES_ERR_NOT_ASCII, "string is not ascii"); return nullptr; }
+  if (len > max_len) { *status = fail(FHES_ERR_TOO_LONG, "string length exceeds maximum length"); return nullptr; }
+  const Dims d(sk->p);
+  auto *ct = new fhes_ct;
+  ct->n_blocks = (int32_t)((len + 1) * sk->nb_char);
+  ct->ct_words = d.ct_words();
+  ct->host.assign((size_t)ct->n_blocks * ct->ct_words, 0);
+  for (size_t i = 0; i < len; i++) {
+    uint64_t c = (unsigned char)s[i];
+    for (int k = 0; k < sk->nb_char; k++, c /= M)
+      ct->host[(i * sk->nb_char + k) * ct->ct_words + d.big] = (c % M) * d.delta;
+  }
+  *status = FHES_OK;
+  return ct;
+}
+
+// mod.rs:406-423: `encrypt(v as u64)` yields num_blocks_char blocks, then extended with
+// trivial zero blocks / trimmed to num_blocks_usize.
+fhes_ct *fhes_usize_encrypt(fhes_client_key *ck, uint64_t v) {
+  if (!ck) { fail(FHES_ERR_INVALID, "null argument"); return nullptr; }
+  fhes_params p;
+  fhes_client_key_params(ck, &p);
+  const int Bc = fhes_client_key_num_blocks_char(ck), Bu = fhes_client_key_num_blocks_usize(ck);
+  const uint64_t M = 1ull << p.message_bits;
+  std::vector<uint8_t> blocks(Bc);
+  for (int k = 0; k < Bc; k++, v /= M) blocks[k] = (uint8_t)(v % M);
+  auto *ct = new fhes_ct;
+  ct->n_blocks = Bu;
+  ct->ct_words = fhes_ct_words(&p);
+  ct->host.assign((size_t)Bu * ct->ct_words, 0);
+  const int enc = std::min(Bc, Bu);
+  int rc = fhes_client_encrypt_blocks(ck, blocks.data(), enc, ct->host.data());
+  if (rc) { delete ct; return nullptr; }
+  return ct;
+}
+
+void fhes_ct_destroy(fhes_ct *ct) {
+  if (!ct) return;
+  if (ct->handle >= 0 && ct->ctx) fhes_arena_free(ct->ctx, ct->handle, ct->n_blocks);
+  delete ct;
+}
+
+int32_t fhes_ct_num_blocks(const fhes_ct *ct) { return ct ? ct->n_blocks : -1; }
+
+static int decrypt_values(const fhes_client_key *ck, fhes_ct *c, std::vector<uint8_t> *vals) {
+  int rc = ensure_host(c);
+  if (rc) return rc;
+  vals->resize(c->n_blocks);
+  return fhes_client_decrypt_blocks(ck, c->host.data(), c->n_blocks, vals->data());
+}
+
+// mod.rs:121-129
+int fhes_string_decrypt(const fhes_client_key *ck, fhes_ct *s, char *buf, int64_t buf_len) {
+  if (!ck || !s || !buf || buf_len < 1) return fail(FHES_ERR_INVALID, "bad argument");
+  fhes_params p;
+  fhes_client_key_params(ck, &p);
+  const int Bc = fhes_client_key_num_blocks_char(ck);
+  const uint64_t M = 1ull << p.message_bits;
+  std::vector<uint8_t> vals;
+  int rc = decrypt_values(ck, s, &vals);
+  if (rc) return rc;
+  int64_t w = 0;
+  for (int i = 0; i + Bc <= s->n_blocks; i += Bc) {
+    uint64_t c = 0;
+    for (int k = Bc - 1; k >= 0; k--) c = c * M + (vals[i + k] % M);
+    c &= 0xff;
+    if (c == 0) continue;  // zeros are dropped (mod.rs:126)
+    if (w + 1 >= buf_len) return fail(FHES_ERR_INVALID, "buffer too small");
+    buf[w++] = (char)c;
+  }
+  buf[w] = 0;
+  return FHES_OK;
+}
+
+int fhes_usize_decrypt(const fhes_client_key *ck, fhes_ct *v, uint64_t *out) {
+  if (!ck || !v || !out) return fail(FHES_ERR_INVALID, "bad argument");
+  fhes_params p;
+  fhes_client_key_params(ck, &p);
+  const uint64_t M = 1ull << p.message_bits;
+  std::vector<uint8_t> vals;
+  int rc = decrypt_values(ck, v, &vals);
+  if (rc) return rc;
+  uint64_t r = 0;
+  for (int k = v->n_blocks - 1; k >= 0; k--) r = r * M + (vals[k] % M);
+  *out = r;
+  return FHES_OK;
+}
+
+int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out) {
+  if (!ck || !b || !out || b->n_blocks != 1) return fail(FHES_ERR_INVALID, "bad argument");
+  std::vector<uint8_t> vals;
+  int rc = decrypt_values(ck, b, &vals);
+  if (rc) return rc;
+  *out = (vals[0] & 1);  // decrypt_bool: message modulo 2
+  return FHES_OK;
+}
+
+int fhes_ct_decrypt_blocks(const fhes_client_key *ck, fhes_ct *c, uint8_t *values) {
+  if (!ck || !c || !values) return fail(FHES_ERR_INVALID, "bad argument");
+  std::vector<uint8_t> vals;
+  int rc = decrypt_values(ck, c, &vals);
+  if (rc) return rc;
+  memcpy(values, vals.data(), vals.size());
+  return FHES_OK;
+}
+
+int fhes_string_op(fhes_server_key *sk, const char *op, fhes_ct *const *args, int32_t n_args,
+                   const int64_t *iargs, int32_t n_iargs, fhes_ct **outs, int32_t max_outs,
+                   int32_t *n_outs) {
+  (void)iargs; (void)n_iargs;
+  if (!sk || !op || !args || n_args < 1 || !outs || !n_outs) return fail(FHES_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lk(sk->mu);
+  std::vector<int32_t> shape;
+  std::string key = op;
+  for (int i = 0; i < n_args; i++) {
+    if (!args[i] || args[i]->n_blocks % sk->nb_char) return fail(FHES_ERR_INVALID, "operand %d is not a string", i);
+    shape.push_back(args[i]->n_blocks / sk->nb_char);
+    key += ":" + std::to_string(shape.back());
+  }
+  fhes_program *prog;
+  auto it = sk->cache.find(key);
+  if (it != sk->cache.end()) prog = it->second;
+  else {
+    prog = fhes_program_compile(&sk->p, op, shape.data(), (int32_t)shape.size(), sk->nb_usize);
+    if (!prog) return FHES_ERR_INVALID;
+    sk->cache[key] = prog;
+  }
+  int64_t info[8];
+  fhes_program_info(prog, info);
+  std::vector<int32_t> in;
+  for (int i = 0; i < n_args; i++) {
+    int rc = ensure_device(sk, args[i]);
+    if (rc) return rc;
+    for (int k = 0; k < args[i]->n_blocks; k++) in.push_back(args[i]->handle + k);
+  }
+  if ((int64_t)in.size() != info[0]) return fail(FHES_ERR_INVALID, "operand sizes do not match the program");
+  std::vector<int32_t> out((size_t)std::max<int64_t>(info[1], 1));
+  int rc = fhes_program_run(sk->ctx, prog, in.data(), out.data());
+  if (rc) return rc;
+  // result layout per operation
+  std::vector<int32_t> parts;
+  const std::string o = op;
+  const int32_t total = (int32_t)info[1];
+  if (o == "find" || o == "rfind") parts = {1, sk->nb_usize};
+  else if (o == "len") parts = {sk->nb_usize};
+  else if (o.find("split") != std::string::npos) {
+    const int32_t n = total / (1 + 2 * sk->nb_usize);
+    parts = {n, n * sk->nb_usize, n * sk->nb_usize};
+  } else parts = {1};
+  int32_t sum = 0;
+  for (int32_t v : parts) sum += v;
+  if (sum != total) return fail(FHES_ERR_STATE, "internal: unexpected output count");
+  if ((int32_t)parts.size() > max_outs) {
+    fhes_arena_free(sk->ctx, out[0], total);
+    return fail(FHES_ERR_INVALID, "need room for %d results", (int)parts.size());
+  }
+  int32_t off = 0;
+  const Dims d(sk->p);
+  for (size_t k = 0; k < parts.size(); k++) {
+    auto *c = new fhes_ct;
+    c->n_blocks = parts[k];
+    c->ct_words = d.ct_words();
+    c->ctx = sk->ctx;
+    c->handle = out[0] + off;  // program outputs are one contiguous handle range
+    off += parts[k];
+    outs[k] = c;
+  }
+  *n_outs = (int32_t)parts.size();
+  return FHES_OK;
+}
+
+}  // extern "C"

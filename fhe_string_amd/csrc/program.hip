@@ -1,0 +1,230 @@
+// program.hip -- Level 1 of the C ABI: compiled circuits (host-side compile / export) and
+// their execution on the device engine, one keyswitch + blind-rotate launch pair per level.
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+
+#include "circuit/strings.h"
+#include "engine.h"
+
+using namespace fhes;
+
+struct DeviceImage {
+  unsigned char *buf = nullptr;  // all descriptor arrays
+  int32_t *slot_map = nullptr;
+  DevNodeArrays arrays{};
+};
+
+struct fhes_program {
+  circ::Program prog;
+  // flattened descriptor arrays (slot numbering)
+  std::vector<int32_t> term_ptr, term_idx, lut_ids, out_idx;
+  std::vector<int64_t> term_coef;
+  std::vector<uint64_t> consts;
+  int32_t n_slots = 0, n_pbs_levels = 0;
+  bool has_linear_level = false;
+  std::mutex mu;
+  std::map<fhes_ctx *, DeviceImage> images;
+};
+
+static void flatten(fhes_program *fp) {
+  const circ::Program &p = fp->prog;
+  const Dims d(p.params);
+  fp->term_ptr.push_back(0);
+  for (size_t j = 0; j < p.nodes.size(); j++) {
+    const circ::Node &nd = p.nodes[j];
+    for (const auto &t : nd.terms) {
+      fp->term_idx.push_back(t.slot);
+      fp->term_coef.push_back(t.coef);
+    }
+    fp->term_ptr.push_back((int32_t)fp->term_idx.size());
+    fp->consts.push_back((uint64_t)nd.cst * d.delta);  // wraps mod 2^64 == mod 2*space*delta
+    fp->lut_ids.push_back(nd.lut);
+    fp->out_idx.push_back(p.n_inputs + (int32_t)j);
+  }
+  fp->n_slots = p.n_inputs + (int32_t)p.nodes.size();
+  const int nl = (int)p.level_ptr.size() - 1;
+  fp->has_linear_level = nl > 0 && !p.nodes.empty() && p.nodes.back().lut < 0;
+  fp->n_pbs_levels = fp->has_linear_level ? nl - 1 : nl;
+}
+
+extern "C" {
+
+fhes_program *fhes_program_compile(const fhes_params *p, const char *op, const int32_t *shape,
+                                   int32_t n_shape, int32_t num_blocks_usize) {
+  std::string why;
+  if (!p || !op || (n_shape > 0 && !shape) || !params_valid(*p, &why)) {
+    fail(FHES_ERR_INVALID, "program_compile: bad argument %s", why.c_str());
+    return nullptr;
+  }
+  try {
+    auto *fp = new fhes_program;
+    fp->prog = circ::compile_op(*p, op, std::vector<int32_t>(shape, shape + n_shape), num_blocks_usize);
+    flatten(fp);
+    return fp;
+  } catch (const std::exception &e) {
+    fail(FHES_ERR_INVALID, "program_compile(%s): %s", op, e.what());
+    return nullptr;
+  }
+}
+
+void fhes_program_destroy(fhes_program *fp) {
+  if (!fp) return;
+  for (auto &kv : fp->images) {
+    (void)hipSetDevice(kv.first->device);
+    (void)hipFree(kv.second.buf);
+    (void)hipFree(kv.second.slot_map);
+  }
+  delete fp;
+}
+
+int fhes_program_info(const fhes_program *fp, int64_t info[8]) {
+  if (!fp || !info) return fail(FHES_ERR_INVALID, "null argument");
+  info[0] = fp->prog.n_inputs;
+  info[1] = (int64_t)fp->prog.out_slots.size();
+  info[2] = (int64_t)fp->prog.nodes.size();
+  info[3] = (int64_t)fp->prog.level_ptr.size() - 1;
+  info[4] = (int64_t)fp->term_idx.size();
+  info[5] = (int64_t)fp->prog.luts.size();
+  info[6] = fp->n_slots;
+  info[7] = fp->prog.n_pbs;
+  return FHES_OK;
+}
+
+int fhes_program_export(const fhes_program *fp, int32_t *level_ptr, int32_t *term_ptr, int32_t *term_idx,
+                        int64_t *term_coef, uint64_t *consts, int32_t *lut_ids, int32_t *out_idx,
+                        uint64_t *lut_tables, int32_t *out_slots, uint64_t *out_trivial) {
+  if (!fp || !level_ptr || !term_ptr || !consts || !lut_ids || !out_idx || !lut_tables || !out_slots)
+    return fail(FHES_ERR_INVALID, "null argument");
+  memcpy(level_ptr, fp->prog.level_ptr.data(), 4 * fp->prog.level_ptr.size());
+  memcpy(term_ptr, fp->term_ptr.data(), 4 * fp->term_ptr.size());
+  if (!fp->term_idx.empty()) {
+    if (!term_idx || !term_coef) return fail(FHES_ERR_INVALID, "null term arrays");
+    memcpy(term_idx, fp->term_idx.data(), 4 * fp->term_idx.size());
+    memcpy(term_coef, fp->term_coef.data(), 8 * fp->term_coef.size());
+  }
+  memcpy(consts, fp->consts.data(), 8 * fp->consts.size());
+  memcpy(lut_ids, fp->lut_ids.data(), 4 * fp->lut_ids.size());
+  memcpy(out_idx, fp->out_idx.data(), 4 * fp->out_idx.size());
+  for (size_t i = 0; i < fp->prog.luts.size(); i++)
+    for (int x = 0; x < 16; x++) lut_tables[i * 16 + x] = fp->prog.luts[i][x];
+  for (size_t i = 0; i < fp->prog.out_slots.size(); i++) {
+    out_slots[i] = fp->prog.out_slots[i];
+    if (out_trivial) out_trivial[i] = 0;
+  }
+  return FHES_OK;
+}
+
+int fhes_program_run(fhes_ctx *ctx, const fhes_program *cfp, const int32_t *in_handles,
+                     int32_t *out_handles) {
+  auto *fp = const_cast<fhes_program *>(cfp);
+  if (!ctx || !fp || !out_handles || (fp->prog.n_inputs > 0 && !in_handles))
+    return fail(FHES_ERR_INVALID, "program_run: null argument");
+  if (memcmp(&ctx->p, &fp->prog.params, sizeof(fhes_params)) != 0)
+    return fail(FHES_ERR_INVALID, "program_run: program was compiled for different parameters");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk2(fp->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
+  const circ::Program &p = fp->prog;
+  const int32_t n_in = p.n_inputs, n_nodes = (int32_t)p.nodes.size(), n_out = (int32_t)p.out_slots.size();
+  for (int32_t i = 0; i < n_in; i++)
+    if (in_handles[i] < 0 || in_handles[i] >= ctx->capacity) return fail(FHES_ERR_INVALID, "program_run: bad input handle");
+
+  // ---- device image (once per ctx) ----
+  auto it = fp->images.find(ctx);
+  if (it == fp->images.end()) {
+    DeviceImage img;
+    std::vector<int32_t> luts(fp->lut_ids.size());
+    std::vector<int32_t> local2ctx(p.luts.size());
+    for (size_t i = 0; i < p.luts.size(); i++) {
+      uint64_t t[16];
+      for (int x = 0; x < 16; x++) t[x] = p.luts[i][x];
+      const int32_t id = lut_register_locked(ctx, t, ctx->dims.space());
+      if (id < 0) return id;
+      local2ctx[i] = id;
+    }
+    for (size_t j = 0; j < luts.size(); j++) luts[j] = fp->lut_ids[j] < 0 ? -1 : local2ctx[fp->lut_ids[j]];
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t nt = std::max<size_t>(fp->term_idx.size(), 1), nn = std::max<size_t>(n_nodes, 1);
+    const size_t o_tp = 0, o_ti = al(o_tp + 4 * (nn + 1)), o_tc = al(o_ti + 4 * nt), o_c = al(o_tc + 8 * nt),
+                 o_l = al(o_c + 8 * nn), o_o = al(o_l + 4 * nn), total = al(o_o + 4 * nn);
+    std::vector<unsigned char> h(total, 0);
+    memcpy(&h[o_tp], fp->term_ptr.data(), 4 * fp->term_ptr.size());
+    if (!fp->term_idx.empty()) {
+      memcpy(&h[o_ti], fp->term_idx.data(), 4 * fp->term_idx.size());
+      memcpy(&h[o_tc], fp->term_coef.data(), 8 * fp->term_coef.size());
+    }
+    if (n_nodes) {
+      memcpy(&h[o_c], fp->consts.data(), 8 * (size_t)n_nodes);
+      memcpy(&h[o_l], luts.data(), 4 * (size_t)n_nodes);
+      memcpy(&h[o_o], fp->out_idx.data(), 4 * (size_t)n_nodes);
+    }
+    FHES_HIP(hipMalloc(&img.buf, total));
+    FHES_HIP(hipMemcpy(img.buf, h.data(), total, hipMemcpyHostToDevice));
+    FHES_HIP(hipMalloc(&img.slot_map, 4 * (size_t)std::max(fp->n_slots, 1)));
+    img.arrays.term_ptr = (const int32_t *)(img.buf + o_tp);
+    img.arrays.term_idx = (const int32_t *)(img.buf + o_ti);
+    img.arrays.term_coef = (const int64_t *)(img.buf + o_tc);
+    img.arrays.consts = (const uint64_t *)(img.buf + o_c);
+    img.arrays.lut_ids = (const int32_t *)(img.buf + o_l);
+    img.arrays.out_idx = (const int32_t *)(img.buf + o_o);
+    img.arrays.slot_map = img.slot_map;
+    it = fp->images.emplace(ctx, img).first;
+  }
+  DeviceImage &img = it->second;
+
+  // ---- slot map for this run ----
+  const int32_t out_base = arena_alloc_locked(ctx, std::max(n_out, 1));
+  if (out_base < 0) return out_base;
+  int32_t scratch = -1;
+  if (n_nodes > 0) {
+    scratch = arena_alloc_locked(ctx, n_nodes);
+    if (scratch < 0) {
+      arena_free_locked(ctx, out_base, std::max(n_out, 1));
+      return scratch;
+    }
+  }
+  std::vector<int32_t> map(std::max(fp->n_slots, 1));
+  for (int32_t i = 0; i < n_in; i++) map[i] = in_handles[i];
+  for (int32_t j = 0; j < n_nodes; j++) map[n_in + j] = scratch + j;
+  std::vector<std::pair<int32_t, int32_t>> copies;  // (dst handle, src slot)
+  std::vector<char> taken(fp->n_slots, 0);
+  for (int32_t k = 0; k < n_out; k++) {
+    const int32_t s = p.out_slots[k];
+    out_handles[k] = out_base + k;
+    if (s >= n_in && !taken[s]) {
+      map[s] = out_base + k;  // the node writes its result straight into the output handle
+      taken[s] = 1;
+    } else {
+      copies.push_back({out_base + k, s});
+    }
+  }
+  FHES_HIP(hipMemcpyAsync(img.slot_map, map.data(), 4 * map.size(), hipMemcpyHostToDevice, ctx->stream));
+  FHES_HIP(hipStreamSynchronize(ctx->stream));  // `map` is a stack object
+
+  // ---- execute level by level ----
+  int rc = FHES_OK;
+  for (int lv = 0; lv < fp->n_pbs_levels && rc == FHES_OK; lv++)
+    rc = launch_pbs(ctx, img.arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv]);
+  if (rc == FHES_OK && fp->has_linear_level) {
+    const int lv = fp->n_pbs_levels;
+    rc = launch_linear(ctx, img.arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv]);
+  }
+  if (rc == FHES_OK) {
+    const size_t bytes = (size_t)ctx->dims.ct_words() * 8;
+    for (auto &c : copies) {
+      hipError_t e = hipMemcpyAsync(ctx->arena + (size_t)c.first * ctx->ct_stride,
+                                    ctx->arena + (size_t)map[c.second] * ctx->ct_stride, bytes,
+                                    hipMemcpyDeviceToDevice, ctx->stream);
+      if (e != hipSuccess) { rc = hip_fail(e, "output copy"); break; }
+    }
+  }
+  // scratch is released in stream order: later work on this ctx is queued behind the reads
+  if (scratch >= 0) arena_free_locked(ctx, scratch, n_nodes);
+  if (rc != FHES_OK) arena_free_locked(ctx, out_base, std::max(n_out, 1));
+  return rc;
+}
+
+}  // extern "C"

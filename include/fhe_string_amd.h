@@ -197,6 +197,8 @@ int32_t fhes_ct_num_blocks(const fhes_ct *ct);
 int fhes_string_decrypt(const fhes_client_key *ck, fhes_ct *s, char *buf, int64_t buf_len);
 int fhes_usize_decrypt(const fhes_client_key *ck, fhes_ct *v, uint64_t *out);
 int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out);
+/* raw decoded value (message + carry + padding bit) of every block; values[num_blocks] */
+int fhes_ct_decrypt_blocks(const fhes_client_key *ck, fhes_ct *c, uint8_t *values);
 
 /* Generic operation dispatch: op names as in fhes_program_compile.  `args` are the
  * ciphertext operands (self first), `iargs` clear integer arguments.  Results are

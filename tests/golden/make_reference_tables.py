@@ -1,0 +1,125 @@
+"""Writes tests/golden/reference_tables.json: the plaintext-level pins of the reference.
+
+The reference's tests assert decrypt(fhe_op(encrypt(x))) == std::str op(x)
+(/root/reference/src/ciphertext/tests/*.rs).  Inputs below are those tables (file:line
+cited per group); expected values are Rust `std::str` results, written out literally
+where SURVEY.md section 8c lists them and otherwise computed by `rust_*` helpers that
+restate the std semantics (the traps: "abc".split("") == ["", "a", "b", "c", ""];
+rfind("") == len).
+"""
+import json
+import os
+
+
+def rust_split(s, p):
+    if p == "":
+        return [""] + list(s) + [""]
+    return s.split(p)
+
+
+def rust_rsplit(s, p):
+    # Rust searches from the right (non-overlapping matches are chosen right to left)
+    if p == "":
+        return list(reversed(rust_split(s, p)))
+    return list(reversed(s.rsplit(p)))
+
+
+def rust_split_inclusive(s, p):
+    parts, out = s.split(p), []
+    for i, x in enumerate(parts):
+        if i < len(parts) - 1:
+            out.append(x + p)
+        elif x != "":
+            out.append(x)
+    return out
+
+
+def rust_split_terminator(s, p):
+    v = rust_split(s, p)
+    if v and v[-1] == "":
+        v = v[:-1]
+    return v
+
+
+def rust_rsplit_terminator(s, p):
+    # back-to-front iteration; the piece after the last match is skipped if empty
+    v = rust_rsplit(s, p)
+    if v and v[0] == "":
+        v = v[1:]
+    return v
+
+
+def opt(v):
+    return None if v < 0 else v
+
+
+cases = []
+
+
+def add(op, a, a_pad, b=None, b_pad=None, expect=None, src=""):
+    cases.append({"op": op, "a": a, "a_pad": a_pad, "b": b, "b_pad": b_pad, "expect": expect, "src": src})
+
+
+# tests/search.rs:15-40 (find / rfind / contains), :96-115 (starts_with / ends_with)
+search = [("abcabc", None, "ab", None), ("abc", 3, "d", 5), ("abcdef", None, "cde", None), ("abc", None, "", None)]
+find_expect = [0, None, 2, 0]
+rfind_expect = [3, None, 2, 3]
+contains_expect = [True, False, True, True]
+for (a, ap, b, bp), f, r, c in zip(search, find_expect, rfind_expect, contains_expect):
+    assert opt(a.find(b)) == f and opt(a.rfind(b)) == r and (b in a) == c
+    add("find", a, ap, b, bp, f, "tests/search.rs:15-40")
+    add("rfind", a, ap, b, bp, r, "tests/search.rs:15-40")
+    add("contains", a, ap, b, bp, c, "tests/search.rs:15-40")
+for (a, ap, b, bp), sw, ew in zip(search[:3], [True, False, False], [False, False, False]):
+    assert a.startswith(b) == sw and a.endswith(b) == ew
+    add("starts_with", a, ap, b, bp, sw, "tests/search.rs:96-115")
+    add("ends_with", a, ap, b, bp, ew, "tests/search.rs:96-115")
+
+# tests/compare.rs:13-38 (is_empty)
+for a, ap in [("a", None), ("a", 3), ("abc", None), ("abc", 5), ("", None), ("", 3)]:
+    add("is_empty", a, ap, expect=(a == ""), src="tests/compare.rs:13-38")
+# tests/compare.rs:67-110 (eq / ne): T,T,F,F,F,F,T
+eqs = [("abc", None, "abc", None), ("abc", 3, "abc", 5), ("abc", None, "abcd", None), ("abcd", None, "ab", None),
+       ("a", None, "b", None), ("a", None, "", None), ("", None, "", None)]
+for (a, ap, b, bp), e in zip(eqs, [True, True, False, False, False, False, True]):
+    assert (a == b) == e
+    add("eq", a, ap, b, bp, e, "tests/compare.rs:67-110")
+    add("ne", a, ap, b, bp, not e, "tests/compare.rs:67-110")
+# tests/compare.rs:156-199 (le, lt, ge, gt): TFTF, TFTF, TTFF, FFTT, TTFF, FFTT, FFTT
+cmps = [("abc", None, "abc", None), ("abc", 3, "abc", 5), ("abc", None, "abcd", None), ("abcd", None, "ab", None),
+        ("abc", None, "bcd", None), ("cde", None, "abc", None), ("a", None, "", None)]
+rows = ["TFTF", "TFTF", "TTFF", "FFTT", "TTFF", "FFTT", "FFTT"]
+for (a, ap, b, bp), row in zip(cmps, rows):
+    for op, ch, py in zip(["le", "lt", "ge", "gt"], row, [a <= b, a < b, a >= b, a > b]):
+        assert (ch == "T") == py
+        add(op, a, ap, b, bp, ch == "T", "tests/compare.rs:156-199")
+# tests/mod.rs:47-60 (len)
+for a, ap in [("", None), ("abc", None), ("abc", 8)]:
+    add("len", a, ap, expect=len(a), src="tests/mod.rs:47-60")
+# tests/split.rs:17-48 (split); pad applies to input AND pattern (split.rs:51-52)
+splits = [("xxx", "x", None), ("axbxc", "x", None), ("xxx", "xx", None), ("abc", "", None), ("axbxc", "x", 8), ("abc", "", 8)]
+split_expect = [["", "", "", ""], ["a", "b", "c"], ["", "x"], ["", "a", "b", "c", ""], ["a", "b", "c"], ["", "a", "b", "c", ""]]
+for (a, p, pad), e in zip(splits, split_expect):
+    assert rust_split(a, p) == e
+    add("split", a, pad, p, pad, e, "tests/split.rs:17-48")
+# tests/split.rs:137-155 (split_terminator), :188-206 (split_inclusive), :284-317 (rsplit), :350-368 (rsplit_terminator)
+four = [("xxx", "x", None), ("axbxc", "x", None), ("xxx", "xx", None), ("axbxc", "x", 8)]
+for a, p, pad in four:
+    add("split_terminator", a, pad, p, pad, rust_split_terminator(a, p), "tests/split.rs:137-155")
+    add("split_inclusive", a, pad, p, pad, rust_split_inclusive(a, p), "tests/split.rs:188-206")
+    add("rsplit_terminator", a, pad, p, pad, rust_rsplit_terminator(a, p), "tests/split.rs:350-368")
+for a, p, pad in [("xxx", "x", None), ("axbxc", "x", None), ("xxx", "xx", None), ("xaxbx", "x", None), ("axb", "x", None),
+                  ("abxxcdxxef", "xx", None), ("axbxc", "x", 8)]:
+    add("rsplit", a, pad, p, pad, rust_rsplit(a, p), "tests/split.rs:284-317")
+# README.md:34 / examples/cmd: input " A bcbc ", pattern "bc" (BASELINE config 1)
+a, b = " A bcbc ", "bc"
+add("contains", a, None, b, None, True, "README.md:34")
+add("find", a, None, b, None, 3, "README.md:34")
+add("rfind", a, None, b, None, 5, "README.md:34")
+add("eq", a, None, b, None, False, "README.md:34")
+add("split", a, None, b, None, [" A ", "", " "], "README.md:34")
+
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tables.json")
+with open(out, "w") as f:
+    json.dump({"source": "matthiasgeihs/fhe_string src/ciphertext/tests/*.rs, README.md", "cases": cases}, f, indent=1)
+print(len(cases), "cases ->", out)

@@ -29,7 +29,7 @@ def load():
         "oracle_blind_rotate": (None, [_P, _P, _P, _P]),
         "oracle_sample_extract": (None, [_P, _P, _P]),
         "oracle_pbs": (None, [_P, _P, _P, _P]),
-        "oracle_exec_levels": (C.c_int, [_P, _P, C.c_size_t, C.c_int32] + [_P] * 9 + [C.c_int32]),
+        "oracle_exec_levels": (C.c_int, [_P, _P, C.c_size_t, C.c_int32] + [_P] * 8 + [C.c_int32]),
         "oracle_lwe_phase": (C.c_uint64, [_P, _P, C.c_int32]),
     }
     for name, (res, args) in sig.items():

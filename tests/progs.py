@@ -1,0 +1,126 @@
+"""Test-side view of compiled programs: export, plaintext model, execution on the oracle."""
+import ctypes as C
+
+import numpy as np
+
+from fhe_string_amd import _lib
+from fhe_string_amd._lib import check, check_ptr
+from tests.helpers import ptr
+
+
+class Prog:
+    def __init__(self, params, op, shape, bu):
+        self.lib = _lib.load(strict=False)
+        self.params, self.op, self.shape, self.bu = params, op, list(shape), bu
+        sh = np.array(shape, dtype=np.int32)
+        self.h = check_ptr(self.lib.fhes_program_compile(C.byref(params), op.encode(), ptr(sh), len(shape), bu))
+        info = (C.c_int64 * 8)()
+        check(self.lib.fhes_program_info(self.h, info))
+        (self.n_inputs, self.n_outputs, self.n_nodes, self.n_levels, self.n_terms, self.n_luts,
+         self.n_slots, self.n_pbs) = [int(v) for v in info]
+        self.level_ptr = np.zeros(self.n_levels + 1, dtype=np.int32)
+        self.term_ptr = np.zeros(self.n_nodes + 1, dtype=np.int32)
+        self.term_idx = np.zeros(max(self.n_terms, 1), dtype=np.int32)
+        self.term_coef = np.zeros(max(self.n_terms, 1), dtype=np.int64)
+        self.consts = np.zeros(max(self.n_nodes, 1), dtype=np.uint64)
+        self.lut_ids = np.zeros(max(self.n_nodes, 1), dtype=np.int32)
+        self.out_idx = np.zeros(max(self.n_nodes, 1), dtype=np.int32)
+        self.lut_tables = np.zeros((max(self.n_luts, 1), 16), dtype=np.uint64)
+        self.out_slots = np.zeros(max(self.n_outputs, 1), dtype=np.int32)
+        check(self.lib.fhes_program_export(self.h, ptr(self.level_ptr), ptr(self.term_ptr), ptr(self.term_idx),
+                                           ptr(self.term_coef), ptr(self.consts), ptr(self.lut_ids),
+                                           ptr(self.out_idx), ptr(self.lut_tables), ptr(self.out_slots), None))
+
+    def __del__(self):
+        try:
+            self.lib.fhes_program_destroy(self.h)
+        except Exception:
+            pass
+
+    # ---- plaintext model: values modulo 2*space (message, carry, padding bit) ----
+    def run_plain(self, inputs, strict=True):
+        bits = self.params.message_bits + self.params.carry_bits
+        space = 1 << bits
+        full = 2 * space
+        delta_shift = 63 - bits
+        vals = np.zeros(self.n_slots, dtype=np.int64)
+        vals[:self.n_inputs] = inputs
+        tp, ti, tc = self.term_ptr, self.term_idx, self.term_coef
+        luts = self.lut_tables.astype(np.int64)
+        csts = (self.consts >> np.uint64(delta_shift)).astype(np.int64)
+        for j in range(self.n_nodes):
+            a, b = tp[j], tp[j + 1]
+            x = (int(np.dot(tc[a:b], vals[ti[a:b]])) + int(csts[j])) % full
+            lid = self.lut_ids[j]
+            if lid < 0:
+                out = x
+            elif x < space:
+                out = int(luts[lid][x])
+            else:  # padding bit set: negacyclic lookup (only the signed comparison uses this)
+                out = (-int(luts[lid][x - space])) % full
+            vals[self.out_idx[j]] = out
+        return vals[self.out_slots[:self.n_outputs]]
+
+    # ---- real crypto on the CPU oracle ----
+    def run_oracle(self, w, input_cts, threads=8):
+        arena = np.zeros((self.n_slots, w.W), dtype=np.uint64)
+        arena[:self.n_inputs] = input_cts
+        polys = np.zeros((max(self.n_luts, 1), w.N), dtype=np.uint64)
+        for i in range(self.n_luts):
+            t = np.ascontiguousarray(self.lut_tables[i])
+            w.orc.oracle_make_lut_poly(w.oc, ptr(t), ptr(polys[i]))
+        rc = w.orc.oracle_exec_levels(w.oc, ptr(arena), w.W, self.n_levels, ptr(self.level_ptr), ptr(self.term_ptr),
+                                      ptr(self.term_idx), ptr(self.term_coef), ptr(self.consts), ptr(self.lut_ids),
+                                      ptr(polys), ptr(self.out_idx), threads)
+        assert rc == 0
+        return arena[self.out_slots[:self.n_outputs]], arena
+
+
+# ---- shared string plumbing (block encodings as in mod.rs:58-92) ----
+def num_blocks_usize(l, msg_mod=4):
+    n, v = 0, 1
+    while v < l + 1:
+        v *= msg_mod
+        n += 1
+    return n
+
+
+def string_blocks(s, pad=None, bc=4, msg_mod=4):
+    """message digits of an FheString: chars + terminator (+ zero padding), little-endian base 4"""
+    slots = (len(s) if pad is None else pad) + 1
+    out = np.zeros(slots * bc, dtype=np.uint8)
+    for i, ch in enumerate(s.encode("latin-1")):
+        c = ch
+        for k in range(bc):
+            out[i * bc + k] = c % msg_mod
+            c //= msg_mod
+    return out
+
+
+def radix_value(digits, msg_mod=4):
+    v = 0
+    for k in reversed(range(len(digits))):
+        v = v * msg_mod + int(digits[k]) % msg_mod
+    return v
+
+
+def decode_result(op, outs, bu, s=None):
+    """decoded message values of the program outputs -> Python value as the reference's
+    decrypt would give (FheOption::decrypt mod.rs:378-386, FheStringSliceVector::decrypt
+    split.rs:208-226)."""
+    outs = [int(v) for v in outs]
+    if op in ("find", "rfind"):
+        return radix_value(outs[1:1 + bu]) if outs[0] & 1 else None
+    if op == "len":
+        return radix_value(outs[:bu])
+    if "split" in op:
+        n = len(outs) // (1 + 2 * bu)
+        res = []
+        for i in range(n):
+            if not outs[i] & 1:
+                continue
+            a = radix_value(outs[n + i * bu:n + (i + 1) * bu])
+            b = radix_value(outs[n + n * bu + i * bu:n + n * bu + (i + 1) * bu])
+            res.append(s[a:b] if a <= b <= len(s) else "")
+        return res
+    return bool(outs[0] & 1)

@@ -1,0 +1,81 @@
+"""The C-ABI library loads and exports every symbol include/fhe_string_amd.h declares;
+host-only entry points work and device entry points fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from fhe_string_amd import _lib
+from fhe_string_amd._lib import Params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fhe_string_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fhes_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(libs):
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) > 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # and the Python binding knows every one of them
+    assert not [n for n in names if n not in _lib.SIGNATURES]
+
+
+def test_parameter_sets_and_block_counts(libs):
+    lib, _ = libs
+    p = Params()
+    assert lib.fhes_params_default(C.byref(p)) == 0
+    assert (p.lwe_dim, p.glwe_dim, p.poly_size, p.pbs_base_log, p.pbs_level, p.ks_base_log, p.ks_level) == \
+           (742, 1, 2048, 23, 1, 3, 5)
+    assert lib.fhes_ct_words(C.byref(p)) == 2049
+    assert lib.fhes_bsk_words(C.byref(p)) * 8 == 48627712
+    assert lib.fhes_ksk_words(C.byref(p)) * 8 == 60866560
+    for l, bu in [(255, 4), (256, 5), (512, 5), (1024, 6), (3, 1), (63, 3)]:   # lib.rs:51-62
+        ck = lib.fhes_client_key_generate(C.byref(p), l, 7)
+        assert lib.fhes_client_key_num_blocks_char(ck) == 4
+        assert lib.fhes_client_key_num_blocks_usize(ck) == bu
+        lib.fhes_client_key_destroy(ck)
+
+
+def test_string_validation_errors(libs):
+    """the error cases of FheString::new (mod.rs:59-70)"""
+    from fhe_string_amd.api import ClientKey, FheString, toy_params
+    from fhe_string_amd._lib import FheError
+    ck = ClientKey(toy_params(), l=15, seed=3)
+    assert FheString.new(ck, "abc").num_blocks == 16
+    assert FheString.new(ck, "abc", 7).num_blocks == 32
+    assert FheString.new(ck, "abc", 7).decrypt(ck) == "abc"
+    for s, pad, code in [("\xe9", None, -10), ("a" * 16, None, -12), ("a", 16, -13), ("abc", 2, -14)]:
+        with pytest.raises(FheError) as e:
+            FheString.new(ck, s, pad)
+        assert e.value.code == code
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_device_entry_points_fail_loudly_without_gpu(libs):
+    lib, _ = libs
+    p = Params()
+    lib.fhes_params_default(C.byref(p))
+    assert not lib.fhes_ctx_create(C.byref(p), 0)
+    assert b"no HIP device" in lib.fhes_last_error() or b"HIP error" in lib.fhes_last_error()
+    ck = lib.fhes_client_key_generate(C.byref(p), 255, 7)
+    assert not lib.fhes_server_key_create(ck, 0)
+    lib.fhes_client_key_destroy(ck)
+
+
+def test_compile_rejects_bad_requests(libs):
+    lib, _ = libs
+    p = Params()
+    lib.fhes_params_default(C.byref(p))
+    sh = np.array([3, 2], dtype=np.int32)
+    assert not lib.fhes_program_compile(C.byref(p), b"no_such_op", sh.ctypes.data_as(C.c_void_p), 2, 4)
+    assert b"unknown operation" in lib.fhes_last_error()
+    assert not lib.fhes_program_compile(C.byref(p), b"find", sh.ctypes.data_as(C.c_void_p), 1, 4)
