@@ -20,7 +20,8 @@ class Stats(C.Structure):
     _fields_ = [("pbs_count", C.c_uint64), ("pbs_launches", C.c_uint64), ("linear_count", C.c_uint64),
                 ("arena_capacity", C.c_uint64), ("arena_in_use", C.c_uint64),
                 ("last_ks_ms", C.c_double), ("last_br_ms", C.c_double),
-                ("total_ks_ms", C.c_double), ("total_br_ms", C.c_double)]
+                ("total_ks_ms", C.c_double), ("total_br_ms", C.c_double),
+                ("timed_launches", C.c_uint64)]
 
 
 class FheError(RuntimeError):

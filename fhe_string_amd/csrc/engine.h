@@ -46,7 +46,9 @@ struct fhes_ctx {
   // stats / timing
   fhes_stats stats{};
   bool timing = false;
-  hipEvent_t ev[3]{};
+  struct Timed { hipEvent_t e0, e1, e2; };
+  std::vector<Timed> pending;         // launches whose events are not yet read
+  std::vector<hipEvent_t> ev_free;    // recycled events
   int br_variant = 0;
 
   explicit fhes_ctx(const fhes_params &pp) : p(pp), dims(pp) {}
@@ -74,5 +76,6 @@ int launch_linear(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t 
 int32_t arena_alloc_locked(fhes_ctx *ctx, int32_t count);
 int arena_free_locked(fhes_ctx *ctx, int32_t first, int32_t count);
 int32_t lut_register_locked(fhes_ctx *ctx, const uint64_t *table, int32_t n);
+int collect_timing_locked(fhes_ctx *ctx);  // synchronises the stream
 
 }  // namespace fhes

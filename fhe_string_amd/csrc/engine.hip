@@ -178,6 +178,32 @@ static int launch_br_v1(fhes_ctx *ctx, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+static int take_event(fhes_ctx *ctx, hipEvent_t *e) {
+  if (!ctx->ev_free.empty()) {
+    *e = ctx->ev_free.back();
+    ctx->ev_free.pop_back();
+    return FHES_OK;
+  }
+  FHES_HIP(hipEventCreate(e));
+  return FHES_OK;
+}
+
+int collect_timing_locked(fhes_ctx *ctx) {
+  if (ctx->pending.empty()) return FHES_OK;
+  FHES_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto &t : ctx->pending) {
+    float ks = 0, br = 0;
+    FHES_HIP(hipEventElapsedTime(&ks, t.e0, t.e1));
+    FHES_HIP(hipEventElapsedTime(&br, t.e1, t.e2));
+    ctx->stats.last_ks_ms = ks; ctx->stats.last_br_ms = br;
+    ctx->stats.total_ks_ms += ks; ctx->stats.total_br_ms += br;
+    ctx->stats.timed_launches += 1;
+    ctx->ev_free.push_back(t.e0); ctx->ev_free.push_back(t.e1); ctx->ev_free.push_back(t.e2);
+  }
+  ctx->pending.clear();
+  return FHES_OK;
+}
+
 int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count) {
   if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
   const int32_t kMaxChunk = 16384;
@@ -186,21 +212,20 @@ int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t cou
     int rc = ensure_ks_out(ctx, c);
     if (rc) return rc;
     dev::NodeDesc d = make_desc(a, first + off, c);
-    if (ctx->timing) FHES_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    fhes_ctx::Timed t{};
+    if (ctx->timing) {
+      if ((rc = take_event(ctx, &t.e0)) || (rc = take_event(ctx, &t.e1)) || (rc = take_event(ctx, &t.e2))) return rc;
+      FHES_HIP(hipEventRecord(t.e0, ctx->stream));
+    }
     rc = launch_keyswitch(ctx, d);
     if (rc) return rc;
-    if (ctx->timing) FHES_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (ctx->timing) FHES_HIP(hipEventRecord(t.e1, ctx->stream));
     if (ctx->dims.N == 2048) rc = launch_br_v1<11>(ctx, d);
     else rc = launch_br_v1<8>(ctx, d);
     if (rc) return rc;
     if (ctx->timing) {
-      FHES_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-      FHES_HIP(hipEventSynchronize(ctx->ev[2]));
-      float ks = 0, br = 0;
-      FHES_HIP(hipEventElapsedTime(&ks, ctx->ev[0], ctx->ev[1]));
-      FHES_HIP(hipEventElapsedTime(&br, ctx->ev[1], ctx->ev[2]));
-      ctx->stats.last_ks_ms = ks; ctx->stats.last_br_ms = br;
-      ctx->stats.total_ks_ms += ks; ctx->stats.total_br_ms += br;
+      FHES_HIP(hipEventRecord(t.e2, ctx->stream));
+      ctx->pending.push_back(t);
     }
     ctx->stats.pbs_count += (uint64_t)c;
     ctx->stats.pbs_launches += 1;
@@ -293,8 +318,6 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   };
   if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-  for (auto &ev : ctx->ev)
-    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
 
   ctx->ct_stride = d.big + 16;
   const char *env = getenv("FHES_ARENA_SLOTS");
@@ -323,7 +346,8 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->bsk_f);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->lut_polys);
   (void)hipFree(ctx->ks_out); (void)hipFree(ctx->desc_buf);
-  for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
+  for (auto &ev : ctx->ev_free) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -440,6 +464,9 @@ int fhes_sync(fhes_ctx *ctx) {
 int fhes_get_stats(fhes_ctx *ctx, fhes_stats *out) {
   if (!ctx || !out) return fail(FHES_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  int rc = collect_timing_locked(ctx);
+  if (rc) return rc;
   ctx->stats.arena_capacity = (uint64_t)ctx->capacity;
   ctx->stats.arena_in_use = (uint64_t)ctx->in_use;
   *out = ctx->stats;
@@ -449,6 +476,9 @@ int fhes_get_stats(fhes_ctx *ctx, fhes_stats *out) {
 int fhes_reset_stats(fhes_ctx *ctx) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
   std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  int rc = collect_timing_locked(ctx);
+  if (rc) return rc;
   ctx->stats = fhes_stats{};
   return FHES_OK;
 }

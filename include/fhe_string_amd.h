@@ -112,6 +112,7 @@ typedef struct fhes_stats {
   double last_br_ms;         /* HIP-event duration of the last blind-rotate launch  */
   double total_ks_ms;        /* accumulated while timing is enabled                 */
   double total_br_ms;
+  uint64_t timed_launches;   /* launch pairs included in total_*_ms                 */
 } fhes_stats;
 
 fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device);
