@@ -30,6 +30,7 @@ struct fhes_ctx {
   uint64_t *ksk = nullptr;   // [big][ks_level][ks_stride]
   int ks_stride = 0;
   double2 *bsk_f = nullptr;  // canonical [n][2][2][M]
+  double2 *bsk_e = nullptr;  // engine layout for blind-rotate variant 2: [n][2][2][8][M/8]
   double2 *twist = nullptr, *tw = nullptr;
 
   // LUT registry
@@ -77,5 +78,6 @@ int32_t arena_alloc_locked(fhes_ctx *ctx, int32_t count);
 int arena_free_locked(fhes_ctx *ctx, int32_t first, int32_t count);
 int32_t lut_register_locked(fhes_ctx *ctx, const uint64_t *table, int32_t n);
 int collect_timing_locked(fhes_ctx *ctx);  // synchronises the stream
+bool ctx_is_live(fhes_ctx *ctx);
 
 }  // namespace fhes

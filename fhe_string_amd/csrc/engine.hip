@@ -9,10 +9,19 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 
 #include "kernels.hip.h"
 
 namespace fhes {
+
+// registry of live contexts: ciphertext objects may outlive their server key
+static std::mutex g_live_mu;
+static std::set<fhes_ctx *> g_live;
+bool ctx_is_live(fhes_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  return g_live.count(ctx) != 0;
+}
 
 int hip_fail(hipError_t e, const char *what) {
   return fail(FHES_ERR_NO_DEVICE, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
@@ -178,6 +187,30 @@ static int launch_br_v1(fhes_ctx *ctx, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+template <int LOGN>
+static int launch_br_v2(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  constexpr int N = 1 << LOGN, M = N / 2;
+  const size_t lds = (size_t)2 * N * 8 + (size_t)4 * M * 16 + (size_t)((ctx->dims.n + 1 + 3) & ~3) * 4;
+  auto kern = dev::blind_rotate_v2_kernel<LOGN, 23>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(d.count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
+                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
+                     ctx->lut_polys, ctx->twist, ctx->tw);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
+static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  const int variant = ctx->br_variant == 0 ? 2 : ctx->br_variant;
+  if (ctx->dims.N == 2048) return variant == 1 ? launch_br_v1<11>(ctx, d) : launch_br_v2<11>(ctx, d);
+  return variant == 1 ? launch_br_v1<8>(ctx, d) : launch_br_v2<8>(ctx, d);
+}
+
 static int take_event(fhes_ctx *ctx, hipEvent_t *e) {
   if (!ctx->ev_free.empty()) {
     *e = ctx->ev_free.back();
@@ -220,8 +253,7 @@ int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t cou
     rc = launch_keyswitch(ctx, d);
     if (rc) return rc;
     if (ctx->timing) FHES_HIP(hipEventRecord(t.e1, ctx->stream));
-    if (ctx->dims.N == 2048) rc = launch_br_v1<11>(ctx, d);
-    else rc = launch_br_v1<8>(ctx, d);
+    rc = launch_blind_rotate(ctx, d);
     if (rc) return rc;
     if (ctx->timing) {
       FHES_HIP(hipEventRecord(t.e2, ctx->stream));
@@ -336,14 +368,22 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   if ((e = hipMalloc(&ctx->tw, tw.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(tw)");
   if ((e = hipMemcpy(ctx->twist, twist.data(), twist.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy twist");
   if ((e = hipMemcpy(ctx->tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy tw");
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.insert(ctx);
+  }
   return ctx;
 }
 
 void fhes_ctx_destroy(fhes_ctx *ctx) {
   if (!ctx) return;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.erase(ctx);
+  }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->bsk_f);
+  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->lut_polys);
   (void)hipFree(ctx->ks_out); (void)hipFree(ctx->desc_buf);
   for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
@@ -379,6 +419,12 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
     else
       hipLaunchKernelGGL((dev::bsk_to_fourier_kernel<8>), dim3(npoly), dim3(d.M / 8), lds, ctx->stream, tmp, ctx->bsk_f, ctx->twist, ctx->tw);
     FHES_HIP(hipGetLastError());
+    if (!ctx->bsk_e) FHES_HIP(hipMalloc(&ctx->bsk_e, npoly * d.M * 16));
+    if (d.N == 2048)
+      hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<11>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e);
+    else
+      hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<8>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e);
+    FHES_HIP(hipGetLastError());
     FHES_HIP(hipStreamSynchronize(ctx->stream));
     FHES_HIP(hipFree(tmp));
   }
@@ -401,6 +447,7 @@ int32_t fhes_arena_alloc(fhes_ctx *ctx, int32_t count) {
 
 int fhes_arena_free(fhes_ctx *ctx, int32_t first, int32_t count) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
+  if (!ctx_is_live(ctx)) return FHES_OK;  // the arena went away with its context
   std::lock_guard<std::mutex> lk(ctx->mu);
   FHES_HIP(hipSetDevice(ctx->device));
   FHES_HIP(hipStreamSynchronize(ctx->stream));  // slots may still be read by queued work
@@ -420,6 +467,7 @@ int fhes_arena_upload(fhes_ctx *ctx, int32_t first, int32_t count, const uint64_
 }
 
 int fhes_arena_download(fhes_ctx *ctx, int32_t first, int32_t count, uint64_t *host) {
+  if (ctx && !ctx_is_live(ctx)) return fail(FHES_ERR_STATE, "the server key owning this ciphertext was destroyed");
   if (!ctx || !host || first < 0 || count <= 0 || (int64_t)first + count > ctx->capacity)
     return fail(FHES_ERR_INVALID, "arena_download: bad range");
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -491,6 +539,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
+  if (v < 0 || v > 2) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
   ctx->br_variant = v;
   return FHES_OK;
 }

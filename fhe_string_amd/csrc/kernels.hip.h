@@ -410,5 +410,254 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
   if (tid == 0) out[N] = acc[N];
 }
 
+// ------------------------------------------------------------------------------------------
+// K2+K3 (variant 2): latency-oriented blind rotate.  Same arithmetic as variant 1 (so the
+// same bits), different mapping:
+//   * twiddles / twists of every pass and the thread's own accumulator coefficients live
+//     in registers for the whole kernel (one workgroup per CU -> 512 VGPRs per lane);
+//   * the GGSW of iteration i is fetched into registers at the top of the iteration from a
+//     lane-coalesced "engine layout" [i][row][col][e][q] and is consumed after the forward FFT;
+//   * the last radix-2 stage (index bit 0 = lane bit 0) runs on DPP quad permutes, so a
+//     transform needs 2 LDS exchanges instead of 3 (N = 2048);
+//   * LDS exchange buffers are XOR-swizzled (conflict-free ds_read/write_b128 in all passes).
+// Requires (log2(N) - 1) % 3 == 1  (N = 2048, N = 256).
+// LDS: acc u64[2][N] | fbuf double2[2][M] | dx double2[2][M] | a_tilde
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fswz(int p) { return p ^ (((p >> 4) & 7) << 1); }
+
+__device__ __forceinline__ double dpp_swap1(double v) {  // value of lane ^ 1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// radix-2 stage on index bit 0 across lane pairs (twiddle index 0: exactly 1), DIF == DIT
+__device__ __forceinline__ void fft_stage_bit0_dpp(double2 (&x)[8], int odd) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const double px = dpp_swap1(x[e].x), py = dpp_swap1(x[e].y);
+    // even lane: u + v (own + partner); odd lane: u - v (partner - own)
+    x[e].x = odd ? (px - x[e].x) : (x[e].x + px);
+    x[e].y = odd ? (py - x[e].y) : (x[e].y + py);
+  }
+}
+
+// butterflies of a 3-bit pass with the 7 twiddles held in registers:
+// w[0..3] for the top bit (by e & 3), w[4..5] for the middle bit (by e & 1), w[6] for the low bit
+template <bool FWD>
+__device__ __forceinline__ void fft_butterflies_reg(double2 (&x)[8], const double2 (&w)[7]) {
+#pragma unroll
+  for (int st = 0; st < 3; ++st) {
+    const int fb = FWD ? (2 - st) : st;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e & (1 << fb)) continue;
+      const int e1 = e | (1 << fb);
+      const double2 tw = fb == 2 ? w[e & 3] : (fb == 1 ? w[4 + (e & 1)] : w[6]);
+      const double2 u = x[e], v = x[e1];
+      if (FWD) {
+        const double2 d = make_double2(u.x - v.x, u.y - v.y);
+        x[e] = make_double2(u.x + v.x, u.y + v.y);
+        x[e1] = cmul(d, tw);
+      } else {
+        const double2 vv = cmul_conj(v, tw);
+        x[e] = make_double2(u.x + vv.x, u.y + vv.y);
+        x[e1] = make_double2(u.x - vv.x, u.y - vv.y);
+      }
+    }
+  }
+}
+
+template <int LOGM, int LO>
+__device__ __forceinline__ void load_pass_twiddles(double2 (&w)[7], int q, const double2 *__restrict__ tw) {
+  // same index formula as fft_butterflies<LOGM, *, LO, 3>
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int fb = k < 4 ? 2 : (k < 6 ? 1 : 0);
+    const int e = k < 4 ? k : (k < 6 ? (k - 4) : 0);  // representative point with bit fb clear
+    const int beta = LO + fb, sh = LOGM - 1 - beta;
+    const int p = fft_point<LOGM, LO, 3>(q, e);
+    w[k] = tw[(p & ((1 << beta) - 1)) << sh];
+  }
+}
+
+template <int LOGN, int BL>
+__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1) void blind_rotate_v2_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
+    int ks_stride, int n_small, const double2 *__restrict__ bsk_e /* engine layout */,
+    const uint64_t *__restrict__ lut_polys, const double2 *__restrict__ twist,
+    const double2 *__restrict__ tw) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
+  constexpr int NP = (LOGM - 1) / 3;  // number of 3-bit passes (bit 0 is the DPP stage)
+  static_assert(LOGM % 3 == 1, "variant 2 needs log2(N/2) % 3 == 1");
+  static_assert(NP == 2 || NP == 3, "supported: N = 256, N = 2048");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                                      // [2][N]
+  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);                   // [2][M]
+  double2 *dx = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16);  // [2][8][TP]
+  uint32_t *at = reinterpret_cast<uint32_t *>(smem_raw + (size_t)2 * N * 8 + (size_t)4 * M * 16);
+
+  const int tid = threadIdx.x;
+  const int r = tid / TP;
+  const int q = tid % TP;
+  const int odd = q & 1;
+  const int node = d.first + blockIdx.x;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  for (int j = tid; j <= n_small; j += blockDim.x)
+    at[j] = (uint32_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  __syncthreads();
+
+  // pass layouts: pass k (k = 0 .. NP-1) owns index bits [LOGM-3-3k, LOGM-3k)
+  constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
+  double2 wA[7], wB[7], wC[7], twr[8];
+  load_pass_twiddles<LOGM, LO_A>(wA, q, tw);
+  load_pass_twiddles<LOGM, LO_B>(wB, q, tw);
+  if (NP == 3) load_pass_twiddles<LOGM, LO_C>(wC, q, tw);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) twr[e] = twist[fft_point<LOGM, LO_A, 3>(q, e)];
+
+  // ---- acc = (0, X^{-b~} * LUT); own coefficients also kept in registers ----
+  uint64_t own_lo[8], own_hi[8];  // coefficients p and p + M of polynomial r
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      own_lo[e] = v0;
+      own_hi[e] = v1;
+      acc[(size_t)r * N + p] = v0;
+      acc[(size_t)r * N + p + M] = v1;
+    }
+  }
+  __syncthreads();
+
+  const uint64_t *acc_r = acc + (size_t)r * N;
+  double2 *buf_r = fbuf + (size_t)r * M;
+  const double scale = 1.0 / (double)M;
+
+  for (int i = 0; i < n_small; ++i) {
+    const int a = (int)at[i];
+    if (a == 0) continue;
+
+    // ---- prefetch this iteration's GGSW column r (consumed after the forward FFT) ----
+    double2 g0[8], g1[8];
+    {
+      const double2 *G = bsk_e + (size_t)i * 4 * M;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        g0[e] = G[((size_t)(0 * 2 + r) * 8 + e) * TP + q];
+        g1[e] = G[((size_t)(1 * 2 + r) * 8 + e) * TP + q];
+      }
+    }
+
+    // ---- diff -> digit -> twist ----
+    double2 x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      const uint64_t d0 = rot_read<N>(acc_r, a, p) - own_lo[e];
+      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - own_hi[e];
+      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twr[e]);
+    }
+
+    // ---- forward FFT ----
+    fft_butterflies_reg<true>(x, wA);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+    fft_butterflies_reg<true>(x, wB);
+    if (NP == 3) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
+      fft_butterflies_reg<true>(x, wC);
+    }
+    fft_stage_bit0_dpp(x, odd);
+
+    // ---- exchange spectra between the two halves, external product ----
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dx[((size_t)r * 8 + e) * TP + q] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double2 other = dx[((size_t)(1 - r) * 8 + e) * TP + q];
+      const double2 D0 = r == 0 ? x[e] : other;
+      const double2 D1 = r == 0 ? other : x[e];
+      double re = D0.x * g0[e].x;
+      double im = D0.x * g0[e].y;
+      re = __builtin_fma(-D0.y, g0[e].y, re);
+      im = __builtin_fma(D0.y, g0[e].x, im);
+      re = __builtin_fma(D1.x, g1[e].x, re);
+      im = __builtin_fma(D1.x, g1[e].y, im);
+      re = __builtin_fma(-D1.y, g1[e].y, re);
+      im = __builtin_fma(D1.y, g1[e].x, im);
+      x[e] = make_double2(re, im);
+    }
+
+    // ---- inverse FFT ----
+    fft_stage_bit0_dpp(x, odd);
+    if (NP == 3) {
+      fft_butterflies_reg<false>(x, wC);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+    }
+    fft_butterflies_reg<false>(x, wB);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
+    fft_butterflies_reg<false>(x, wA);
+
+    // ---- untwist, round to the torus, accumulate (registers + LDS copy for the rotations) ----
+    // every rotated read of this iteration completed before the barriers above
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      const double2 v = cmul_conj(x[e], twr[e]);
+      own_lo[e] += torus_from_f64(v.x * scale);
+      own_hi[e] += torus_from_f64(v.y * scale);
+      acc[(size_t)r * N + p] = own_lo[e];
+      acc[(size_t)r * N + p + M] = own_hi[e];
+    }
+    __syncthreads();
+  }
+
+  // ---- sample extract ----
+  uint64_t *out = arena + (size_t)resolve(d, d.out_idx[node]) * ct_stride;
+  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
+  if (tid == 0) out[N] = acc[N];
+}
+
+// engine layout of the Fourier BSK for variant 2: [poly][e][q] with the point
+// p = fft_point<LOGM, LO_last3, 3>(q, e) of the last 3-bit pass (the layout the spectrum
+// is in when the external product runs).  grid = polynomials, block = M/8.
+template <int LOGN>
+__global__ void bsk_to_engine_layout_kernel(const double2 *__restrict__ canon, double2 *__restrict__ out) {
+  constexpr int M = (1 << LOGN) / 2, LOGM = LOGN - 1, TP = M / 8;
+  constexpr int NP = (LOGM - 1) / 3;
+  constexpr int LO_C = LOGM - 3 * NP;
+  const int q = threadIdx.x;
+  const double2 *src = canon + (size_t)blockIdx.x * M;
+  double2 *dst = out + (size_t)blockIdx.x * M;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dst[(size_t)e * TP + q] = src[fft_point<LOGM, LO_C, 3>(q, e)];
+}
+
 }  // namespace dev
 }  // namespace fhes

@@ -11,6 +11,7 @@
 using namespace fhes;
 
 struct DeviceImage {
+  int device = 0;
   unsigned char *buf = nullptr;  // all descriptor arrays
   int32_t *slot_map = nullptr;
   DevNodeArrays arrays{};
@@ -72,7 +73,7 @@ fhes_program *fhes_program_compile(const fhes_params *p, const char *op, const i
 void fhes_program_destroy(fhes_program *fp) {
   if (!fp) return;
   for (auto &kv : fp->images) {
-    (void)hipSetDevice(kv.first->device);
+    (void)hipSetDevice(kv.second.device);
     (void)hipFree(kv.second.buf);
     (void)hipFree(kv.second.slot_map);
   }
@@ -136,6 +137,7 @@ int fhes_program_run(fhes_ctx *ctx, const fhes_program *cfp, const int32_t *in_h
   auto it = fp->images.find(ctx);
   if (it == fp->images.end()) {
     DeviceImage img;
+    img.device = ctx->device;
     std::vector<int32_t> luts(fp->lut_ids.size());
     std::vector<int32_t> local2ctx(p.luts.size());
     for (size_t i = 0; i < p.luts.size(); i++) {
