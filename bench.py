@@ -4,9 +4,11 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete `find` (all of its bootstraps, 69 dependent levels) on inputs that are
-already resident in HBM.  With N > 1 (launched by torch.distributed.run, one process per GPU)
-every rank runs the same workload on its own encrypted string: independent strings shard with no
+One "step" = one pass of `find` over one batch of B independent (input, pattern) pairs that are
+already resident in HBM (default B = 56: every one of the 69 dependent levels then fills the 256
+CUs; `--batch 1` times a single find).  The single-find wall-clock is measured too (untimed region)
+and reported as `find_wall_ms_single`.  With N > 1 (launched by torch.distributed.run, one process
+per GPU) every rank runs the same workload on its own B strings: independent strings shard with no
 data-path collective, so scaling is "weak" and `value` is the PBS all ranks executed per second.
 
 The JSON line also carries
@@ -65,6 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="blind-rotate kernel variant (0 = auto)")
+    ap.add_argument("--batch", type=int, default=56, help="independent (input, pattern) pairs per step and rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,38 +89,105 @@ def main():
         build.build_oracle(verbose=False)
     if dist:
         dist.barrier()
-    from fhe_string_amd import api, _lib
+    from fhe_string_amd import _lib
+    from fhe_string_amd._lib import Params, Stats, check, check_ptr
+    import numpy as np
 
     lib = _lib.load()
-    params = api.default_params()
-    ck = api.ClientKey(params, 255, seed=0xF4E50000)
-    sk = api.ServerKey(ck, device=local_rank)
-    _lib.check(lib.fhes_set_kernel_variant(sk.ctx, args.variant))
-    text, pat = north_star_inputs(rank)
-    a = api.FheString.new(ck, text)
-    b = api.FheString.new(ck, pat)
+    params = Params()
+    check(lib.fhes_params_default(C.byref(params)))
+    ck = check_ptr(lib.fhes_client_key_generate(C.byref(params), 255, 0xF4E50000))
+    W = params.ct_words()
+    bsk = np.zeros(lib.fhes_bsk_words(C.byref(params)), dtype=np.uint64)
+    ksk = np.zeros(lib.fhes_ksk_words(C.byref(params)), dtype=np.uint64)
+    check(lib.fhes_client_key_make_server_keys(ck, bsk.ctypes.data, ksk.ctypes.data))
+    ctx = check_ptr(lib.fhes_ctx_create(C.byref(params), local_rank))   # no CPU fallback
+    check(lib.fhes_upload_keys(ctx, bsk.ctypes.data, ksk.ctypes.data))
+    del bsk, ksk
+    check(lib.fhes_set_kernel_variant(ctx, args.variant))
+
+    # ---- synthetic batch: B (text, pattern) pairs, encrypted client-side, uploaded once ----
+    B = max(args.batch, 1)
+    shape = np.array([65, 5], dtype=np.int32)
+    prog = check_ptr(lib.fhes_program_compile(C.byref(params), b"find", shape.ctypes.data, 2, 4))
+    info = (C.c_int64 * 8)()
+    check(lib.fhes_program_info(prog, info))
+    n_in, n_out, n_levels, pbs_per_find = int(info[0]), int(info[1]), int(info[3]), int(info[7])
+    pairs = [north_star_inputs(rank * 1000 + j) for j in range(B)]
+
+    def blocks(s):
+        out = np.zeros((len(s) + 1) * 4, dtype=np.uint8)
+        for i, ch in enumerate(s.encode("latin-1")):
+            for k in range(4):
+                out[i * 4 + k] = (ch >> (2 * k)) & 3
+        return out
+
+    msgs = np.concatenate([np.concatenate([blocks(t), blocks(p)]) for t, p in pairs])
+    cts = np.zeros((len(msgs), W), dtype=np.uint64)
+    check(lib.fhes_client_encrypt_blocks(ck, msgs.ctypes.data, len(msgs), cts.ctypes.data))
+    h_in = check(lib.fhes_arena_alloc(ctx, len(cts)))
+    check(lib.fhes_arena_upload(ctx, h_in, len(cts), cts.ctypes.data))
+    del cts
+    in_handles = np.arange(h_in, h_in + B * n_in, dtype=np.int32)
+    out_handles = np.zeros(B * n_out, dtype=np.int32)
+
+    def sync():
+        check(lib.fhes_sync(ctx))
 
     def barrier():
-        sk.sync()
+        sync()
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
-        sk.sync()
+        sync()
 
-    result = None
-    for _ in range(max(args.warmup, 0)):
-        result = a.find(sk, b)      # uploads inputs on first use, compiles and caches the program
-    barrier()
-    sk.reset_stats()
-    _lib.check(lib.fhes_set_timing(sk.ctx, 1))
+    def run_batch(n):
+        check(lib.fhes_program_run_batch(ctx, prog, n, in_handles.ctypes.data, out_handles.ctypes.data))
+
+    def free_outputs(n):
+        check(lib.fhes_arena_free(ctx, int(out_handles[0]), n * n_out))
+
+    def decode(n):
+        res = np.zeros((n * n_out, W), dtype=np.uint64)
+        check(lib.fhes_arena_download(ctx, int(out_handles[0]), n * n_out, res.ctypes.data))
+        vals = np.zeros(n * n_out, dtype=np.uint8)
+        check(lib.fhes_client_decrypt_blocks(ck, res.ctypes.data, n * n_out, vals.ctypes.data))
+        out = []
+        for i in range(n):
+            v = vals[i * n_out:(i + 1) * n_out]
+            out.append(sum(int(v[1 + k] & 3) << (2 * k) for k in range(4)) if v[0] & 1 else -1)
+        return out
+
+    # ---- untimed: warmup + single-find latency ----
+    run_batch(1)
+    sync()
+    free_outputs(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = a.find(sk, b)
+    run_batch(1)
+    sync()
+    single_ms = (time.perf_counter() - t0) * 1e3
+    single_ok = decode(1)[0] == pairs[0][0].find(pairs[0][1])
+    free_outputs(1)
+    for _ in range(max(args.warmup, 0)):
+        run_batch(B)
+        sync()
+        free_outputs(B)
+    barrier()
+    check(lib.fhes_reset_stats(ctx))
+    check(lib.fhes_set_timing(ctx, 1))
+    t0 = time.perf_counter()
+    for step in range(args.steps):
+        if step:
+            free_outputs(B)          # stream-ordered bookkeeping of the previous step's results
+        run_batch(B)
     barrier()
     dt = time.perf_counter() - t0
-    _lib.check(lib.fhes_set_timing(sk.ctx, 0))
-    st = sk.stats()
-    ok = result.decrypt(ck) == text.find(pat)
+    check(lib.fhes_set_timing(ctx, 0))
+    st = Stats()
+    check(lib.fhes_get_stats(ctx, C.byref(st)))
+    got = decode(B)
+    ok = single_ok and all(g == t.find(p) for g, (t, p) in zip(got, pairs))
+    text, pat = pairs[0]
 
     dt_max = dt
     if dist:
@@ -126,7 +196,6 @@ def main():
         dt_max = float(t.item())
 
     if rank == 0:
-        pbs_per_find = st.pbs_count // max(args.steps, 1)
         total_pbs = st.pbs_count * world_size
         launches = max(st.timed_launches, 1)
         br_ms = st.total_br_ms / launches
@@ -155,10 +224,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": "FheString::find, 64-char unpadded input, 4-char encrypted pattern, "
                                    "PARAM_MESSAGE_2_CARRY_2_KS_PBS, l=255 (BASELINE config 2)",
-                       "pbs_per_find": int(pbs_per_find), "levels": 69,
-                       "strings_per_rank": 1, "parallelism": f"{world_size} independent strings"},
+                       "pbs_per_find": int(pbs_per_find), "levels": int(n_levels),
+                       "strings_per_step_per_rank": B,
+                       "parallelism": f"{world_size} rank(s) x {B} independent strings per step"},
             "result_ok": bool(ok),
-            "find_wall_ms": round(dt_max / max(args.steps, 1) * 1e3, 3),
+            "find_wall_ms_single": round(single_ms, 3),
+            "pbs_per_s_single_find": round(pbs_per_find / (single_ms * 1e-3), 1),
             "roofline": {"bound": "hbm", "kernel": "blind_rotate", "achieved": round(br_achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(br_achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
@@ -175,7 +246,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(params, text, pat)
         print(json.dumps(line), flush=True)
 
-    sk.close()
+    lib.fhes_program_destroy(prog)
+    lib.fhes_ctx_destroy(ctx)
+    lib.fhes_client_key_destroy(ck)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

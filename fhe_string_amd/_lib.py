@@ -75,6 +75,7 @@ SIGNATURES = {
     "fhes_program_info": (C.c_int, [_P, _P]),
     "fhes_program_export": (C.c_int, [_P] + [_P] * 10),
     "fhes_program_run": (C.c_int, [_P, _P, _P, _P]),
+    "fhes_program_run_batch": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "fhes_server_key_create": (_P, [_P, C.c_int32]),
     "fhes_server_key_destroy": (None, [_P]),
     "fhes_server_key_ctx": (_P, [_P]),

@@ -15,6 +15,7 @@ struct fhes_ctx {
   fhes_params p;
   fhes::Dims dims;
   int device = 0;
+  int n_cus = 256;
   hipStream_t stream = nullptr;
   std::mutex mu;
 
@@ -62,6 +63,7 @@ struct DevNodeArrays {  // device pointers
   const int64_t *term_coef;
   const uint64_t *consts;
   const int32_t *lut_ids, *out_idx, *slot_map;
+  int32_t n_slots = 0;  // stride of slot_map per instance
 };
 
 int hip_fail(hipError_t e, const char *what);
@@ -71,9 +73,9 @@ int hip_fail(hipError_t e, const char *what);
     if (_e != hipSuccess) return fhes::hip_fail(_e, #call);   \
   } while (0)
 
-// launches keyswitch + blind rotate for nodes [first, first+count)
-int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count);
-int launch_linear(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count);
+// launches keyswitch + blind rotate for nodes [first, first+count) of n_inst instances
+int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst = 1);
+int launch_linear(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst = 1);
 int32_t arena_alloc_locked(fhes_ctx *ctx, int32_t count);
 int arena_free_locked(fhes_ctx *ctx, int32_t first, int32_t count);
 int32_t lut_register_locked(fhes_ctx *ctx, const uint64_t *table, int32_t n);

@@ -124,11 +124,11 @@ int32_t lut_register_locked(fhes_ctx *ctx, const uint64_t *table, int32_t n) {
 }
 
 // ---- launches ------------------------------------------------------------------------------
-static dev::NodeDesc make_desc(const DevNodeArrays &a, int32_t first, int32_t count) {
+static dev::NodeDesc make_desc(const DevNodeArrays &a, int32_t first, int32_t count, int32_t v0, int32_t v_count) {
   dev::NodeDesc d;
   d.term_ptr = a.term_ptr; d.term_idx = a.term_idx; d.term_coef = a.term_coef;
   d.consts = a.consts; d.lut_ids = a.lut_ids; d.out_idx = a.out_idx; d.slot_map = a.slot_map;
-  d.first = first; d.count = count;
+  d.first = first; d.count = count; d.n_slots = a.n_slots; d.v0 = v0; d.v_count = v_count;
   return d;
 }
 
@@ -145,8 +145,8 @@ static int ensure_ks_out(fhes_ctx *ctx, int64_t nodes) {
 
 static int launch_keyswitch(fhes_ctx *ctx, const dev::NodeDesc &d) {
   const Dims &dm = ctx->dims;
-  FHES_HIP(hipMemsetAsync(ctx->ks_out, 0, (size_t)d.count * ctx->ks_stride * sizeof(uint64_t), ctx->stream));
-  const int tiles = (d.count + dev::KS_TB - 1) / dev::KS_TB;
+  FHES_HIP(hipMemsetAsync(ctx->ks_out, 0, (size_t)d.v_count * ctx->ks_stride * sizeof(uint64_t), ctx->stream));
+  const int tiles = (d.v_count + dev::KS_TB - 1) / dev::KS_TB;
   const int max_splits = dm.big / dev::KS_IC;
   int splits = 1;
   while (splits < max_splits && tiles * splits < 1024) splits *= 2;
@@ -180,7 +180,7 @@ static int launch_br_v1(fhes_ctx *ctx, const dev::NodeDesc &d) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(d.count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_f,
                      ctx->lut_polys, ctx->twist, ctx->tw);
   FHES_HIP(hipGetLastError());
@@ -198,17 +198,39 @@ static int launch_br_v2(fhes_ctx *ctx, const dev::NodeDesc &d) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(d.count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
                      ctx->lut_polys, ctx->twist, ctx->tw);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
 
+template <int LOGN>
+static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  constexpr int N = 1 << LOGN, M = N / 2;
+  const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
+  auto kern = dev::blind_rotate_v3_kernel<LOGN, 23>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
+                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
+                     ctx->lut_polys, ctx->twist, ctx->tw);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
+// variant: 0 = auto (latency kernel for launches that fit one workgroup per CU, throughput
+// kernel otherwise), 1 / 2 / 3 = force
 static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
-  const int variant = ctx->br_variant == 0 ? 2 : ctx->br_variant;
-  if (ctx->dims.N == 2048) return variant == 1 ? launch_br_v1<11>(ctx, d) : launch_br_v2<11>(ctx, d);
-  return variant == 1 ? launch_br_v1<8>(ctx, d) : launch_br_v2<8>(ctx, d);
+  int variant = ctx->br_variant;
+  if (variant == 0) variant = d.v_count <= ctx->n_cus + ctx->n_cus / 4 ? 2 : 3;
+  if (ctx->dims.N == 2048)
+    return variant == 1 ? launch_br_v1<11>(ctx, d) : variant == 2 ? launch_br_v2<11>(ctx, d) : launch_br_v3<11>(ctx, d);
+  return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 2 ? launch_br_v2<8>(ctx, d) : launch_br_v3<8>(ctx, d);
 }
 
 static int take_event(fhes_ctx *ctx, hipEvent_t *e) {
@@ -237,14 +259,17 @@ int collect_timing_locked(fhes_ctx *ctx) {
   return FHES_OK;
 }
 
-int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count) {
+int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst) {
   if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
+  if (count <= 0 || n_inst <= 0) return FHES_OK;
+  const int64_t total = (int64_t)count * n_inst;
+  if (total > INT32_MAX) return fail(FHES_ERR_INVALID, "batch too large");
   const int32_t kMaxChunk = 16384;
-  for (int32_t off = 0; off < count; off += kMaxChunk) {
-    const int32_t c = std::min(kMaxChunk, count - off);
+  for (int32_t off = 0; off < (int32_t)total; off += kMaxChunk) {
+    const int32_t c = std::min<int32_t>(kMaxChunk, (int32_t)total - off);
     int rc = ensure_ks_out(ctx, c);
     if (rc) return rc;
-    dev::NodeDesc d = make_desc(a, first + off, c);
+    dev::NodeDesc d = make_desc(a, first, count, off, c);
     fhes_ctx::Timed t{};
     if (ctx->timing) {
       if ((rc = take_event(ctx, &t.e0)) || (rc = take_event(ctx, &t.e1)) || (rc = take_event(ctx, &t.e2))) return rc;
@@ -265,13 +290,13 @@ int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t cou
   return FHES_OK;
 }
 
-int launch_linear(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count) {
-  if (count <= 0) return FHES_OK;
-  dev::NodeDesc d = make_desc(a, first, count);
-  hipLaunchKernelGGL(dev::linear_kernel, dim3(count), dim3(256), 0, ctx->stream, d, ctx->arena,
+int launch_linear(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst) {
+  if (count <= 0 || n_inst <= 0) return FHES_OK;
+  dev::NodeDesc d = make_desc(a, first, count, 0, count * n_inst);
+  hipLaunchKernelGGL(dev::linear_kernel, dim3(count * n_inst), dim3(256), 0, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->dims.big);
   FHES_HIP(hipGetLastError());
-  ctx->stats.linear_count += (uint64_t)count;
+  ctx->stats.linear_count += (uint64_t)count * n_inst;
   return FHES_OK;
 }
 
@@ -319,6 +344,7 @@ static int stage_desc(fhes_ctx *ctx, int32_t count, const int32_t *term_ptr, con
   a->term_coef = (const int64_t *)(b + o_tc); a->consts = (const uint64_t *)(b + o_c);
   a->lut_ids = (const int32_t *)(b + o_l); a->out_idx = (const int32_t *)(b + o_o);
   a->slot_map = nullptr;
+  a->n_slots = 0;
   return FHES_OK;
 }
 
@@ -351,6 +377,11 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
 
+  {
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+    ctx->n_cus = prop.multiProcessorCount;
+  }
   ctx->ct_stride = d.big + 16;
   const char *env = getenv("FHES_ARENA_SLOTS");
   ctx->capacity = env ? atoll(env) : (int64_t)1 << 18;
@@ -539,7 +570,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  if (v < 0 || v > 2) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
+  if (v < 0 || v > 3) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
   ctx->br_variant = v;
   return FHES_OK;
 }
@@ -576,7 +607,7 @@ int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles
   if (rc) return rc;
   rc = ensure_ks_out(ctx, count);
   if (rc) return rc;
-  dev::NodeDesc d = make_desc(a, 0, count);
+  dev::NodeDesc d = make_desc(a, 0, count, 0, count);
   rc = launch_keyswitch(ctx, d);
   if (rc) return rc;
   std::vector<uint64_t> h((size_t)count * ctx->ks_stride);

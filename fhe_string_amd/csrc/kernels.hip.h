@@ -43,6 +43,22 @@ __device__ __forceinline__ uint64_t torus_from_f64(double y) {
   const unsigned lo = (unsigned)l;
   return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)lo;
 }
+// Same value (rint(y) mod 2^64, exact for |y| < 2^115) with 7 f64 adds and 2 integer ops:
+// magic-constant splitting.  y + 1.5*2^116 rounds y to a multiple of 2^64; z = y - that is in
+// [-2^63, 2^63]; z + 1.5*2^84 leaves rint(z/2^32) mod 2^32 in the low mantissa dword;
+// rem + 1.5*2^52 leaves rint(rem) as a 52-bit two's complement value offset by 2^51.
+__device__ __forceinline__ uint64_t torus_from_f64_fast(double y) {
+  const double C0 = 0x1.8p116, C1 = 0x1.8p84, C2 = 0x1.8p52;
+  const double h0 = (y + C0) - C0;
+  const double z = y - h0;
+  const double t1 = z + C1;
+  const double rem = z - (t1 - C1);
+  const double t2 = rem + C2;
+  const uint32_t hi32 = (uint32_t)__double2loint(t1);
+  const uint32_t lo = (uint32_t)__double2loint(t2);
+  const uint32_t mhi = ((uint32_t)__double2hiint(t2) & 0xFFFFFu) - 0x80000u;  // 0 or 0xFFFFFFFF
+  return ((uint64_t)(hi32 + mhi) << 32) | (uint64_t)lo;
+}
 // correctly rounded int64 -> f64 (single rounding)
 __device__ __forceinline__ double i64_to_f64(uint64_t v) {
   const int hi = (int)(v >> 32);
@@ -187,13 +203,20 @@ struct NodeDesc {
   const uint64_t *consts;    // raw torus word added to the body
   const int32_t *lut_ids;
   const int32_t *out_idx;    // slot / handle
-  const int32_t *slot_map;   // optional slot -> arena handle
-  int32_t first;             // first node of this launch
-  int32_t count;             // nodes in this launch
+  const int32_t *slot_map;   // optional [n_inst][n_slots]: slot -> arena handle
+  int32_t first;             // first node (of the program) of this level
+  int32_t count;             // nodes of this level, per instance
+  int32_t n_slots;           // slots per instance (stride of slot_map)
+  int32_t v0;                // first virtual index of this launch
+  int32_t v_count;           // virtual nodes in this launch
 };
+// A launch covers virtual indices v in [v0, v0 + v_count) of the space
+// (instance, node-in-level):  instance = v / count, node = first + v % count.
+// Batched execution of one program on many independent inputs is the same launch with
+// n_inst * count virtual nodes.
 
-__device__ __forceinline__ int32_t resolve(const NodeDesc &d, int32_t s) {
-  return d.slot_map ? d.slot_map[s] : s;
+__device__ __forceinline__ int32_t resolve(const NodeDesc &d, int32_t inst, int32_t s) {
+  return d.slot_map ? d.slot_map[(size_t)inst * d.n_slots + s] : s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -219,8 +242,8 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
   const int tile = blockIdx.x;
   const int i_begin = blockIdx.y * coeffs_per_split;
   const int i_end = i_begin + coeffs_per_split;
-  const int node0 = d.first + tile * KS_TB;
-  const int nodes_here = min(KS_TB, d.first + d.count - node0);
+  const int vbase = tile * KS_TB;  // virtual index (relative to v0) of this block's first ciphertext
+  const int nodes_here = min(KS_TB, d.v_count - vbase);
   const int total = ks_level * ks_base_log;
   const int B = 1 << ks_base_log;
 
@@ -236,9 +259,10 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
       const int b = idx / KS_IC, ii = idx % KS_IC;
       uint64_t x = 0;
       if (b < nodes_here) {
-        const int node = node0 + b;
+        const int v = d.v0 + vbase + b;
+        const int inst = v / d.count, node = d.first + v % d.count;
         for (int t = d.term_ptr[node]; t < d.term_ptr[node + 1]; ++t) {
-          const uint64_t *src = arena + (size_t)resolve(d, d.term_idx[t]) * ct_stride;
+          const uint64_t *src = arena + (size_t)resolve(d, inst, d.term_idx[t]) * ct_stride;
           x += (uint64_t)d.term_coef[t] * src[chunk + ii];
         }
       }
@@ -272,8 +296,9 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
 #pragma unroll
   for (int b = 0; b < KS_TB; ++b) {
     if (b >= nodes_here) break;
-    const int node = node0 + b;
-    uint64_t *dst = ks_out + (size_t)(node - d.first) * ks_stride;
+    const int v = d.v0 + vbase + b;
+    const int inst = v / d.count, node = d.first + v % d.count;
+    uint64_t *dst = ks_out + (size_t)(vbase + b) * ks_stride;
 #pragma unroll
     for (int q = 0; q < JPT; ++q) {
       const int j = tid + 256 * q;
@@ -281,7 +306,7 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
       if (j == n_small && blockIdx.y == 0) {  // body of the input combination
         uint64_t body = d.consts[node];
         for (int t = d.term_ptr[node]; t < d.term_ptr[node + 1]; ++t) {
-          const uint64_t *src = arena + (size_t)resolve(d, d.term_idx[t]) * ct_stride;
+          const uint64_t *src = arena + (size_t)resolve(d, inst, d.term_idx[t]) * ct_stride;
           body += (uint64_t)d.term_coef[t] * src[big];
         }
         v += body;
@@ -296,13 +321,14 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void linear_kernel(NodeDesc d, uint64_t *__restrict__ arena,
                                                      int ct_stride, int big) {
-  const int node = d.first + blockIdx.x;
-  uint64_t *dst = arena + (size_t)resolve(d, d.out_idx[node]) * ct_stride;
+  const int v = d.v0 + blockIdx.x;
+  const int inst = v / d.count, node = d.first + v % d.count;
+  uint64_t *dst = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
   const int t0 = d.term_ptr[node], t1 = d.term_ptr[node + 1];
   for (int j = threadIdx.x; j <= big; j += blockDim.x) {
     uint64_t x = (j == big) ? d.consts[node] : 0;
     for (int t = t0; t < t1; ++t)
-      x += (uint64_t)d.term_coef[t] * arena[(size_t)resolve(d, d.term_idx[t]) * ct_stride + j];
+      x += (uint64_t)d.term_coef[t] * arena[(size_t)resolve(d, inst, d.term_idx[t]) * ct_stride + j];
     dst[j] = x;
   }
 }
@@ -328,7 +354,8 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
   const int tid = threadIdx.x;
   const int r = tid / TP;  // polynomial handled by this half of the workgroup
   const int q = tid % TP;
-  const int node = d.first + blockIdx.x;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
 
   // ---- modulus switch to Z_{2N} ----
   const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
@@ -405,7 +432,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
   }
 
   // ---- sample extract (constant coefficient) ----
-  uint64_t *out = arena + (size_t)resolve(d, d.out_idx[node]) * ct_stride;
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
   for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
   if (tid == 0) out[N] = acc[N];
 }
@@ -433,14 +460,28 @@ __device__ __forceinline__ double dpp_swap1(double v) {  // value of lane ^ 1
 }
 
 // radix-2 stage on index bit 0 across lane pairs (twiddle index 0: exactly 1), DIF == DIT
-__device__ __forceinline__ void fft_stage_bit0_dpp(double2 (&x)[8], int odd) {
+// sgn = +1.0 on even lanes, -1.0 on odd lanes: fma(own, sgn, partner) is own + partner (u + v)
+// resp. partner - own (u - v), correctly rounded like the add / sub it replaces.
+__device__ __forceinline__ void fft_stage_bit0_dpp(double2 (&x)[8], double sgn) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const double px = dpp_swap1(x[e].x), py = dpp_swap1(x[e].y);
-    // even lane: u + v (own + partner); odd lane: u - v (partner - own)
-    x[e].x = odd ? (px - x[e].x) : (x[e].x + px);
-    x[e].y = odd ? (py - x[e].y) : (x[e].y + py);
+    x[e].x = __builtin_fma(x[e].x, sgn, px);
+    x[e].y = __builtin_fma(x[e].y, sgn, py);
   }
+}
+
+// one point of the external product: D0*g0 + D1*g1 in the canonical FMA order
+__device__ __forceinline__ double2 ext_mac(double2 D0, double2 D1, double2 g0, double2 g1) {
+  double re = D0.x * g0.x;
+  double im = D0.x * g0.y;
+  re = __builtin_fma(-D0.y, g0.y, re);
+  im = __builtin_fma(D0.y, g0.x, im);
+  re = __builtin_fma(D1.x, g1.x, re);
+  im = __builtin_fma(D1.x, g1.y, im);
+  re = __builtin_fma(-D1.y, g1.y, re);
+  im = __builtin_fma(D1.y, g1.x, im);
+  return make_double2(re, im);
 }
 
 // butterflies of a 3-bit pass with the 7 twiddles held in registers:
@@ -501,8 +542,9 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
   const int tid = threadIdx.x;
   const int r = tid / TP;
   const int q = tid % TP;
-  const int odd = q & 1;
-  const int node = d.first + blockIdx.x;
+  const double sgn = (q & 1) ? -1.0 : 1.0;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
 
   const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
   for (int j = tid; j <= n_small; j += blockDim.x)
@@ -515,8 +557,12 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
   load_pass_twiddles<LOGM, LO_A>(wA, q, tw);
   load_pass_twiddles<LOGM, LO_B>(wB, q, tw);
   if (NP == 3) load_pass_twiddles<LOGM, LO_C>(wC, q, tw);
+  double2 twi[8];  // conj-untwist factors pre-scaled by 1/M (power of two: exact, same bits)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) twr[e] = twist[fft_point<LOGM, LO_A, 3>(q, e)];
+  for (int e = 0; e < 8; ++e) {
+    twr[e] = twist[fft_point<LOGM, LO_A, 3>(q, e)];
+    twi[e] = make_double2(twr[e].x * (1.0 / (double)M), twr[e].y * (1.0 / (double)M));
+  }
 
   // ---- acc = (0, X^{-b~} * LUT); own coefficients also kept in registers ----
   uint64_t own_lo[8], own_hi[8];  // coefficients p and p + M of polynomial r
@@ -541,7 +587,6 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
 
   const uint64_t *acc_r = acc + (size_t)r * N;
   double2 *buf_r = fbuf + (size_t)r * M;
-  const double scale = 1.0 / (double)M;
 
   for (int i = 0; i < n_small; ++i) {
     const int a = (int)at[i];
@@ -584,30 +629,22 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
       for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
       fft_butterflies_reg<true>(x, wC);
     }
-    fft_stage_bit0_dpp(x, odd);
+    fft_stage_bit0_dpp(x, sgn);
 
     // ---- exchange spectra between the two halves, external product ----
 #pragma unroll
     for (int e = 0; e < 8; ++e) dx[((size_t)r * 8 + e) * TP + q] = x[e];
     __syncthreads();
+    if (r == 0) {  // wave-uniform: D0 = own spectrum, D1 = the other half's
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const double2 other = dx[((size_t)(1 - r) * 8 + e) * TP + q];
-      const double2 D0 = r == 0 ? x[e] : other;
-      const double2 D1 = r == 0 ? other : x[e];
-      double re = D0.x * g0[e].x;
-      double im = D0.x * g0[e].y;
-      re = __builtin_fma(-D0.y, g0[e].y, re);
-      im = __builtin_fma(D0.y, g0[e].x, im);
-      re = __builtin_fma(D1.x, g1[e].x, re);
-      im = __builtin_fma(D1.x, g1[e].y, im);
-      re = __builtin_fma(-D1.y, g1[e].y, re);
-      im = __builtin_fma(D1.y, g1[e].x, im);
-      x[e] = make_double2(re, im);
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], dx[((size_t)1 * 8 + e) * TP + q], g0[e], g1[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(dx[((size_t)0 * 8 + e) * TP + q], x[e], g0[e], g1[e]);
     }
 
     // ---- inverse FFT ----
-    fft_stage_bit0_dpp(x, odd);
+    fft_stage_bit0_dpp(x, sgn);
     if (NP == 3) {
       fft_butterflies_reg<false>(x, wC);
 #pragma unroll
@@ -629,9 +666,9 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      const double2 v = cmul_conj(x[e], twr[e]);
-      own_lo[e] += torus_from_f64(v.x * scale);
-      own_hi[e] += torus_from_f64(v.y * scale);
+      const double2 v = cmul_conj(x[e], twi[e]);
+      own_lo[e] += torus_from_f64_fast(v.x);
+      own_hi[e] += torus_from_f64_fast(v.y);
       acc[(size_t)r * N + p] = own_lo[e];
       acc[(size_t)r * N + p + M] = own_hi[e];
     }
@@ -639,7 +676,174 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
   }
 
   // ---- sample extract ----
-  uint64_t *out = arena + (size_t)resolve(d, d.out_idx[node]) * ct_stride;
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
+  if (tid == 0) out[N] = acc[N];
+}
+
+// ------------------------------------------------------------------------------------------
+// K2+K3 (variant 3): throughput-oriented sibling of variant 2 -- same arithmetic, same bits.
+// Two independent workgroups per CU (<= 256 registers, <= 80 KB LDS each) so that one
+// workgroup's barriers / LDS round trips are covered by the other's f64 work:
+//   * the thread's own accumulator coefficients are re-read from LDS (frees 32 registers);
+//   * the two halves exchange spectra through the FFT buffer (two extra barriers);
+//   * the 1/M scale is folded into the rounding FMAs (exact: power of two).
+// (A first version kept the twiddle table in LDS: strided ds_read_b128 gave 1.1 G bank-conflict
+//  cycles per launch and the LDS pipe was 55 % busy -- twiddles stay in registers.)
+// LDS: acc u64[2][N] | fbuf double2[2][M] | a_tilde u16
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t torus_from_f64_scaled(double v, double s) {
+  // rint(v * s) mod 2^64 with s a power of two; same value as torus_from_f64_fast(v * s)
+  const double C0 = 0x1.8p116, C1 = 0x1.8p84, C2 = 0x1.8p52;
+  const double h0 = __builtin_fma(v, s, C0) - C0;
+  const double z = __builtin_fma(v, s, -h0);
+  const double t1 = z + C1;
+  const double rem = z - (t1 - C1);
+  const double t2 = rem + C2;
+  const uint32_t hi32 = (uint32_t)__double2loint(t1);
+  const uint32_t lo = (uint32_t)__double2loint(t2);
+  const uint32_t mhi = ((uint32_t)__double2hiint(t2) & 0xFFFFFu) - 0x80000u;
+  return ((uint64_t)(hi32 + mhi) << 32) | (uint64_t)lo;
+}
+
+template <int LOGN, int BL>
+__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v3_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
+    int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
+    const double2 *__restrict__ twist, const double2 *__restrict__ tw) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
+  constexpr int NP = (LOGM - 1) / 3;
+  static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N]
+  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][M]
+  uint16_t *at = reinterpret_cast<uint16_t *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16);
+
+  const int tid = threadIdx.x;
+  const int r = tid / TP;
+  const int q = tid % TP;
+  const double sgn = (q & 1) ? -1.0 : 1.0;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  for (int j = tid; j <= n_small; j += blockDim.x)
+    at[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  __syncthreads();
+
+  constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
+  double2 wA[7], wB[7], wC[7];
+  load_pass_twiddles<LOGM, LO_A>(wA, q, tw);
+  load_pass_twiddles<LOGM, LO_B>(wB, q, tw);
+  if (NP == 3) load_pass_twiddles<LOGM, LO_C>(wC, q, tw);
+  const double2 *twist_q = twist + q;  // twist[fft_point<LOGM, LO_A, 3>(q, e)] = twist_q[e * TP]
+
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      acc[(size_t)r * N + p] = v0;
+      acc[(size_t)r * N + p + M] = v1;
+    }
+  }
+  __syncthreads();
+
+  uint64_t *acc_r = acc + (size_t)r * N;
+  double2 *buf_r = fbuf + (size_t)r * M;
+  const double2 *buf_o = fbuf + (size_t)(1 - r) * M;
+  const double scale = 1.0 / (double)M;
+
+  for (int i = 0; i < n_small; ++i) {
+    const int a = (int)at[i];
+    if (a == 0) continue;
+
+    // GGSW column r of this iteration, consumed after the forward FFT
+    double2 g0[8], g1[8];
+    {
+      const double2 *G = bsk_e + (size_t)i * 4 * M;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        g0[e] = G[((size_t)(0 * 2 + r) * 8 + e) * TP + q];
+        g1[e] = G[((size_t)(1 * 2 + r) * 8 + e) * TP + q];
+      }
+    }
+    double2 x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      const uint64_t d0 = rot_read<N>(acc_r, a, p) - acc_r[p];
+      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - acc_r[p + M];
+      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twist_q[e * TP]);
+    }
+
+    // ---- forward FFT ----
+    fft_butterflies_reg<true>(x, wA);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+    fft_butterflies_reg<true>(x, wB);
+    if (NP == 3) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
+    }
+    if (NP == 3) fft_butterflies_reg<true>(x, wC);
+    fft_stage_bit0_dpp(x, sgn);
+
+    // ---- exchange spectra through fbuf ([e][q] order), external product ----
+    __syncthreads();  // every thread of this half has taken its pass inputs out of buf_r
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf_r[(size_t)e * TP + q] = x[e];
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], buf_o[(size_t)e * TP + q], g0[e], g1[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(buf_o[(size_t)e * TP + q], x[e], g0[e], g1[e]);
+    }
+    __syncthreads();  // the other half has read my spectrum: buf_r may be overwritten
+
+    // ---- inverse FFT ----
+    fft_stage_bit0_dpp(x, sgn);
+    if (NP == 3) {
+      fft_butterflies_reg<false>(x, wC);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+    }
+    fft_butterflies_reg<false>(x, wB);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
+    fft_butterflies_reg<false>(x, wA);
+
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      const double2 v = cmul_conj(x[e], twist_q[e * TP]);
+      acc_r[p] += torus_from_f64_scaled(v.x, scale);
+      acc_r[p + M] += torus_from_f64_scaled(v.y, scale);
+    }
+    __syncthreads();
+  }
+
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
   for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
   if (tid == 0) out[N] = acc[N];
 }

@@ -14,6 +14,7 @@ struct DeviceImage {
   int device = 0;
   unsigned char *buf = nullptr;  // all descriptor arrays
   int32_t *slot_map = nullptr;
+  size_t slot_map_cap = 0;
   DevNodeArrays arrays{};
 };
 
@@ -117,11 +118,11 @@ int fhes_program_export(const fhes_program *fp, int32_t *level_ptr, int32_t *ter
   return FHES_OK;
 }
 
-int fhes_program_run(fhes_ctx *ctx, const fhes_program *cfp, const int32_t *in_handles,
-                     int32_t *out_handles) {
+int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_inst,
+                           const int32_t *in_handles, int32_t *out_handles) {
   auto *fp = const_cast<fhes_program *>(cfp);
-  if (!ctx || !fp || !out_handles || (fp->prog.n_inputs > 0 && !in_handles))
-    return fail(FHES_ERR_INVALID, "program_run: null argument");
+  if (!ctx || !fp || !out_handles || n_inst < 1 || (fp->prog.n_inputs > 0 && !in_handles))
+    return fail(FHES_ERR_INVALID, "program_run: bad argument");
   if (memcmp(&ctx->p, &fp->prog.params, sizeof(fhes_params)) != 0)
     return fail(FHES_ERR_INVALID, "program_run: program was compiled for different parameters");
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -130,7 +131,9 @@ int fhes_program_run(fhes_ctx *ctx, const fhes_program *cfp, const int32_t *in_h
   if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
   const circ::Program &p = fp->prog;
   const int32_t n_in = p.n_inputs, n_nodes = (int32_t)p.nodes.size(), n_out = (int32_t)p.out_slots.size();
-  for (int32_t i = 0; i < n_in; i++)
+  const int32_t n_slots = std::max(fp->n_slots, 1);
+  if ((int64_t)n_inst * std::max(n_nodes, 1) > INT32_MAX / 2) return fail(FHES_ERR_INVALID, "program_run: batch too large");
+  for (int64_t i = 0; i < (int64_t)n_in * n_inst; i++)
     if (in_handles[i] < 0 || in_handles[i] >= ctx->capacity) return fail(FHES_ERR_INVALID, "program_run: bad input handle");
 
   // ---- device image (once per ctx) ----
@@ -165,42 +168,56 @@ int fhes_program_run(fhes_ctx *ctx, const fhes_program *cfp, const int32_t *in_h
     }
     FHES_HIP(hipMalloc(&img.buf, total));
     FHES_HIP(hipMemcpy(img.buf, h.data(), total, hipMemcpyHostToDevice));
-    FHES_HIP(hipMalloc(&img.slot_map, 4 * (size_t)std::max(fp->n_slots, 1)));
     img.arrays.term_ptr = (const int32_t *)(img.buf + o_tp);
     img.arrays.term_idx = (const int32_t *)(img.buf + o_ti);
     img.arrays.term_coef = (const int64_t *)(img.buf + o_tc);
     img.arrays.consts = (const uint64_t *)(img.buf + o_c);
     img.arrays.lut_ids = (const int32_t *)(img.buf + o_l);
     img.arrays.out_idx = (const int32_t *)(img.buf + o_o);
-    img.arrays.slot_map = img.slot_map;
+    img.arrays.n_slots = n_slots;
     it = fp->images.emplace(ctx, img).first;
   }
   DeviceImage &img = it->second;
+  if (img.slot_map_cap < (size_t)n_inst * n_slots) {
+    FHES_HIP(hipStreamSynchronize(ctx->stream));
+    if (img.slot_map) FHES_HIP(hipFree(img.slot_map));
+    img.slot_map = nullptr;
+    img.slot_map_cap = 0;
+    FHES_HIP(hipMalloc(&img.slot_map, 4 * (size_t)n_inst * n_slots));
+    img.slot_map_cap = (size_t)n_inst * n_slots;
+  }
+  img.arrays.slot_map = img.slot_map;
 
-  // ---- slot map for this run ----
-  const int32_t out_base = arena_alloc_locked(ctx, std::max(n_out, 1));
+  // ---- slot maps for this run ----
+  const int32_t out_total = std::max(n_out * n_inst, 1);
+  const int32_t out_base = arena_alloc_locked(ctx, out_total);
   if (out_base < 0) return out_base;
   int32_t scratch = -1;
   if (n_nodes > 0) {
-    scratch = arena_alloc_locked(ctx, n_nodes);
+    scratch = arena_alloc_locked(ctx, n_nodes * n_inst);
     if (scratch < 0) {
-      arena_free_locked(ctx, out_base, std::max(n_out, 1));
+      arena_free_locked(ctx, out_base, out_total);
       return scratch;
     }
   }
-  std::vector<int32_t> map(std::max(fp->n_slots, 1));
-  for (int32_t i = 0; i < n_in; i++) map[i] = in_handles[i];
-  for (int32_t j = 0; j < n_nodes; j++) map[n_in + j] = scratch + j;
-  std::vector<std::pair<int32_t, int32_t>> copies;  // (dst handle, src slot)
-  std::vector<char> taken(fp->n_slots, 0);
-  for (int32_t k = 0; k < n_out; k++) {
-    const int32_t s = p.out_slots[k];
-    out_handles[k] = out_base + k;
-    if (s >= n_in && !taken[s]) {
-      map[s] = out_base + k;  // the node writes its result straight into the output handle
-      taken[s] = 1;
-    } else {
-      copies.push_back({out_base + k, s});
+  std::vector<int32_t> map((size_t)n_inst * n_slots);
+  std::vector<std::pair<int32_t, int32_t>> copies;  // (dst handle, src handle index into map)
+  std::vector<char> taken(n_slots);
+  for (int32_t inst = 0; inst < n_inst; inst++) {
+    int32_t *m = &map[(size_t)inst * n_slots];
+    for (int32_t i = 0; i < n_in; i++) m[i] = in_handles[(size_t)inst * n_in + i];
+    for (int32_t j = 0; j < n_nodes; j++) m[n_in + j] = scratch + inst * n_nodes + j;
+    std::fill(taken.begin(), taken.end(), 0);
+    for (int32_t k = 0; k < n_out; k++) {
+      const int32_t s = p.out_slots[k];
+      const int32_t h = out_base + inst * n_out + k;
+      out_handles[(size_t)inst * n_out + k] = h;
+      if (s >= n_in && !taken[s]) {
+        m[s] = h;  // the node writes its result straight into the output handle
+        taken[s] = 1;
+      } else {
+        copies.push_back({h, inst * n_slots + s});
+      }
     }
   }
   FHES_HIP(hipMemcpyAsync(img.slot_map, map.data(), 4 * map.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -209,10 +226,10 @@ int fhes_program_run(fhes_ctx *ctx, const fhes_program *cfp, const int32_t *in_h
   // ---- execute level by level ----
   int rc = FHES_OK;
   for (int lv = 0; lv < fp->n_pbs_levels && rc == FHES_OK; lv++)
-    rc = launch_pbs(ctx, img.arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv]);
+    rc = launch_pbs(ctx, img.arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv], n_inst);
   if (rc == FHES_OK && fp->has_linear_level) {
     const int lv = fp->n_pbs_levels;
-    rc = launch_linear(ctx, img.arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv]);
+    rc = launch_linear(ctx, img.arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv], n_inst);
   }
   if (rc == FHES_OK) {
     const size_t bytes = (size_t)ctx->dims.ct_words() * 8;
@@ -224,9 +241,13 @@ int fhes_program_run(fhes_ctx *ctx, const fhes_program *cfp, const int32_t *in_h
     }
   }
   // scratch is released in stream order: later work on this ctx is queued behind the reads
-  if (scratch >= 0) arena_free_locked(ctx, scratch, n_nodes);
-  if (rc != FHES_OK) arena_free_locked(ctx, out_base, std::max(n_out, 1));
+  if (scratch >= 0) arena_free_locked(ctx, scratch, n_nodes * n_inst);
+  if (rc != FHES_OK) arena_free_locked(ctx, out_base, out_total);
   return rc;
+}
+
+int fhes_program_run(fhes_ctx *ctx, const fhes_program *fp, const int32_t *in_handles, int32_t *out_handles) {
+  return fhes_program_run_batch(ctx, fp, 1, in_handles, out_handles);
 }
 
 }  // extern "C"

@@ -174,6 +174,11 @@ int fhes_program_export(const fhes_program *prog, int32_t *level_ptr, int32_t *t
  * allocated arena handles (n_outputs). */
 int fhes_program_run(fhes_ctx *ctx, const fhes_program *prog, const int32_t *in_handles,
                      int32_t *out_handles);
+/* The same program on n_inst independent inputs in one pass: every level is one launch pair
+ * over n_inst * (nodes of the level) bootstraps.  in_handles [n_inst][n_inputs],
+ * out_handles [n_inst][n_outputs] (one contiguous handle range, instance-major). */
+int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *prog, int32_t n_inst,
+                           const int32_t *in_handles, int32_t *out_handles);
 
 /* ============================ Level 2: reference API mirror ============================= */
 typedef struct fhes_server_key fhes_server_key; /* ServerKey (server_key.rs:11-17) */

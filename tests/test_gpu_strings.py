@@ -102,3 +102,39 @@ def test_split_with_padding_on_gpu(keys):
     sep = api.FheString.new(ck, ",")
     assert a.split(sk, sep).decrypt(ck) == s.split(",")
     assert a.rsplit(sk, sep).decrypt(ck) == list(reversed(s.rsplit(",")))
+
+
+def test_batched_program_equals_single_runs(libs):
+    """fhes_program_run_batch: n independent finds in one pass give, per instance, exactly the
+    ciphertexts of a single run (and the std::str answers)."""
+    w = world("default")
+    bu = num_blocks_usize(255)
+    rng = np.random.default_rng(11)
+    texts, pats = [], []
+    for k in range(5):
+        s = "".join(chr(c) for c in rng.integers(0x61, 0x67, size=12))
+        texts.append(s)
+        pats.append(s[k + 3:k + 5] if k % 2 == 0 else "zz")
+    p = Prog(w.p, "find", [13, 3], bu)
+    ctx = w.ctx()
+    n_inst = len(texts)
+    cts = w.encrypt(np.concatenate([np.concatenate([string_blocks(t), string_blocks(q)]) for t, q in zip(texts, pats)]))
+    h = check(w.lib.fhes_arena_alloc(ctx, len(cts)))
+    check(w.lib.fhes_arena_upload(ctx, h, len(cts), ptr(cts)))
+    in_handles = np.arange(h, h + len(cts), dtype=np.int32)
+    out_handles = np.zeros(n_inst * p.n_outputs, dtype=np.int32)
+    check(w.lib.fhes_program_run_batch(ctx, p.h, n_inst, ptr(in_handles), ptr(out_handles)))
+    batch = np.zeros((n_inst * p.n_outputs, w.W), dtype=np.uint64)
+    check(w.lib.fhes_arena_download(ctx, int(out_handles[0]), len(batch), ptr(batch)))
+    for i in range(n_inst):
+        got = decode_result("find", w.decrypt(batch[i * p.n_outputs:(i + 1) * p.n_outputs]), bu)
+        exp = texts[i].find(pats[i])
+        assert got == (None if exp < 0 else exp), (texts[i], pats[i])
+        single = np.zeros(p.n_outputs, dtype=np.int32)
+        check(w.lib.fhes_program_run(ctx, p.h, ptr(in_handles[i * p.n_inputs:(i + 1) * p.n_inputs]), ptr(single)))
+        one = np.zeros((p.n_outputs, w.W), dtype=np.uint64)
+        check(w.lib.fhes_arena_download(ctx, int(single[0]), p.n_outputs, ptr(one)))
+        assert np.array_equal(one, batch[i * p.n_outputs:(i + 1) * p.n_outputs])
+        check(w.lib.fhes_arena_free(ctx, int(single[0]), p.n_outputs))
+    check(w.lib.fhes_arena_free(ctx, h, len(cts)))
+    check(w.lib.fhes_arena_free(ctx, int(out_handles[0]), len(batch)))
