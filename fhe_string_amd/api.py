@@ -123,11 +123,13 @@ class _Ct:
         return _L().fhes_ct_num_blocks(self._h)
 
 
-def _op(sk, name, *args, max_outs=4):
+def _op(sk, name, *args, ints=(), max_outs=4):
+    """args: ciphertext operands (FheString / FheUsize) in the reference's argument order"""
     arr = (C.c_void_p * len(args))(*[a._h for a in args])
+    iarr = (C.c_int64 * max(len(ints), 1))(*ints)
     outs = (C.c_void_p * max_outs)()
     n = C.c_int32()
-    check(_L().fhes_string_op(sk._h, name.encode(), arr, len(args), None, 0, outs, max_outs, C.byref(n)))
+    check(_L().fhes_string_op(sk._h, name.encode(), arr, len(args), iarr, len(ints), outs, max_outs, C.byref(n)))
     return [outs[i] for i in range(n.value)]
 
 
@@ -146,6 +148,15 @@ class FheUsize(_Ct):
         return ck.decrypt_usize(self)
 
 
+class FheAsciiChar(_Ct):
+    """mod.rs:30-38"""
+
+    def decrypt(self, ck):
+        d = _decrypt_digits(ck, self)
+        bits = ck.params.message_bits
+        return sum(int(v) << (bits * k) for k, v in enumerate(d)) & 0xFF
+
+
 class FheOption:
     """mod.rs:358-399"""
 
@@ -156,6 +167,8 @@ class FheOption:
     def decrypt(self, ck):
         if not ck.decrypt_bool(self.is_some):
             return None
+        if isinstance(self.val, tuple):
+            return tuple(v.decrypt(ck) for v in self.val)
         return self.val.decrypt(ck)
 
 
@@ -281,6 +294,83 @@ class FheString(_Ct):
 
     def rsplit_terminator(self, k, p):
         return self._split(k, "rsplit_terminator", p)
+
+    def splitn(self, k, n, p):
+        o = _op(k, "splitn", self, n, p)
+        return FheStringSliceVector(self, _Ct(o[0]), _Ct(o[1]), _Ct(o[2]), k.num_blocks_usize)
+
+    def rsplitn(self, k, n, p):
+        o = _op(k, "rsplitn", self, n, p)
+        return FheStringSliceVector(self, _Ct(o[0]), _Ct(o[1]), _Ct(o[2]), k.num_blocks_usize)
+
+    def split_ascii_whitespace(self, k):
+        o = _op(k, "split_ascii_whitespace", self)
+        return FheStringSliceVector(self, _Ct(o[0]), _Ct(o[1]), _Ct(o[2]), k.num_blocks_usize)
+
+    def split_once(self, k, p):
+        o = _op(k, "split_once", self, p)
+        return FheOption(BooleanBlock(o[0]), (FheString(o[1]), FheString(o[2])))
+
+    def rsplit_once(self, k, p):
+        o = _op(k, "rsplit_once", self, p)
+        return FheOption(BooleanBlock(o[0]), (FheString(o[1]), FheString(o[2])))
+
+    # --- mod.rs:165-237 ---
+    def char_at(self, k, i):
+        return FheAsciiChar(_op(k, "char_at", self, i)[0])
+
+    def substr_to(self, k, index):
+        return FheString(_op(k, "substr_to", self, index)[0])
+
+    def substr_from(self, k, index):
+        return FheString(_op(k, "substr_from", self, index)[0])
+
+    def substr_end(self, k, start, end):
+        return FheString(_op(k, "substr_end", self, start, end)[0])
+
+    # --- trim.rs ---
+    def truncate(self, k, index):
+        return FheString(_op(k, "truncate", self, index)[0])
+
+    def trim(self, k):
+        return FheString(_op(k, "trim", self)[0])
+
+    def trim_start(self, k):
+        return FheString(_op(k, "trim_start", self)[0])
+
+    def trim_end(self, k):
+        return FheString(_op(k, "trim_end", self)[0])
+
+    def strip_prefix(self, k, s):
+        o = _op(k, "strip_prefix", self, s)
+        return FheOption(BooleanBlock(o[0]), FheString(o[1]))
+
+    def strip_suffix(self, k, s):
+        o = _op(k, "strip_suffix", self, s)
+        return FheOption(BooleanBlock(o[0]), FheString(o[1]))
+
+    # --- convert.rs / compare.rs:113 ---
+    def to_lowercase(self, k):
+        return FheString(_op(k, "to_lowercase", self)[0])
+
+    def to_uppercase(self, k):
+        return FheString(_op(k, "to_uppercase", self)[0])
+
+    def eq_ignore_ascii_case(self, k, s):
+        return BooleanBlock(_op(k, "eq_ignore_ascii_case", self, s)[0])
+
+    # --- replace.rs / insert.rs ---
+    def replace(self, k, p, s, l):
+        return FheString(_op(k, "replace", self, p, s, ints=(l,))[0])
+
+    def replacen(self, k, p, s, n_max, l):
+        return FheString(_op(k, "replacen", self, p, s, n_max, ints=(l,))[0])
+
+    def add(self, k, s):
+        return FheString(_op(k, "add", self, s)[0])
+
+    def insert(self, k, index, s):
+        return FheString(_op(k, "insert", self, index, s)[0])
 
 
 class StringEncryption:

@@ -51,6 +51,7 @@ struct Program {
   std::vector<int32_t> level_ptr;       // PBS levels, then (optionally) one linear level
   std::vector<Table> luts;
   std::vector<int32_t> out_slots;       // one per output block
+  std::vector<int32_t> out_parts;       // block counts of the result objects (sum == out_slots.size())
   int64_t n_pbs = 0;
   std::string name;
 };

@@ -185,10 +185,13 @@ struct S {
   }
 
   // mod.rs:271-287
+  // (i == j) holds for at most one j: the terms are mutually exclusive, `any` of them is
+  // their plain sum (a boolean), see sum_exclusive.
   Blk element_at_bool(const std::vector<Blk> &v, const Radix &i) {
-    std::vector<Blk> w;
-    for (size_t j = 0; j < v.size(); j++) w.push_back(o.bitand_(o.scalar_eq(i, j), v[j]));
-    return any(w);
+    std::vector<Radix> w;
+    for (size_t j = 0; j < v.size(); j++) w.push_back(Radix{o.bitand_(o.scalar_eq(i, j), v[j])});
+    if (w.empty()) return o.trivial_bool(false);
+    return sum_exclusive(w, 1)[0];
   }
 
   // search.rs:68-110
@@ -227,6 +230,150 @@ struct S {
     return out;
   }
 
+  // one-hot gather: terms are mutually exclusive (i == j holds for at most one j), so the
+  // column sums cannot exceed one term's value -- the degree bound of a sum of exclusive
+  // terms is the maximum, not the total, and no carry can appear.
+  Radix sum_exclusive(const std::vector<Radix> &v, int nblocks) {
+    Radix out;
+    for (int c = 0; c < nblocks; c++) {
+      Blk acc = o.b.trivial(0);
+      uint32_t deg = 0;
+      for (const Radix &r : v) {
+        if (r[c].trivial() && r[c].cst == 0) continue;
+        Blk t = o.b.tame(r[c], 1);
+        if (acc.noise + t.noise > Builder::kNoiseCap) { acc = o.b.clean(acc); }
+        deg = std::max(deg, std::max(acc.deg, t.deg));
+        acc = o.b.add(acc, t);
+        acc.deg = deg;
+      }
+      out.push_back(acc);
+    }
+    return out;
+  }
+
+  // mod.rs:217-237
+  Radix char_at(const Str &a, const Radix &i) {
+    std::vector<Radix> v;
+    for (size_t j = 0; j < a.size(); j++) v.push_back(if_then_else_zero(o.scalar_eq(i, j), a[j]));
+    if (v.empty()) return term_char();
+    return sum_exclusive(v, Bc);
+  }
+  // mod.rs:165-180 and trim.rs:119-132 (identical circuits)
+  Str substr_to(const Str &a, const Radix &index) {
+    Str v;
+    for (size_t i = 0; i < a.size(); i++) v.push_back(if_then_else_zero(o.scalar_cmp(index, i, Cmp::GT), a[i]));
+    return v;
+  }
+  // mod.rs:183-195
+  Str substr_from(const Str &a, const Radix &index) {
+    Str v;
+    for (size_t i = 0; i < a.size(); i++) v.push_back(char_at(a, o.scalar_add(index, i)));
+    return v;
+  }
+  // mod.rs:198-213
+  Str substr_end(const Str &a, const Radix &start, const Radix &end) {
+    Str v;
+    for (size_t i = 0; i < a.size(); i++) {
+      Radix t = o.scalar_add(start, i);
+      Blk lt_end = o.cmp(t, end, Cmp::LT);
+      v.push_back(if_then_else_zero(lt_end, char_at(a, t)));
+    }
+    return v;
+  }
+
+  // trim.rs:15-25
+  Blk is_whitespace(const Radix &c) {
+    Blk ge9 = o.scalar_cmp(c, 9, Cmp::GE), le13 = o.scalar_cmp(c, 13, Cmp::LE);
+    return o.bitor_(o.bitand_(ge9, le13), o.scalar_eq(c, 32));
+  }
+  Blk not_term_not_ws(const Radix &c) {  // trim.rs:46-51, 65-70
+    Blk not_term = o.bitnot_(o.scalar_eq(c, 0));
+    Blk not_ws = o.bitnot_(is_whitespace(c));
+    return o.bitand_(not_term, not_ws);
+  }
+  // trim.rs:31-39
+  Str trim_start(const Str &a) {
+    std::vector<Blk> v;
+    for (const Radix &c : a) v.push_back(o.bitnot_(is_whitespace(c)));
+    Option i_opt = index_of(v, false);
+    return substr_from(a, if_then_else_zero(i_opt.is_some, i_opt.val));
+  }
+  // trim.rs:43-58
+  Str trim_end(const Str &a) {
+    std::vector<Blk> v;
+    for (const Radix &c : a) v.push_back(not_term_not_ws(c));
+    Option i_opt = index_of(v, true);
+    return substr_to(a, if_then_else_zero(i_opt.is_some, o.scalar_add(i_opt.val, 1)));
+  }
+  // trim.rs:63-85
+  Str trim(const Str &a) {
+    std::vector<Blk> found;
+    for (const Radix &c : a) found.push_back(not_term_not_ws(c));
+    Option first = index_of(found, false), last = index_of(found, true);
+    Str t = substr_to(a, if_then_else_zero(last.is_some, o.scalar_add(last.val, 1)));
+    return substr_from(t, if_then_else_zero(first.is_some, first.val));
+  }
+
+  // convert.rs:14-45
+  Radix to_lowercase_char(const Radix &c) {
+    Blk ucase = o.bitand_(o.scalar_cmp(c, 65, Cmp::GE), o.scalar_cmp(c, 90, Cmp::LE));
+    return o.if_then_else(ucase, o.scalar_add(c, 32), c);
+  }
+  Radix to_uppercase_char(const Radix &c) {
+    Blk lcase = o.bitand_(o.scalar_cmp(c, 97, Cmp::GE), o.scalar_cmp(c, 122, Cmp::LE));
+    return o.if_then_else(lcase, o.scalar_sub(c, 32), c);
+  }
+  Str map_chars(const Str &a, bool lower) {  // convert.rs:51-61
+    Str v;
+    for (const Radix &c : a) v.push_back(lower ? to_lowercase_char(c) : to_uppercase_char(c));
+    return v;
+  }
+
+  // replace.rs:37-104
+  Str replace_opt(const Str &a, const Str &p, const Str &sub, const Radix *n_max, size_t l, size_t max_len_key) {
+    l = std::min(l, max_len_key);
+    std::vector<Blk> found = find_all(a, p);
+    Radix p_len = len(p), s_len = len(sub);
+    Radix len_diff = o.sub(p_len, s_len);
+    Blk in_match = o.trivial_bool(false);
+    Radix j = usize(0), n = usize(0);
+    Str v;
+    for (size_t i = 0; i < l; i++) {
+      Radix c = o.scalar_add(o.mul(n, len_diff), i);
+      Blk j_lt_slen = o.cmp(j, s_len, Cmp::LT);
+      Blk m_and_j = o.bitand_(in_match, j_lt_slen);
+      Blk found_c = element_at_bool(found, c);
+      Blk fc = n_max ? o.bitand_(found_c, o.cmp(n, *n_max, Cmp::LT)) : found_c;
+      Radix n_add = o.add(n, usize_from_bool(fc));
+      in_match = if_then_else_bool(m_and_j, in_match, fc);
+      j = if_then_else_zero(m_and_j, j);
+      n = o.if_then_else(m_and_j, n, n_add);
+      Radix sj = char_at(sub, j), self_c = char_at(a, c);
+      v.push_back(o.if_then_else(in_match, sj, self_c));
+      j = o.scalar_add(j, 1);
+    }
+    v.push_back(term_char());
+    return v;
+  }
+
+  // insert.rs:48-124
+  Str insert(const Str &a, const Radix &index, const Str &bstr, size_t max_len_key) {
+    const size_t l = std::min(max_len(a) + max_len(bstr), max_len_key);
+    Radix b_len = len(bstr);
+    Radix index_add_blen = o.add(index, b_len);
+    Str v;
+    for (size_t i = 0; i < l; i++) {
+      Blk i_lt = o.scalar_cmp(index_add_blen, i, Cmp::GT);
+      Radix b_at = char_at(bstr, o.sub(usize(i), index));
+      Radix a_at = char_at(a, o.sub(usize(i), b_len));
+      Radix c2 = o.if_then_else(i_lt, b_at, a_at);
+      Blk c0 = o.scalar_cmp(index, i, Cmp::GT);
+      v.push_back(o.if_then_else(c0, a[i % a.size()], c2));
+    }
+    v.push_back(term_char());
+    return v;
+  }
+
   struct Slice { Blk is_some; Radix start, end; };  // FheOption<FheStringSlice> split.rs:10-28
 
   // split.rs:116-144
@@ -241,6 +388,62 @@ struct S {
       bb = o.bitand_(bb, o.bitnot_(vi.is_some));
       vi.is_some = is_some;
     }
+  }
+
+  // split.rs:86-113
+  void truncate_slices(std::vector<Slice> &v, const Radix &i) {
+    Radix n = usize(0);
+    for (Slice &vi : v) {
+      Blk n_lt_i = o.cmp(n, i, Cmp::LT);
+      Blk is_some = o.bitand_(n_lt_i, vi.is_some);
+      n = o.add(n, usize_from_bool(vi.is_some));
+      vi.is_some = is_some;
+    }
+  }
+  // split.rs:147-173
+  void expand_first(std::vector<Slice> &v) {
+    Blk not_found = o.trivial_bool(true);
+    Radix zero = usize(0);
+    for (Slice &vi : v) {
+      Blk nf_and_some = o.bitand_(not_found, vi.is_some);
+      vi.start = o.if_then_else(nf_and_some, zero, vi.start);
+      not_found = o.bitand_(not_found, o.bitnot_(vi.is_some));
+    }
+  }
+  // split.rs:176-205
+  void expand_last(std::vector<Slice> &v, const Str &a) {
+    Blk not_found = o.trivial_bool(true);
+    Radix self_len = len(a);
+    for (size_t k = v.size(); k-- > 0;) {
+      Slice &vi = v[k];
+      Blk nf_and_some = o.bitand_(not_found, vi.is_some);
+      vi.end = o.if_then_else(nf_and_some, self_len, vi.end);
+      not_found = o.bitand_(not_found, o.bitnot_(vi.is_some));
+    }
+  }
+  // search.rs:179-194 over search.rs:54-64
+  Option find_next_pred(const std::vector<Blk> &pred, size_t i) {
+    std::vector<Blk> sub(pred.begin() + std::min(i, pred.size()), pred.end());
+    Option idx = index_of(sub, false);
+    return {idx.is_some, o.scalar_add(idx.val, i)};
+  }
+  // split.rs:415-473
+  std::vector<Slice> split_ascii_whitespace(const Str &a) {
+    std::vector<Blk> ws;
+    for (const Radix &c : a) ws.push_back(o.bitor_(is_whitespace(c), o.scalar_eq(c, 0)));
+    std::vector<Option> next;
+    for (size_t i = 0; i < a.size(); i++) next.push_back(find_next_pred(ws, i));
+    Radix self_len = len(a);
+    std::vector<Slice> v;
+    for (size_t i = 0; i < a.size(); i++) {
+      Blk prev = i == 0 ? o.trivial_bool(true) : ws[i - 1];
+      Blk is_some = o.bitand_(o.bitnot_(ws[i]), prev);
+      Radix end;
+      if (i + 1 < next.size()) end = o.if_then_else(next[i + 1].is_some, next[i + 1].val, self_len);
+      else end = self_len;  // opt_default: is_some = false (split.rs:433-436)
+      v.push_back({is_some, usize(i), end});
+    }
+    return v;
   }
 
   // split.rs:238-333
@@ -281,6 +484,31 @@ void push_all(std::vector<Blk> &out, const Radix &r) {
 
 }  // namespace
 
+// Operand signature of every operation: S = FheString, U = FheUsize, I = clear integer.
+// `shape` lists, in operand order, the slot count of each S operand and the value of each I
+// operand (U operands contribute nothing: they are num_blocks_usize blocks).
+struct OpSig { const char *name; const char *sig; };
+static const OpSig kOps[] = {
+    {"find", "SS"}, {"rfind", "SS"}, {"contains", "SS"}, {"starts_with", "SS"}, {"ends_with", "SS"},
+    {"eq", "SS"}, {"ne", "SS"}, {"lt", "SS"}, {"le", "SS"}, {"gt", "SS"}, {"ge", "SS"},
+    {"eq_ignore_ascii_case", "SS"}, {"is_empty", "S"}, {"len", "S"},
+    {"split", "SS"}, {"rsplit", "SS"}, {"split_inclusive", "SS"}, {"split_terminator", "SS"},
+    {"rsplit_terminator", "SS"}, {"splitn", "SUS"}, {"rsplitn", "SUS"}, {"split_ascii_whitespace", "S"},
+    {"split_once", "SS"}, {"rsplit_once", "SS"},
+    {"char_at", "SU"}, {"substr_to", "SU"}, {"substr_from", "SU"}, {"substr_end", "SUU"}, {"truncate", "SU"},
+    {"trim", "S"}, {"trim_start", "S"}, {"trim_end", "S"}, {"strip_prefix", "SS"}, {"strip_suffix", "SS"},
+    {"to_lowercase", "S"}, {"to_uppercase", "S"},
+    {"replace", "SSSI"}, {"replacen", "SSSUI"}, {"add", "SS"}, {"insert", "SUS"},
+};
+
+const char *op_signature(const std::string &op) {
+  for (const auto &e : kOps)
+    if (op == e.name) return e.sig;
+  if (op == "find_all_range") return "SSII";
+  if (op == "any_of" || op == "index_of" || op == "rindex_of") return "I";
+  return nullptr;
+}
+
 Program compile_op(const fhes_params &p, const std::string &op, const std::vector<int32_t> &shape,
                    int32_t num_blocks_usize) {
   const int msg_mod = 1 << p.message_bits;
@@ -288,70 +516,187 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
   for (int v = 1; v < 128; v *= msg_mod) Bc++;  // lib.rs:60-61
   const int Bu = num_blocks_usize;
   if (Bu < 1 || Bu > 16) throw std::invalid_argument("num_blocks_usize out of range");
+  uint64_t max_len_key = 1;  // mod.rs:240-244, 435-437
+  for (int i = 0; i < Bu; i++) max_len_key *= (uint64_t)msg_mod;
+  max_len_key -= 1;
 
-  // inputs: strings as [slots][Bc] blocks, in argument order
-  int n_str = 0;
-  static const char *two_str[] = {"find", "rfind", "contains", "starts_with", "ends_with", "eq", "ne",
-                                  "lt", "le", "gt", "ge", "split", "rsplit", "split_inclusive",
-                                  "split_terminator", "rsplit_terminator"};
-  static const char *one_str[] = {"is_empty", "len"};
-  for (auto s : two_str) if (op == s) n_str = 2;
-  for (auto s : one_str) if (op == s) n_str = 1;
-  if (!n_str) throw std::invalid_argument("unknown operation '" + op + "'");
-  if ((int)shape.size() != n_str) throw std::invalid_argument("operation '" + op + "' needs one slot count per string operand");
+  // position-sharded building blocks: shape = {slots_a, slots_b, lo, hi}
+  if (op == "find_all_range") {
+    if (shape.size() != 4 || shape[0] < 1 || shape[1] < 1 || shape[2] < 0 || shape[3] < shape[2] || shape[3] > shape[0] - 1)
+      throw std::invalid_argument("find_all_range needs {slots_a, slots_b, lo, hi} with 0 <= lo <= hi <= slots_a - 1");
+    Builder b(p, (shape[0] + shape[1]) * Bc);
+    Ops o(b);
+    S s{o, Bc, Bu};
+    Str sa, sb;
+    int32_t next = 0;
+    for (int c = 0; c < shape[0]; c++) { Radix ch; for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1)); sa.push_back(ch); }
+    for (int c = 0; c < shape[1]; c++) { Radix ch; for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1)); sb.push_back(ch); }
+    std::vector<Blk> out;
+    for (int i = shape[2]; i < shape[3]; i++) out.push_back(s.substr_eq(sa, (size_t)i, sb));  // search.rs:33-41
+    Program prog = b.finish(out, op);
+    prog.out_parts = {(int32_t)out.size()};
+    return prog;
+  }
+  // reductions over n boolean blocks: shape = {n}
+  if (op == "any_of" || op == "index_of" || op == "rindex_of") {
+    if (shape.size() != 1 || shape[0] < 0) throw std::invalid_argument(op + " needs {n}");
+    Builder b(p, shape[0]);
+    Ops o(b);
+    S s{o, Bc, Bu};
+    std::vector<Blk> v;
+    for (int i = 0; i < shape[0]; i++) v.push_back(b.input(i, 1));
+    std::vector<Blk> out;
+    Program prog;
+    if (op == "any_of") {
+      out.push_back(s.any(v));  // logic.rs:41-51
+      prog = b.finish(out, op);
+      prog.out_parts = {1};
+    } else {
+      Option r = s.index_of(v, op == "rindex_of");  // mod.rs:292-355
+      out.push_back(r.is_some);
+      push_all(out, r.val);
+      prog = b.finish(out, op);
+      prog.out_parts = {1, Bu};
+    }
+    return prog;
+  }
+
+  const char *sig = op_signature(op);
+  if (!sig) throw std::invalid_argument("unknown operation '" + op + "'");
+  const std::string sg = sig;
+  size_t need = 0;
+  for (char c : sg) need += (c == 'S' || c == 'I');
+  if (shape.size() != need)
+    throw std::invalid_argument("operation '" + op + "' (signature " + sg + ") needs " + std::to_string(need) + " shape entries");
   int32_t n_inputs = 0;
-  for (int v : shape) {
-    if (v < 1) throw std::invalid_argument("a string has at least its terminator slot");
-    n_inputs += v * Bc;
+  {
+    size_t k = 0;
+    for (char c : sg) {
+      if (c == 'S') { if (shape[k] < 1) throw std::invalid_argument("a string has at least its terminator slot"); n_inputs += shape[k++] * Bc; }
+      else if (c == 'U') n_inputs += Bu;
+      else { if (shape[k] < 0) throw std::invalid_argument("negative integer argument"); k++; }
+    }
   }
   Builder b(p, n_inputs);
   Ops o(b);
   S s{o, Bc, Bu};
   std::vector<Str> strs;
-  int32_t next = 0;
-  for (int v : shape) {
-    Str st;
-    for (int c = 0; c < v; c++) {
-      Radix ch;
-      for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1));
-      st.push_back(ch);
+  std::vector<Radix> us;
+  std::vector<int64_t> ints;
+  {
+    int32_t next = 0;
+    size_t k = 0;
+    for (char c : sg) {
+      if (c == 'S') {
+        Str st;
+        for (int ch = 0; ch < shape[k]; ch++) {
+          Radix r;
+          for (int q = 0; q < Bc; q++) r.push_back(b.input(next++, msg_mod - 1));
+          st.push_back(r);
+        }
+        strs.push_back(st);
+        k++;
+      } else if (c == 'U') {
+        Radix r;
+        for (int q = 0; q < Bu; q++) r.push_back(b.input(next++, msg_mod - 1));
+        us.push_back(r);
+      } else ints.push_back(shape[k++]);
     }
-    strs.push_back(st);
   }
 
   std::vector<Blk> out;
-  if (op == "find" || op == "rfind") {
-    Option r = op == "find" ? s.find(strs[0], strs[1]) : s.rfind(strs[0], strs[1]);
-    out.push_back(r.is_some);
-    push_all(out, r.val);
-  } else if (op == "contains") out.push_back(s.contains(strs[0], strs[1]));
-  else if (op == "starts_with") out.push_back(s.starts_with(strs[0], strs[1]));
-  else if (op == "ends_with") out.push_back(s.ends_with(strs[0], strs[1]));
-  else if (op == "eq") out.push_back(s.eq(strs[0], strs[1]));
-  else if (op == "ne") out.push_back(o.bitnot_(s.eq(strs[0], strs[1])));  // compare.rs:49-52
-  else if (op == "lt") out.push_back(s.lt(strs[0], strs[1]));
-  else if (op == "le") out.push_back(s.le(strs[0], strs[1]));
-  else if (op == "gt") out.push_back(s.gt(strs[0], strs[1]));
-  else if (op == "ge") out.push_back(s.ge(strs[0], strs[1]));
-  else if (op == "is_empty") out.push_back(s.is_empty(strs[0]));
-  else if (op == "len") push_all(out, s.len(strs[0]));
-  else {
-    // split family (split.rs:339-411); output: is_some[n], start[n][Bu], end[n][Bu]
-    std::vector<S::Slice> v;
-    if (op == "split") v = s.split_opt(strs[0], strs[1], false, false);
-    else if (op == "rsplit") { v = s.split_opt(strs[0], strs[1], false, true); std::reverse(v.begin(), v.end()); }
-    else if (op == "split_inclusive") v = s.split_opt(strs[0], strs[1], true, false);
-    else if (op == "split_terminator") { v = s.split_opt(strs[0], strs[1], false, false); s.truncate_last_if_empty(v); }
-    else {  // rsplit_terminator
-      v = s.split_opt(strs[0], strs[1], false, true);
-      s.truncate_last_if_empty(v);  // rsplit reverses, this op reverses back, truncates, reverses
-      std::reverse(v.begin(), v.end());
-    }
+  std::vector<int32_t> parts;
+  auto put_bool = [&](const Blk &x) { out.push_back(x); parts.push_back(1); };
+  auto put_radix = [&](const Radix &r) { push_all(out, r); parts.push_back((int32_t)r.size()); };
+  auto put_str = [&](const Str &st) { for (const Radix &c : st) push_all(out, c); parts.push_back((int32_t)st.size() * Bc); };
+  auto put_slices = [&](const std::vector<S::Slice> &v) {
     for (auto &e : v) out.push_back(e.is_some);
     for (auto &e : v) push_all(out, e.start);
     for (auto &e : v) push_all(out, e.end);
+    parts.push_back((int32_t)v.size());
+    parts.push_back((int32_t)v.size() * Bu);
+    parts.push_back((int32_t)v.size() * Bu);
+  };
+
+  if (op == "find" || op == "rfind") {
+    Option r = op == "find" ? s.find(strs[0], strs[1]) : s.rfind(strs[0], strs[1]);
+    put_bool(r.is_some);
+    put_radix(r.val);
+  } else if (op == "contains") put_bool(s.contains(strs[0], strs[1]));
+  else if (op == "starts_with") put_bool(s.starts_with(strs[0], strs[1]));
+  else if (op == "ends_with") put_bool(s.ends_with(strs[0], strs[1]));
+  else if (op == "eq") put_bool(s.eq(strs[0], strs[1]));
+  else if (op == "ne") put_bool(o.bitnot_(s.eq(strs[0], strs[1])));  // compare.rs:49-52
+  else if (op == "lt") put_bool(s.lt(strs[0], strs[1]));
+  else if (op == "le") put_bool(s.le(strs[0], strs[1]));
+  else if (op == "gt") put_bool(s.gt(strs[0], strs[1]));
+  else if (op == "ge") put_bool(s.ge(strs[0], strs[1]));
+  else if (op == "eq_ignore_ascii_case")  // compare.rs:113-116
+    put_bool(s.eq(s.map_chars(strs[0], true), s.map_chars(strs[1], true)));
+  else if (op == "is_empty") put_bool(s.is_empty(strs[0]));
+  else if (op == "len") put_radix(s.len(strs[0]));
+  else if (op == "char_at") put_radix(s.char_at(strs[0], us[0]));
+  else if (op == "substr_to" || op == "truncate") put_str(s.substr_to(strs[0], us[0]));
+  else if (op == "substr_from") put_str(s.substr_from(strs[0], us[0]));
+  else if (op == "substr_end") put_str(s.substr_end(strs[0], us[0], us[1]));
+  else if (op == "trim") put_str(s.trim(strs[0]));
+  else if (op == "trim_start") put_str(s.trim_start(strs[0]));
+  else if (op == "trim_end") put_str(s.trim_end(strs[0]));
+  else if (op == "to_lowercase") put_str(s.map_chars(strs[0], true));
+  else if (op == "to_uppercase") put_str(s.map_chars(strs[0], false));
+  else if (op == "strip_prefix") {  // trim.rs:89-97
+    put_bool(s.substr_eq(strs[0], 0, strs[1]));
+    put_str(s.substr_from(strs[0], s.len(strs[1])));
+  } else if (op == "strip_suffix") {  // trim.rs:101-116
+    Option found = s.rfind(strs[0], strs[1]);
+    Str stripped = s.substr_to(strs[0], found.val);
+    Radix t = o.add(found.val, s.len(strs[1]));
+    put_bool(o.bitand_(found.is_some, o.eq(t, s.len(strs[0]))));
+    put_str(stripped);
+  } else if (op == "split_once" || op == "rsplit_once") {  // split.rs:478-513
+    Option found = op == "split_once" ? s.find(strs[0], strs[1]) : s.rfind(strs[0], strs[1]);
+    Radix next = o.add(found.val, s.len(strs[1]));
+    put_bool(found.is_some);
+    put_str(s.substr_to(strs[0], found.val));
+    put_str(s.substr_from(strs[0], next));
+  } else if (op == "replace") {  // replace.rs:17-20
+    put_str(s.replace_opt(strs[0], strs[1], strs[2], nullptr, (size_t)ints[0], max_len_key));
+  } else if (op == "replacen") {  // replace.rs:23-33
+    put_str(s.replace_opt(strs[0], strs[1], strs[2], &us[0], (size_t)ints[0], max_len_key));
+  } else if (op == "add") {  // insert.rs:14-17
+    put_str(s.insert(strs[0], s.len(strs[0]), strs[1], max_len_key));
+  } else if (op == "insert") {  // insert.rs:48
+    put_str(s.insert(strs[0], us[0], strs[1], max_len_key));
+  } else if (op == "split_ascii_whitespace") put_slices(s.split_ascii_whitespace(strs[0]));
+  else {
+    // split family (split.rs:339-411); output: is_some[n], start[n][Bu], end[n][Bu]
+    std::vector<S::Slice> v;
+    const Str &a = strs[0], &pat = strs[1];
+    if (op == "split") v = s.split_opt(a, pat, false, false);
+    else if (op == "rsplit") { v = s.split_opt(a, pat, false, true); std::reverse(v.begin(), v.end()); }
+    else if (op == "split_inclusive") v = s.split_opt(a, pat, true, false);
+    else if (op == "split_terminator") { v = s.split_opt(a, pat, false, false); s.truncate_last_if_empty(v); }
+    else if (op == "rsplit_terminator") {
+      v = s.split_opt(a, pat, false, true);
+      s.truncate_last_if_empty(v);  // rsplit reverses, this op reverses back, truncates, reverses
+      std::reverse(v.begin(), v.end());
+    } else if (op == "splitn") {  // split.rs:368-373
+      v = s.split_opt(a, pat, false, false);
+      s.truncate_slices(v, us[0]);
+      s.expand_last(v, a);
+    } else if (op == "rsplitn") {  // split.rs:380-387
+      v = s.split_opt(a, pat, false, true);
+      std::reverse(v.begin(), v.end());
+      s.truncate_slices(v, us[0]);
+      std::reverse(v.begin(), v.end());
+      s.expand_first(v);
+      std::reverse(v.begin(), v.end());
+    } else throw std::invalid_argument("unhandled operation '" + op + "'");
+    put_slices(v);
   }
-  return b.finish(out, op);
+  Program prog = b.finish(out, op);
+  prog.out_parts = parts;
+  return prog;
 }
 
 }  // namespace circ

@@ -240,16 +240,32 @@ int fhes_ct_decrypt_blocks(const fhes_client_key *ck, fhes_ct *c, uint8_t *value
 int fhes_string_op(fhes_server_key *sk, const char *op, fhes_ct *const *args, int32_t n_args,
                    const int64_t *iargs, int32_t n_iargs, fhes_ct **outs, int32_t max_outs,
                    int32_t *n_outs) {
-  (void)iargs; (void)n_iargs;
   if (!sk || !op || !args || n_args < 1 || !outs || !n_outs) return fail(FHES_ERR_INVALID, "bad argument");
+  const char *sig = fhes_op_signature(op);
+  if (!sig) return fail(FHES_ERR_INVALID, "unknown operation '%s'", op);
   std::lock_guard<std::mutex> lk(sk->mu);
   std::vector<int32_t> shape;
   std::string key = op;
-  for (int i = 0; i < n_args; i++) {
-    if (!args[i] || args[i]->n_blocks % sk->nb_char) return fail(FHES_ERR_INVALID, "operand %d is not a string", i);
-    shape.push_back(args[i]->n_blocks / sk->nb_char);
-    key += ":" + std::to_string(shape.back());
+  int ai = 0, ii = 0;
+  for (const char *c = sig; *c; ++c) {
+    if (*c == 'I') {
+      if (ii >= n_iargs || !iargs) return fail(FHES_ERR_INVALID, "operation '%s' (signature %s): missing integer argument", op, sig);
+      if (iargs[ii] < 0 || iargs[ii] > INT32_MAX) return fail(FHES_ERR_INVALID, "integer argument out of range");
+      shape.push_back((int32_t)iargs[ii++]);
+      key += ":i" + std::to_string(shape.back());
+      continue;
+    }
+    if (ai >= n_args || !args[ai]) return fail(FHES_ERR_INVALID, "operation '%s' (signature %s): missing operand %d", op, sig, ai);
+    if (*c == 'S') {
+      if (args[ai]->n_blocks % sk->nb_char) return fail(FHES_ERR_INVALID, "operand %d is not a string", ai);
+      shape.push_back(args[ai]->n_blocks / sk->nb_char);
+      key += ":" + std::to_string(shape.back());
+    } else if (args[ai]->n_blocks != sk->nb_usize) {
+      return fail(FHES_ERR_INVALID, "operand %d is not an FheUsize (%d blocks)", ai, sk->nb_usize);
+    }
+    ai++;
   }
+  if (ai != n_args || ii != n_iargs) return fail(FHES_ERR_INVALID, "operation '%s' (signature %s): wrong operand count", op, sig);
   fhes_program *prog;
   auto it = sk->cache.find(key);
   if (it != sk->cache.end()) prog = it->second;
@@ -267,29 +283,16 @@ int fhes_string_op(fhes_server_key *sk, const char *op, fhes_ct *const *args, in
     for (int k = 0; k < args[i]->n_blocks; k++) in.push_back(args[i]->handle + k);
   }
   if ((int64_t)in.size() != info[0]) return fail(FHES_ERR_INVALID, "operand sizes do not match the program");
+  int32_t parts[16];
+  const int32_t n_parts = fhes_program_out_parts(prog, parts, 16);
+  if (n_parts < 1 || n_parts > 16) return fail(FHES_ERR_STATE, "internal: bad result layout");
+  if (n_parts > max_outs) return fail(FHES_ERR_INVALID, "need room for %d results", n_parts);
   std::vector<int32_t> out((size_t)std::max<int64_t>(info[1], 1));
   int rc = fhes_program_run(sk->ctx, prog, in.data(), out.data());
   if (rc) return rc;
-  // result layout per operation
-  std::vector<int32_t> parts;
-  const std::string o = op;
-  const int32_t total = (int32_t)info[1];
-  if (o == "find" || o == "rfind") parts = {1, sk->nb_usize};
-  else if (o == "len") parts = {sk->nb_usize};
-  else if (o.find("split") != std::string::npos) {
-    const int32_t n = total / (1 + 2 * sk->nb_usize);
-    parts = {n, n * sk->nb_usize, n * sk->nb_usize};
-  } else parts = {1};
-  int32_t sum = 0;
-  for (int32_t v : parts) sum += v;
-  if (sum != total) return fail(FHES_ERR_STATE, "internal: unexpected output count");
-  if ((int32_t)parts.size() > max_outs) {
-    fhes_arena_free(sk->ctx, out[0], total);
-    return fail(FHES_ERR_INVALID, "need room for %d results", (int)parts.size());
-  }
   int32_t off = 0;
   const Dims d(sk->p);
-  for (size_t k = 0; k < parts.size(); k++) {
+  for (int32_t k = 0; k < n_parts; k++) {
     auto *c = new fhes_ct;
     c->n_blocks = parts[k];
     c->ct_words = d.ct_words();
@@ -298,7 +301,7 @@ int fhes_string_op(fhes_server_key *sk, const char *op, fhes_ct *const *args, in
     off += parts[k];
     outs[k] = c;
   }
-  *n_outs = (int32_t)parts.size();
+  *n_outs = n_parts;
   return FHES_OK;
 }
 

@@ -94,6 +94,15 @@ int fhes_program_info(const fhes_program *fp, int64_t info[8]) {
   return FHES_OK;
 }
 
+int32_t fhes_program_out_parts(const fhes_program *fp, int32_t *parts, int32_t max_parts) {
+  if (!fp || (max_parts > 0 && !parts)) return fail(FHES_ERR_INVALID, "null argument");
+  const int32_t n = (int32_t)fp->prog.out_parts.size();
+  for (int32_t i = 0; i < n && i < max_parts; i++) parts[i] = fp->prog.out_parts[i];
+  return n;
+}
+
+const char *fhes_op_signature(const char *op) { return op ? circ::op_signature(op) : nullptr; }
+
 int fhes_program_export(const fhes_program *fp, int32_t *level_ptr, int32_t *term_ptr, int32_t *term_idx,
                         int64_t *term_coef, uint64_t *consts, int32_t *lut_ids, int32_t *out_idx,
                         uint64_t *lut_tables, int32_t *out_slots, uint64_t *out_trivial) {

@@ -152,10 +152,14 @@ int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles
 /* ============================ Level 1: compiled circuits ================================ */
 typedef struct fhes_program fhes_program;
 
+/* Operand signature of an operation: one letter per operand in the order of the reference's
+ * method arguments (self first): S = FheString, U = FheUsize, I = clear integer.  E.g.
+ * "find" -> "SS", "splitn" -> "SUS" (self, n, pattern), "replacen" -> "SSSUI".  NULL if unknown. */
+const char *fhes_op_signature(const char *op);
 /* Compile a string operation for static shapes (host only, no device needed).
- *   op: "find" "rfind" "contains" "starts_with" "ends_with" "eq" "ne" "lt" "le" "gt"
- *       "ge" "is_empty" "len" "split" ... (see fhe_string_amd/csrc/circuit/ops.cpp)
- *   shape: op-specific (slot counts of the operands), n_shape entries
+ *   op: the reference's method name (see fhe_string_amd/csrc/circuit/strings.cpp: kOps)
+ *   shape: in operand order, the slot count (chars incl. terminator/padding) of each S
+ *          operand and the value of each I operand; U operands contribute no entry
  *   num_blocks_usize: lib.rs:62 */
 fhes_program *fhes_program_compile(const fhes_params *p, const char *op, const int32_t *shape,
                                    int32_t n_shape, int32_t num_blocks_usize);
@@ -163,6 +167,9 @@ void fhes_program_destroy(fhes_program *prog);
 /* sizes: [0]=n_inputs [1]=n_outputs [2]=n_nodes [3]=n_levels [4]=n_terms [5]=n_luts
  *        [6]=n_slots (inputs + node outputs) [7]=n_pbs */
 int fhes_program_info(const fhes_program *prog, int64_t info[8]);
+/* Block counts of the result objects, in order (e.g. find -> {1, Bu}; split -> {n, n*Bu, n*Bu};
+ * strip_prefix -> {1, slots*Bc}).  Returns the number of parts. */
+int32_t fhes_program_out_parts(const fhes_program *prog, int32_t *parts, int32_t max_parts);
 /* Export for execution elsewhere (tests run programs on the oracle / a plaintext model).
  * Slot numbering: inputs are slots [0,n_inputs); node j writes slot out_idx[j]. */
 int fhes_program_export(const fhes_program *prog, int32_t *level_ptr, int32_t *term_ptr,
@@ -206,9 +213,11 @@ int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out);
 /* raw decoded value (message + carry + padding bit) of every block; values[num_blocks] */
 int fhes_ct_decrypt_blocks(const fhes_client_key *ck, fhes_ct *c, uint8_t *values);
 
-/* Generic operation dispatch: op names as in fhes_program_compile.  `args` are the
- * ciphertext operands (self first), `iargs` clear integer arguments.  Results are
- * returned in `outs` (caller destroys).  FheOption<T> returns {is_some, val}. */
+/* Generic operation dispatch: op names and operand order as in fhes_op_signature.  `args` are
+ * the ciphertext operands (S and U, in signature order), `iargs` the clear integers (I).
+ * Results are returned in `outs` (caller destroys), one object per part of
+ * fhes_program_out_parts: FheOption<T> -> {is_some, val}; split family -> {is_some[n],
+ * start[n][Bu], end[n][Bu]} over `self`; split_once -> {is_some, prefix, suffix}. */
 int fhes_string_op(fhes_server_key *sk, const char *op, fhes_ct *const *args, int32_t n_args,
                    const int64_t *iargs, int32_t n_iargs, fhes_ct **outs, int32_t max_outs,
                    int32_t *n_outs);

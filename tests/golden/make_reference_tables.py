@@ -119,7 +119,65 @@ add("rfind", a, None, b, None, 5, "README.md:34")
 add("eq", a, None, b, None, False, "README.md:34")
 add("split", a, None, b, None, [" A ", "", " "], "README.md:34")
 
+# ---- second table: operations with FheUsize / clear-int operands or string results ----------
+# generic form: {"op", "args": [operand...], "expect", "src"}; operand = {"s": str, "pad": int|None}
+# for an FheString, {"u": int} for an encrypted FheUsize, {"i": int} for a clear integer; operand
+# order as in the reference's method signature (self first).
+ext = []
+
+
+def S(s, pad=None):
+    return {"s": s, "pad": pad}
+
+
+def addx(op, args, expect, src):
+    ext.append({"op": op, "args": args, "expect": expect, "src": src})
+
+
+WS = " \t\n\x0b\x0c\r"
+# tests/trim.rs:15-36
+for a, pad in [("   abc   ", None), ("abc   ", None), ("   abc", None), ("abc", None), ("a ", 3), ("", None)]:
+    addx("trim", [S(a, pad)], a.strip(WS), "tests/trim.rs:15-36")
+    addx("trim_start", [S(a, pad)], a.lstrip(WS), "tests/trim.rs:15-36")
+    addx("trim_end", [S(a, pad)], a.rstrip(WS), "tests/trim.rs:15-36")
+# tests/trim.rs:95-116
+for a, b in [("abc", "ab"), ("abc", "bc"), ("abc", "abc"), ("abc", "def")]:
+    addx("strip_prefix", [S(a), S(b)], a[len(b):] if a.startswith(b) else None, "tests/trim.rs:95-116")
+    addx("strip_suffix", [S(a), S(b)], a[:len(a) - len(b)] if a.endswith(b) else None, "tests/trim.rs:95-116")
+# tests/replace.rs:20-41 (pad applies to input, pattern and replacement; l = result length)
+for a, p, r, pad in [("aa", "a", "b", None), ("abdb", "b", "c", None), ("aa", "aa", "b", None), ("ababcd", "ab", "c", 8)]:
+    res = a.replace(p, r)
+    addx("replace", [S(a, pad), S(p, pad), S(r, pad), {"i": len(res)}], res, "tests/replace.rs:20-41")
+# tests/replace.rs:78-96
+for a, p, r, pad, n in [("aaa", "a", "b", None, 2), ("abdb", "b", "c", 4, 1), ("aaaa", "aa", "b", None, 3)]:
+    res = a.replace(p, r, n)
+    addx("replacen", [S(a, pad), S(p, pad), S(r, pad), {"u": n}, {"i": len(res)}], res, "tests/replace.rs:78-96")
+# tests/insert.rs:22-43 (add)
+for a, b in [("abc", "def"), ("abc", ""), ("", "def"), ("", "")]:
+    addx("add", [S(a), S(b)], a + b, "tests/insert.rs:22-43")
+# tests/convert.rs:15-24
+for a in ["ABC", "Abc", "abc def"]:
+    addx("to_lowercase", [S(a)], a.lower(), "tests/convert.rs:15-24")
+    addx("to_uppercase", [S(a)], a.upper(), "tests/convert.rs:15-24")
+# tests/compare.rs:271-290
+for a, ap, b, bp in [("abc", None, "ABC", None), ("AbC", 3, "aBc", 5), ("ABC", None, "def", None)]:
+    addx("eq_ignore_ascii_case", [S(a, ap), S(b, bp)], a.lower() == b.lower(), "tests/compare.rs:271-290")
+# tests/split.rs:81-102 (splitn), :402-423 (rsplitn): operands (self, n, pattern)
+for a, p, pad, n in [("xxx", "x", None, 1), ("axbxc", "x", None, 2), ("xxx", "xx", None, 3), ("axbxc", "x", 8, 2)]:
+    addx("splitn", [S(a, pad), {"u": n}, S(p, pad)], a.split(p, n - 1) if n else [], "tests/split.rs:81-102")
+    addx("rsplitn", [S(a, pad), {"u": n}, S(p, pad)], list(reversed(a.rsplit(p, n - 1))) if n else [], "tests/split.rs:402-423")
+# tests/split.rs:238-251
+for a, pad in [(" x x x ", None), ("ab cd ed", None), ("ab", None), (" x x x ", 8)]:
+    addx("split_ascii_whitespace", [S(a, pad)], a.split(), "tests/split.rs:238-251")
+# tests/split.rs:458-477 (split_once), :518-537 (rsplit_once)
+for a, p, pad in [("xxx", "x", None), ("axbxc", "x", None), ("xxx", "xx", None), ("axbxc", "x", 8)]:
+    i = a.find(p)
+    addx("split_once", [S(a, pad), S(p, pad)], [a[:i], a[i + len(p):]] if i >= 0 else None, "tests/split.rs:458-477")
+    i = a.rfind(p)
+    addx("rsplit_once", [S(a, pad), S(p, pad)], [a[:i], a[i + len(p):]] if i >= 0 else None, "tests/split.rs:518-537")
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tables.json")
 with open(out, "w") as f:
-    json.dump({"source": "matthiasgeihs/fhe_string src/ciphertext/tests/*.rs, README.md", "cases": cases}, f, indent=1)
-print(len(cases), "cases ->", out)
+    json.dump({"source": "matthiasgeihs/fhe_string src/ciphertext/tests/*.rs, README.md", "cases": cases,
+               "cases_ext": ext}, f, indent=1)
+print(len(cases), "+", len(ext), "cases ->", out)

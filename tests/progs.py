@@ -30,6 +30,9 @@ class Prog:
         check(self.lib.fhes_program_export(self.h, ptr(self.level_ptr), ptr(self.term_ptr), ptr(self.term_idx),
                                            ptr(self.term_coef), ptr(self.consts), ptr(self.lut_ids),
                                            ptr(self.out_idx), ptr(self.lut_tables), ptr(self.out_slots), None))
+        parts = (C.c_int32 * 16)()
+        n = self.lib.fhes_program_out_parts(self.h, parts, 16)
+        self.out_parts = [int(parts[i]) for i in range(max(n, 0))]
 
     def __del__(self):
         try:
@@ -102,6 +105,64 @@ def radix_value(digits, msg_mod=4):
     for k in reversed(range(len(digits))):
         v = v * msg_mod + int(digits[k]) % msg_mod
     return v
+
+
+# ---- generic operand / result handling (signatures from fhes_op_signature) ----
+def usize_blocks(v, bu, msg_mod=4):
+    out = np.zeros(bu, dtype=np.uint8)
+    for k in range(bu):
+        out[k] = v % msg_mod
+        v //= msg_mod
+    return out
+
+
+def build_inputs(lib, op, args, bu):
+    """args: list of {"s","pad"} / {"u"} / {"i"} in signature order -> (shape, message digits)"""
+    sig = lib.fhes_op_signature(op.encode()).decode()
+    assert len(sig) == len(args), (op, sig, args)
+    shape, digits = [], []
+    for c, a in zip(sig, args):
+        if c == "S":
+            blk = string_blocks(a["s"], a.get("pad"))
+            shape.append(len(blk) // 4)
+            digits.append(blk)
+        elif c == "U":
+            digits.append(usize_blocks(a["u"], bu))
+        else:
+            shape.append(a["i"])
+    return shape, (np.concatenate(digits) if digits else np.zeros(0, dtype=np.uint8))
+
+
+def blocks_to_str(vals, bc=4, msg_mod=4):
+    chars = []
+    for i in range(0, len(vals) - bc + 1, bc):
+        c = radix_value(vals[i:i + bc], msg_mod) & 0xFF
+        if c:
+            chars.append(chr(c))
+    return "".join(chars)
+
+
+STRING_RESULT = {"trim", "trim_start", "trim_end", "substr_to", "substr_from", "substr_end", "truncate",
+                 "to_lowercase", "to_uppercase", "replace", "replacen", "add", "insert"}
+OPTION_STRING = {"strip_prefix", "strip_suffix"}
+OPTION_PAIR = {"split_once", "rsplit_once"}
+
+
+def decode_generic(op, outs, parts, bu, self_str=None):
+    outs = [int(v) for v in outs]
+    chunks, off = [], 0
+    for n in parts:
+        chunks.append(outs[off:off + n])
+        off += n
+    if op in STRING_RESULT:
+        return blocks_to_str(chunks[0])
+    if op in OPTION_STRING:
+        return blocks_to_str(chunks[1]) if chunks[0][0] & 1 else None
+    if op in OPTION_PAIR:
+        return [blocks_to_str(chunks[1]), blocks_to_str(chunks[2])] if chunks[0][0] & 1 else None
+    if op == "char_at":
+        return radix_value(chunks[0]) & 0xFF
+    return decode_result(op, outs, bu, self_str)
 
 
 def decode_result(op, outs, bu, s=None):

@@ -11,7 +11,9 @@ from fhe_string_amd.api import default_params
 from tests.progs import Prog, decode_result, num_blocks_usize, string_blocks
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = json.load(open(os.path.join(HERE, "golden", "reference_tables.json")))["cases"]
+_TABLES = json.load(open(os.path.join(HERE, "golden", "reference_tables.json")))
+CASES = _TABLES["cases"]
+CASES_EXT = _TABLES["cases_ext"]
 
 _cache = {}
 
@@ -123,3 +125,72 @@ def test_north_star_shape(libs):
     assert run_plain("find", s, None, "\x7f\x7f\x7f\x7f", None)[0] is None
     assert p.n_inputs == (65 + 5) * 4 and p.n_outputs == 5
     assert run_plain("contains", s, None, pat, None)[0] is True
+
+
+# ---- operations with FheUsize / clear-int operands or string results -----------------------
+def run_ext(op, args, l=255):
+    import numpy as np
+    from fhe_string_amd import _lib
+    from tests.progs import build_inputs, decode_generic
+    bu = num_blocks_usize(l)
+    shape, digits = build_inputs(_lib.load(), op, args, bu)
+    p = prog(op, shape, bu)
+    outs = p.run_plain(digits.astype("int64"))
+    self_str = args[0]["s"] if "s" in args[0] else None
+    return decode_generic(op, outs, p.out_parts, bu, self_str), p
+
+
+@pytest.mark.parametrize("case", CASES_EXT, ids=lambda c: f"{c['op']}-{c['args'][0].get('s')!r}-{len(c['args'])}")
+def test_reference_tables_ext(case, libs):
+    got, _ = run_ext(case["op"], case["args"])
+    assert got == case["expect"], case
+
+
+def S(s, pad=None):
+    return {"s": s, "pad": pad}
+
+
+def test_index_operations_against_python(libs):
+    rnd = random.Random(7)
+    for trial in range(25):
+        la = rnd.randint(0, 7)
+        a = "".join(rnd.choice("abc xy") for _ in range(la))
+        pad = rnd.choice([None, la + rnd.randint(0, 2)])
+        i, j = rnd.randint(0, la + 2), rnd.randint(0, la + 2)
+        ctx = (a, pad, i, j)
+        assert run_ext("char_at", [S(a, pad), {"u": i}])[0] == (ord(a[i]) if i < la else 0), ctx
+        assert run_ext("substr_to", [S(a, pad), {"u": i}])[0] == a[:i], ctx
+        assert run_ext("truncate", [S(a, pad), {"u": i}])[0] == a[:i], ctx
+        assert run_ext("substr_from", [S(a, pad), {"u": i}])[0] == a[i:], ctx
+        assert run_ext("substr_end", [S(a, pad), {"u": i}, {"u": j}])[0] == a[i:j], ctx
+        b = "".join(rnd.choice("ab") for _ in range(rnd.randint(0, 3)))
+        k = rnd.randint(0, la)
+        assert run_ext("insert", [S(a, pad), {"u": k}, S(b)])[0] == a[:k] + b + a[k:], ctx + (b, k)
+        assert run_ext("add", [S(a, pad), S(b)])[0] == a + b, ctx + (b,)
+
+
+def test_replace_and_split_variants_against_python(libs):
+    rnd = random.Random(11)
+    for trial in range(20):
+        la = rnd.randint(1, 7)
+        a = "".join(rnd.choice("abx") for _ in range(la))
+        p = "".join(rnd.choice("abx") for _ in range(rnd.randint(1, 2)))
+        # the reference's replace emits one output char per step and therefore mishandles an EMPTY
+        # replacement (it spends a slot on the terminator of `s`, replace.rs:91-94): not tested there
+        r = "".join(rnd.choice("yz") for _ in range(rnd.randint(1, 2)))
+        n = rnd.randint(0, 3)
+        res = a.replace(p, r)
+        ctx = (a, p, r, n)
+        assert run_ext("replace", [S(a), S(p), S(r), {"i": len(res)}])[0] == res, ctx
+        resn = a.replace(p, r, n)
+        assert run_ext("replacen", [S(a), S(p), S(r), {"u": n}, {"i": len(resn)}])[0] == resn, ctx
+        assert run_ext("splitn", [S(a), {"u": n}, S(p)])[0] == (a.split(p, n - 1) if n else []), ctx
+        i = a.find(p)
+        assert run_ext("split_once", [S(a), S(p)])[0] == ([a[:i], a[i + len(p):]] if i >= 0 else None), ctx
+        assert run_ext("strip_prefix", [S(a), S(p)])[0] == (a[len(p):] if a.startswith(p) else None), ctx
+        w = "".join(rnd.choice("a b\t") for _ in range(rnd.randint(0, 7)))
+        assert run_ext("split_ascii_whitespace", [S(w)])[0] == w.split(), (w,)
+        assert run_ext("trim", [S(w)])[0] == w.strip(" \t"), (w,)
+        m = "".join(rnd.choice("aBcD zZ@[`{") for _ in range(rnd.randint(0, 6)))
+        assert run_ext("to_lowercase", [S(m)])[0] == m.lower(), (m,)
+        assert run_ext("to_uppercase", [S(m)])[0] == m.upper(), (m,)

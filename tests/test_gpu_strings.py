@@ -18,7 +18,9 @@ from tests.progs import Prog, decode_result, num_blocks_usize, string_blocks
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = json.load(open(os.path.join(HERE, "golden", "reference_tables.json")))["cases"]
+_TABLES = json.load(open(os.path.join(HERE, "golden", "reference_tables.json")))
+CASES = _TABLES["cases"]
+CASES_EXT = _TABLES["cases_ext"]
 
 
 @pytest.fixture(scope="module")
@@ -138,3 +140,61 @@ def test_batched_program_equals_single_runs(libs):
         check(w.lib.fhes_arena_free(ctx, int(single[0]), p.n_outputs))
     check(w.lib.fhes_arena_free(ctx, h, len(cts)))
     check(w.lib.fhes_arena_free(ctx, int(out_handles[0]), len(batch)))
+
+
+def test_config4_contains_1024_sharded_path_single_rank(libs):
+    """BASELINE config 4 through the position-sharded path (ShardedSearch over DeviceExecutor,
+    world size 1 here; the 2-rank exchange is covered by tests/test_parallel_gloo.py)."""
+    from fhe_string_amd.parallel import DeviceExecutor, ShardedSearch
+    w = world("default", l=1024)
+    bu = num_blocks_usize(1024)
+    assert bu == 6
+    rng = np.random.default_rng(0xF4E50004)
+    s = "".join(chr(c) for c in rng.integers(0x20, 0x7F, size=1000))
+    pat = s[700:708]
+    a = w.encrypt(string_blocks(s, 1024))
+    ss = ShardedSearch(DeviceExecutor(w.ctx(), w.p), bu)
+    for p, expect in [(pat, True), ("\x7f" * 8, False)]:
+        r = ss.contains(a, w.encrypt(string_blocks(p)))
+        assert bool(w.decrypt(r)[0] & 1) is expect
+    f = ss.find(a, w.encrypt(string_blocks(pat)))
+    assert decode_result("find", w.decrypt(f), bu) == s.find(pat)
+
+
+def test_config3_split_256(libs):
+    """BASELINE config 3: split of a 256-char input on a 1-char encrypted separator (l = 256)."""
+    ck, sk = api.generate_keys_with_params(api.default_params(), 256, seed=0xF4E50000)
+    try:
+        rng = np.random.default_rng(0xF4E50003)
+        chars = [chr(c) for c in rng.integers(0x61, 0x7B, size=256)]
+        for i in range(7, 256, 8):
+            chars[i] = ","
+        s = "".join(chars)
+        a = api.FheString.new(ck, s)
+        sep = api.FheString.new(ck, ",")
+        assert a.split(sk, sep).decrypt(ck) == s.split(",")
+        assert a.len(sk).decrypt(ck) == 256
+    finally:
+        sk.close()
+
+
+def run_api_ext(ck, sk, case):
+    args = []
+    for a in case["args"]:
+        if "s" in a:
+            args.append(api.FheString.new(ck, a["s"], a.get("pad")))
+        elif "u" in a:
+            args.append(api.FheUsize.new(ck, a["u"]))
+        else:
+            args.append(a["i"])
+    r = getattr(args[0], case["op"])(sk, *args[1:])
+    if isinstance(r, api.BooleanBlock):
+        return ck.decrypt_bool(r)
+    d = r.decrypt(ck)
+    return list(d) if isinstance(d, tuple) else d
+
+
+@pytest.mark.parametrize("case", CASES_EXT, ids=lambda c: f"{c['op']}-{c['args'][0].get('s')!r}-{len(c['args'])}")
+def test_reference_tables_ext_on_gpu(case, keys):
+    ck, sk = keys
+    assert run_api_ext(ck, sk, case) == case["expect"], case

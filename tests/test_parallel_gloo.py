@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: two gloo ranks shard the positions of find_all, all-gather found[], and run
+the replicated reduction.  The executor here is the oracle (test infrastructure); on the GPU the
+same ShardedSearch runs over DeviceExecutor + RCCL.  Results must be bit-identical to the
+unsharded programs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fhe_string_amd.parallel import ShardedSearch, shard_range
+from tests.helpers import World
+from tests.progs import Prog, decode_result, num_blocks_usize, string_blocks
+
+
+class OracleExecutor:
+    def __init__(self, w):
+        self.w = w
+
+    def run(self, op, shape, bu, input_cts):
+        p = Prog(self.w.p, op, shape, bu)
+        outs, _ = p.run_oracle(self.w, input_cts, threads=2)
+        return outs
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world_size, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        w = World("toy", 255, 0xF4E50000)            # same seeds on every rank: identical keys / inputs
+        bu = num_blocks_usize(255)
+        text, pat, miss = "abcabcxabc", "cx", "zz"
+        a = w.encrypt(string_blocks(text, 12))
+        b = w.encrypt(string_blocks(pat))
+        m = w.encrypt(string_blocks(miss))
+        ss = ShardedSearch(OracleExecutor(w), bu, dist)
+        found = ss.find_all(a, b)
+        res_find = ss.find(a, b)
+        res_contains = ss.contains(a, b)
+        res_miss = ss.contains(a, m)
+        # unsharded references
+        ref_found, _ = Prog(w.p, "find_all_range", [13, 3, 0, 12], bu).run_oracle(w, np.concatenate([a, b]))
+        ref_find, _ = Prog(w.p, "find", [13, 3], bu).run_oracle(w, np.concatenate([a, b]))
+        q.put((rank, bool(np.array_equal(found, ref_found)), bool(np.array_equal(res_find, ref_find)),
+               decode_result("find", w.decrypt(res_find), bu), bool(w.decrypt(res_contains)[0] & 1),
+               bool(w.decrypt(res_miss)[0] & 1)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 64, 1024):
+        for ws in (1, 2, 3, 8):
+            parts = [shard_range(n, ws, r) for r in range(ws)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(ws - 1))
+            assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+
+
+def test_sharded_search_two_gloo_ranks(libs):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, found_ok, find_ok, find_val, contains, miss in results:
+        assert found_ok, f"rank {rank}: gathered found[] differs from the unsharded find_all"
+        assert find_ok, f"rank {rank}: sharded find differs from the unsharded program"
+        assert find_val == "abcabcxabc".find("cx") == 5
+        assert contains is True and miss is False
