@@ -223,11 +223,32 @@ static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+template <int MINW>
+static int launch_br_v4(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  constexpr int N = 2048, M = N / 2;
+  const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
+  auto kern = dev::blind_rotate_v4_kernel<11, 23, MINW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 2), lds, ctx->stream, d, ctx->arena,
+                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e4,
+                     ctx->lut_polys, ctx->twist, ctx->tw);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
 // variant: 0 = auto (latency kernel for launches that fit one workgroup per CU, throughput
 // kernel otherwise), 1 / 2 / 3 = force
 static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
   int variant = ctx->br_variant;
   if (variant == 0) variant = d.v_count <= ctx->n_cus + ctx->n_cus / 4 ? 2 : 3;
+  if (variant >= 4 && ctx->dims.N != 2048) variant = 3;
+  if (variant == 4) return launch_br_v4<4>(ctx, d);
+  if (variant == 5) return launch_br_v4<2>(ctx, d);
   if (ctx->dims.N == 2048)
     return variant == 1 ? launch_br_v1<11>(ctx, d) : variant == 2 ? launch_br_v2<11>(ctx, d) : launch_br_v3<11>(ctx, d);
   return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 2 ? launch_br_v2<8>(ctx, d) : launch_br_v3<8>(ctx, d);
@@ -414,7 +435,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
+  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e); (void)hipFree(ctx->bsk_e4);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->lut_polys);
   (void)hipFree(ctx->ks_out); (void)hipFree(ctx->desc_buf);
   for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
@@ -456,6 +477,11 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
     else
       hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<8>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e);
     FHES_HIP(hipGetLastError());
+    if (d.N == 2048) {
+      if (!ctx->bsk_e4) FHES_HIP(hipMalloc(&ctx->bsk_e4, npoly * d.M * 16));
+      hipLaunchKernelGGL((dev::bsk_to_engine4_layout_kernel<11>), dim3(npoly), dim3(d.M / 4), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e4);
+      FHES_HIP(hipGetLastError());
+    }
     FHES_HIP(hipStreamSynchronize(ctx->stream));
     FHES_HIP(hipFree(tmp));
   }
@@ -570,7 +596,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  if (v < 0 || v > 3) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
+  if (v < 0 || v > 5) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
   ctx->br_variant = v;
   return FHES_OK;
 }

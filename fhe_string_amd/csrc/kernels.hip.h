@@ -848,6 +848,255 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   if (tid == 0) out[N] = acc[N];
 }
 
+// ------------------------------------------------------------------------------------------
+// K2+K3 (variant 4): 4 points per thread, 2 * M/4 threads per ciphertext (N = 2048: 512 threads,
+// 8 waves).  Same arithmetic as variants 1-3 (same bits).  Half the per-thread state of the
+// 8-point variants -> <= 128 registers, so two workgroups (16 waves) share a CU and every SIMD
+// has 4 waves to interleave.  Passes own 2 index bits: {9,8} {7,6} {5,4} {3,2} through LDS,
+// bits 1 and 0 are lane bits and run on DPP quad permutes (their twiddles are 1 and -i).
+// LDS: acc u64[2][N] | fbuf double2[2][M] | a_tilde u16
+// ------------------------------------------------------------------------------------------
+template <int LOGM, int LO>
+__device__ __forceinline__ int fft_point4(int q, int e) {  // 2-bit pass, e = 0..3, no group bits
+  return ((q >> LO) << (LO + 2)) | (e << LO) | (q & ((1 << LO) - 1));
+}
+__device__ __forceinline__ int fswz4(int p) {  // conflict-free for all four 2-bit pass layouts
+  const int h = (p >> 4) & 3;
+  return p ^ (h << 2) ^ ((h & 1) << 3);
+}
+__device__ __forceinline__ double dpp_swap2(double v) {  // value of lane ^ 2
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <int LOGM, int LO>
+__device__ __forceinline__ void load_pass_twiddles4(double2 (&w)[3], int q, const double2 *__restrict__ tw) {
+  // stage on bit LO+1: butterflies e = 0,1 -> w[0], w[1];  stage on bit LO: e = 0 (and 2) -> w[2]
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int fb = k < 2 ? 1 : 0, e = k < 2 ? k : 0;
+    const int beta = LO + fb, sh = LOGM - 1 - beta;
+    const int p = fft_point4<LOGM, LO>(q, e);
+    w[k] = tw[(p & ((1 << beta) - 1)) << sh];
+  }
+}
+
+template <bool FWD>
+__device__ __forceinline__ void fft_butterflies4(double2 (&x)[4], const double2 (&w)[3]) {
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int fb = FWD ? (1 - st) : st;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e & (1 << fb)) continue;
+      const int e1 = e | (1 << fb);
+      const double2 tw = fb == 1 ? w[e & 1] : w[2];
+      const double2 u = x[e], v = x[e1];
+      if (FWD) {
+        const double2 d = make_double2(u.x - v.x, u.y - v.y);
+        x[e] = make_double2(u.x + v.x, u.y + v.y);
+        x[e1] = cmul(d, tw);
+      } else {
+        const double2 vv = cmul_conj(v, tw);
+        x[e] = make_double2(u.x + vv.x, u.y + vv.y);
+        x[e1] = make_double2(u.x - vv.x, u.y - vv.y);
+      }
+    }
+  }
+}
+
+// forward (DIF) stages on index bits 1 and 0 = lane bits 1 and 0.
+//   bit 1: pair (L, L^2), twiddle = 1 when lane bit 0 is clear, -i when it is set
+//   bit 0: pair (L, L^1), twiddle = 1
+// s1 / s0 = -1.0 on lanes whose bit 1 / bit 0 is set, else +1.0;  rot = lane bits 1 and 0 both set
+__device__ __forceinline__ void fft_quad_stages_fwd(double2 (&x)[4], double s1, double s0, bool rot) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    double re = __builtin_fma(x[e].x, s1, dpp_swap2(x[e].x));  // u + v  |  u - v
+    double im = __builtin_fma(x[e].y, s1, dpp_swap2(x[e].y));
+    const double r2 = rot ? im : re;   // (u - v) * (-i) = (im, -re)
+    const double i2 = rot ? -re : im;
+    x[e].x = __builtin_fma(r2, s0, dpp_swap1(r2));
+    x[e].y = __builtin_fma(i2, s0, dpp_swap1(i2));
+  }
+}
+// inverse (DIT): bit 0 first (twiddle 1), then bit 1 with conj twiddle (+i on the rot lanes)
+__device__ __forceinline__ void fft_quad_stages_inv(double2 (&x)[4], double s1, double s0, bool rot) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double re = __builtin_fma(x[e].x, s0, dpp_swap1(x[e].x));
+    const double im = __builtin_fma(x[e].y, s0, dpp_swap1(x[e].y));
+    const double r2 = rot ? -im : re;  // v * conj(-i) = v * i = (-im, re)
+    const double i2 = rot ? re : im;
+    x[e].x = __builtin_fma(r2, s1, dpp_swap2(r2));
+    x[e].y = __builtin_fma(i2, s1, dpp_swap2(i2));
+  }
+}
+
+template <int LOGN, int BL, int MINW>
+__global__ __launch_bounds__(512, MINW) void blind_rotate_v4_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
+    int ks_stride, int n_small, const double2 *__restrict__ bsk_e4 /* [i][row][col][4][M/4] */,
+    const uint64_t *__restrict__ lut_polys, const double2 *__restrict__ twist,
+    const double2 *__restrict__ tw) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 4;
+  static_assert(LOGM == 10, "variant 4 is written for N = 2048");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N]
+  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][M]
+  uint16_t *at = reinterpret_cast<uint16_t *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16);
+
+  const int tid = threadIdx.x;
+  const int r = tid / TP;
+  const int q = tid % TP;
+  const double s0 = (q & 1) ? -1.0 : 1.0, s1 = (q & 2) ? -1.0 : 1.0;
+  const bool rot = (q & 3) == 3;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  for (int j = tid; j <= n_small; j += blockDim.x)
+    at[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  __syncthreads();
+
+  constexpr int LO_A = 8, LO_B = 6, LO_C = 4, LO_D = 2;
+  double2 wA[3], wB[3], wC[3], wD[3];
+  load_pass_twiddles4<LOGM, LO_A>(wA, q, tw);
+  load_pass_twiddles4<LOGM, LO_B>(wB, q, tw);
+  load_pass_twiddles4<LOGM, LO_C>(wC, q, tw);
+  load_pass_twiddles4<LOGM, LO_D>(wD, q, tw);
+  const double2 *twist_q = twist + q;  // twist[fft_point4<LOGM, LO_A>(q, e)] = twist_q[e * TP]
+
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = q + e * TP;
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      acc[(size_t)r * N + p] = v0;
+      acc[(size_t)r * N + p + M] = v1;
+    }
+  }
+  __syncthreads();
+
+  uint64_t *acc_r = acc + (size_t)r * N;
+  double2 *buf_r = fbuf + (size_t)r * M;
+  const double2 *buf_o = fbuf + (size_t)(1 - r) * M;
+  const double scale = 1.0 / (double)M;
+
+  for (int i = 0; i < n_small; ++i) {
+    const int a = (int)at[i];
+    if (a == 0) continue;
+
+    double2 g0[4], g1[4];
+    {
+      const double2 *G = bsk_e4 + (size_t)i * 4 * M;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        g0[e] = G[((size_t)(0 * 2 + r) * 4 + e) * TP + q];
+        g1[e] = G[((size_t)(1 * 2 + r) * 4 + e) * TP + q];
+      }
+    }
+    double2 x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = q + e * TP;
+      const uint64_t d0 = rot_read<N>(acc_r, a, p) - acc_r[p];
+      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - acc_r[p + M];
+      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twist_q[e * TP]);
+    }
+
+    // ---- forward FFT: A | B | C | D through LDS, bits 1,0 on DPP ----
+    fft_butterflies4<true>(x, wA);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_A>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_B>(q, e))];
+    fft_butterflies4<true>(x, wB);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_B>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_C>(q, e))];
+    fft_butterflies4<true>(x, wC);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_C>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_D>(q, e))];
+    fft_butterflies4<true>(x, wD);
+    fft_quad_stages_fwd(x, s1, s0, rot);
+
+    // ---- exchange spectra between the halves ([e][q] order), external product ----
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) buf_r[(size_t)e * TP + q] = x[e];
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = ext_mac(x[e], buf_o[(size_t)e * TP + q], g0[e], g1[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = ext_mac(buf_o[(size_t)e * TP + q], x[e], g0[e], g1[e]);
+    }
+    __syncthreads();
+
+    // ---- inverse FFT ----
+    fft_quad_stages_inv(x, s1, s0, rot);
+    fft_butterflies4<false>(x, wD);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_D>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_C>(q, e))];
+    fft_butterflies4<false>(x, wC);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_C>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_B>(q, e))];
+    fft_butterflies4<false>(x, wB);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_B>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_A>(q, e))];
+    fft_butterflies4<false>(x, wA);
+
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = q + e * TP;
+      const double2 v = cmul_conj(x[e], twist_q[e * TP]);
+      acc_r[p] += torus_from_f64_scaled(v.x, scale);
+      acc_r[p + M] += torus_from_f64_scaled(v.y, scale);
+    }
+    __syncthreads();
+  }
+
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
+  if (tid == 0) out[N] = acc[N];
+}
+
+// engine layout for variant 4: [poly][e(4)][q(M/4)], point p = fft_point4<LOGM, 2>(q, e)
+template <int LOGN>
+__global__ void bsk_to_engine4_layout_kernel(const double2 *__restrict__ canon, double2 *__restrict__ out) {
+  constexpr int M = (1 << LOGN) / 2, LOGM = LOGN - 1, TP = M / 4;
+  const int q = threadIdx.x;
+  const double2 *src = canon + (size_t)blockIdx.x * M;
+  double2 *dst = out + (size_t)blockIdx.x * M;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dst[(size_t)e * TP + q] = src[fft_point4<LOGM, 2>(q, e)];
+}
+
 // engine layout of the Fourier BSK for variant 2: [poly][e][q] with the point
 // p = fft_point<LOGM, LO_last3, 3>(q, e) of the last 3-bit pass (the layout the spectrum
 // is in when the external product runs).  grid = polynomials, block = M/8.

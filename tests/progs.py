@@ -170,7 +170,7 @@ def decode_result(op, outs, bu, s=None):
     decrypt would give (FheOption::decrypt mod.rs:378-386, FheStringSliceVector::decrypt
     split.rs:208-226)."""
     outs = [int(v) for v in outs]
-    if op in ("find", "rfind"):
+    if op in ("find", "rfind", "find_logdepth"):
         return radix_value(outs[1:1 + bu]) if outs[0] & 1 else None
     if op == "len":
         return radix_value(outs[:bu])

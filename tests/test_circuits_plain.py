@@ -194,3 +194,16 @@ def test_replace_and_split_variants_against_python(libs):
         m = "".join(rnd.choice("aBcD zZ@[`{") for _ in range(rnd.randint(0, 6)))
         assert run_ext("to_lowercase", [S(m)])[0] == m.lower(), (m,)
         assert run_ext("to_uppercase", [S(m)])[0] == m.upper(), (m,)
+
+
+def test_logdepth_find_equals_faithful_find(libs):
+    rnd = random.Random(5)
+    for trial in range(40):
+        la, lb = rnd.randint(0, 12), rnd.randint(0, 3)
+        a = "".join(rnd.choice("ab") for _ in range(la))
+        b = "".join(rnd.choice("ab") for _ in range(lb))
+        a_pad = rnd.choice([None, la + rnd.randint(0, 3)])
+        assert run_plain("find_logdepth", a, a_pad, b, None)[0] == run_plain("find", a, a_pad, b, None)[0], (a, b)
+    _, p_fast = run_plain("find_logdepth", "x" * 64, None, "xxxx", None)
+    _, p_ref = run_plain("find", "x" * 64, None, "xxxx", None)
+    assert p_fast.n_levels < 20 < p_ref.n_levels

@@ -124,3 +124,42 @@ def test_pbs_linear_combination_inputs(w):
     check(w.lib.fhes_arena_download(ctx, h + 2 * n, n, ptr(res)))
     assert np.array_equal(w.decrypt(res), (4 * xs + ys + 1).astype(np.uint8))
     check(w.lib.fhes_arena_free(ctx, h, 3 * n))
+
+
+def test_all_blind_rotate_variants_agree(libs):
+    """every kernel variant produces the oracle's bits (real parameters)"""
+    w = world("default")
+    ctx = w.ctx()
+    count = 40
+    rng = np.random.default_rng(3)
+    vals = rng.integers(0, 16, size=count).astype(np.uint8)
+    cts = w.encrypt(vals)
+    t, poly = w.lut_poly(lambda x: (5 * x + 3) % 16)
+    lid = check(w.lib.fhes_lut_register(ctx, ptr(t), 16))
+    h_in = check(w.lib.fhes_arena_alloc(ctx, count))
+    h_out = check(w.lib.fhes_arena_alloc(ctx, count))
+    check(w.lib.fhes_arena_upload(ctx, h_in, count, ptr(cts)))
+    term_ptr = np.arange(count + 1, dtype=np.int32)
+    term_idx = np.arange(h_in, h_in + count, dtype=np.int32)
+    term_coef = np.ones(count, dtype=np.int64)
+    consts = np.zeros(count, dtype=np.uint64)
+    lut_ids = np.full(count, lid, dtype=np.int32)
+    outs = np.arange(h_out, h_out + count, dtype=np.int32)
+    ref = np.stack([w.oracle_pbs(cts[i], poly) for i in range(4)])
+    try:
+        for variant in (1, 2, 3, 4):
+            check(w.lib.fhes_set_kernel_variant(ctx, variant))
+            check(w.lib.fhes_pbs_batch(ctx, count, ptr(term_ptr), ptr(term_idx), ptr(term_coef), ptr(consts),
+                                       ptr(lut_ids), ptr(outs)))
+            res = np.zeros((count, w.W), dtype=np.uint64)
+            check(w.lib.fhes_arena_download(ctx, h_out, count, ptr(res)))
+            assert np.array_equal(res[:4], ref), f"variant {variant} differs from the oracle"
+            assert list(w.decrypt(res)) == [(5 * int(v) + 3) % 16 for v in vals], f"variant {variant}"
+            if variant == 1:
+                first = res
+            else:
+                assert np.array_equal(res, first), f"variant {variant} differs from variant 1"
+    finally:
+        check(w.lib.fhes_set_kernel_variant(ctx, 0))
+    check(w.lib.fhes_arena_free(ctx, h_in, count))
+    check(w.lib.fhes_arena_free(ctx, h_out, count))
