@@ -33,6 +33,7 @@ struct fhes_ctx {
   double2 *bsk_f = nullptr;  // canonical [n][2][2][M]
   double2 *bsk_e = nullptr;  // engine layout for blind-rotate variants 2/3: [n][2][2][8][M/8]
   double2 *bsk_e4 = nullptr; // engine layout for variant 4: [n][2][2][4][M/4]
+  double2 *bsk_e6 = nullptr; // engine layout for variant 6: [n][2][2][16][64]
   double2 *twist = nullptr, *tw = nullptr;
 
   // LUT registry

@@ -241,14 +241,32 @@ static int launch_br_v4(fhes_ctx *ctx, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+static int launch_br_v6(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  constexpr int M = 1024;
+  const size_t lds = (size_t)8 * dev::V6_WBUF * 16 + (size_t)15 * 64 * 16 + (size_t)15 * 4 * 16 + (size_t)4 * ctx->ks_stride * 2;
+  auto kern = dev::blind_rotate_v6_kernel<23>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((d.v_count + 3) / 4), dim3(512), lds, ctx->stream, d, ctx->arena,
+                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e6,
+                     ctx->lut_polys, ctx->twist, ctx->tw);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
 // variant: 0 = auto (latency kernel for launches that fit one workgroup per CU, throughput
 // kernel otherwise), 1 / 2 / 3 = force
 static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
   int variant = ctx->br_variant;
   if (variant == 0) variant = d.v_count <= ctx->n_cus + ctx->n_cus / 4 ? 2 : 3;
-  if (variant >= 4 && ctx->dims.N != 2048) variant = 3;
+  if (variant >= 4 && (ctx->dims.N != 2048 || ctx->dims.n + 1 > 768)) variant = 3;
   if (variant == 4) return launch_br_v4<4>(ctx, d);
   if (variant == 5) return launch_br_v4<2>(ctx, d);
+  if (variant == 6) return launch_br_v6(ctx, d);
   if (ctx->dims.N == 2048)
     return variant == 1 ? launch_br_v1<11>(ctx, d) : variant == 2 ? launch_br_v2<11>(ctx, d) : launch_br_v3<11>(ctx, d);
   return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 2 ? launch_br_v2<8>(ctx, d) : launch_br_v3<8>(ctx, d);
@@ -435,7 +453,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e); (void)hipFree(ctx->bsk_e4);
+  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e); (void)hipFree(ctx->bsk_e4); (void)hipFree(ctx->bsk_e6);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->lut_polys);
   (void)hipFree(ctx->ks_out); (void)hipFree(ctx->desc_buf);
   for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
@@ -480,6 +498,9 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
     if (d.N == 2048) {
       if (!ctx->bsk_e4) FHES_HIP(hipMalloc(&ctx->bsk_e4, npoly * d.M * 16));
       hipLaunchKernelGGL((dev::bsk_to_engine4_layout_kernel<11>), dim3(npoly), dim3(d.M / 4), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e4);
+      FHES_HIP(hipGetLastError());
+      if (!ctx->bsk_e6) FHES_HIP(hipMalloc(&ctx->bsk_e6, npoly * d.M * 16));
+      hipLaunchKernelGGL(dev::bsk_to_engine6_layout_kernel, dim3(npoly), dim3(64), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e6);
       FHES_HIP(hipGetLastError());
     }
     FHES_HIP(hipStreamSynchronize(ctx->stream));
@@ -596,7 +617,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  if (v < 0 || v > 5) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
+  if (v < 0 || v > 6) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
   ctx->br_variant = v;
   return FHES_OK;
 }

@@ -1097,6 +1097,296 @@ __global__ void bsk_to_engine4_layout_kernel(const double2 *__restrict__ canon, 
   for (int e = 0; e < 4; ++e) dst[(size_t)e * TP + q] = src[fft_point4<LOGM, 2>(q, e)];
 }
 
+// ------------------------------------------------------------------------------------------
+// K2+K3 (variant 6): one WAVE per polynomial, 16 points per lane, 4 ciphertexts per 512-thread
+// workgroup (wave w: ciphertext slot w>>1, polynomial w&1).  Same arithmetic, same bits.
+//   * the three FFT passes own index bits {9..6}, {5..2}, {1,0}; the two transposes between
+//     them go through a per-wave 16 KB LDS buffer and need NO barrier (a wave's LDS operations
+//     execute in order); the only workgroup barriers are the two around the spectrum exchange
+//     between the two polynomials of a ciphertext;
+//   * the accumulator lives in registers; the rotation X^a reads it back through the same
+//     per-wave buffer;
+//   * pass-A twiddles [15][64] and pass-B twiddles [15][4] are shared LDS tables;
+//   * no iteration is skipped (a == 0 is an exact no-op) so that all waves see the same barriers.
+// LDS: wbuf double2[8][1088] | twA double2[15][64] | twB double2[15][4] | a_tilde u16[4][ks_stride]
+// ------------------------------------------------------------------------------------------
+// additive skew (one 16-byte slot of padding per 16 points): every layout's address is
+// lane_base + constant(m), LB / LC accesses and all writes are conflict-free, LA reads 2-way
+__device__ __forceinline__ int swz6(int p) { return p + (p >> 4); }
+constexpr int V6_WBUF = 1088;  // double2 slots per wave buffer (1024 + 64 padding)
+
+template <bool FWD, int RB, typename TW>
+__device__ __forceinline__ void bfly16_stage(double2 (&x)[16], TW twof) {
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    if (m & (1 << RB)) continue;
+    const int m1 = m | (1 << RB);
+    const double2 w = twof(m);
+    const double2 u = x[m], v = x[m1];
+    if (FWD) {
+      const double2 dd = make_double2(u.x - v.x, u.y - v.y);
+      x[m] = make_double2(u.x + v.x, u.y + v.y);
+      x[m1] = cmul(dd, w);
+    } else {
+      const double2 vv = cmul_conj(v, w);
+      x[m] = make_double2(u.x + vv.x, u.y + vv.y);
+      x[m1] = make_double2(u.x - vv.x, u.y - vv.y);
+    }
+  }
+}
+
+// pass C: index bits 1 (twiddle 1 for even m, -i for odd m) and 0 (twiddle 1), register bits 1, 0
+template <bool FWD>
+__device__ __forceinline__ void bfly16_passC(double2 (&x)[16]) {
+  if (FWD) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      if (m & 2) continue;
+      const double2 u = x[m], v = x[m | 2];
+      const double2 dd = make_double2(u.x - v.x, u.y - v.y);
+      x[m] = make_double2(u.x + v.x, u.y + v.y);
+      x[m | 2] = (m & 1) ? make_double2(dd.y, -dd.x) : dd;  // * (-i)
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m += 2) {
+      const double2 u = x[m], v = x[m | 1];
+      x[m] = make_double2(u.x + v.x, u.y + v.y);
+      x[m | 1] = make_double2(u.x - v.x, u.y - v.y);
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; m += 2) {
+      const double2 u = x[m], v = x[m | 1];
+      x[m] = make_double2(u.x + v.x, u.y + v.y);
+      x[m | 1] = make_double2(u.x - v.x, u.y - v.y);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      if (m & 2) continue;
+      const double2 u = x[m], v = x[m | 2];
+      const double2 vv = (m & 1) ? make_double2(-v.y, v.x) : v;  // * conj(-i) = * i
+      x[m] = make_double2(u.x + vv.x, u.y + vv.y);
+      x[m | 2] = make_double2(u.x - vv.x, u.y - vv.y);
+    }
+  }
+}
+
+template <int BL>
+__global__ __launch_bounds__(512, 2) void blind_rotate_v6_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
+    int ks_stride, int n_small, const double2 *__restrict__ bsk_e6 /* [i][row][col][16][64] */,
+    const uint64_t *__restrict__ lut_polys, const double2 *__restrict__ twist,
+    const double2 *__restrict__ tw) {
+  constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double2 *wbuf_all = reinterpret_cast<double2 *>(smem_raw);                              // [8][M]
+  double2 *twA = reinterpret_cast<double2 *>(smem_raw + (size_t)8 * V6_WBUF * 16);         // [15][64]
+  double2 *twB = twA + 15 * 64;                                                            // [15][4]
+  uint16_t *at_all = reinterpret_cast<uint16_t *>(twB + 15 * 4);                           // [4][ks_stride]
+
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int c = w >> 1, r = w & 1;
+  const int lo2 = l & 3;
+  const int rel_raw = blockIdx.x * 4 + c;
+  const bool valid = rel_raw < d.v_count;
+  const int rel = valid ? rel_raw : d.v_count - 1;  // idle slots shadow the last ciphertext
+  const int vidx = d.v0 + rel;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+
+  // ---- tables and modulus switch ----
+  for (int k = w; k < 15; k += 8) {
+    int idx;
+    if (k < 8) idx = l + 64 * k;
+    else if (k < 12) idx = (l + 64 * (k - 8)) << 1;
+    else if (k < 14) idx = (l + 64 * (k - 12)) << 2;
+    else idx = l << 3;
+    twA[k * 64 + l] = tw[idx];
+  }
+  if (tid < 60) {
+    const int k = tid >> 2, q2 = tid & 3;
+    int idx;
+    if (k < 8) idx = ((k << 2) | q2) << 4;
+    else if (k < 12) idx = (((k - 8) << 2) | q2) << 5;
+    else if (k < 14) idx = (((k - 12) << 2) | q2) << 6;
+    else idx = q2 << 7;
+    twB[k * 4 + q2] = tw[idx];
+  }
+  {
+    uint16_t *at_c = at_all + (size_t)c * ks_stride;
+    const uint64_t *ks = ks_out + (size_t)rel * ks_stride;
+    for (int j = (r << 6) | l; j <= n_small; j += 128)
+      at_c[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  }
+  __syncthreads();
+  const uint16_t *at = at_all + (size_t)c * ks_stride;
+
+  double2 *wbuf = wbuf_all + (size_t)w * V6_WBUF;
+  const double2 *obuf = wbuf_all + (size_t)(w ^ 1) * V6_WBUF;
+  uint64_t *stage = reinterpret_cast<uint64_t *>(wbuf);  // u64[N] view of the same 16 KB
+  const double scale = 1.0 / (double)M;
+
+  // ---- acc = (0, X^{-b~} * LUT): coefficients p = l + 64 m and p + M of polynomial r ----
+  uint64_t acc_lo[16], acc_hi[16];
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int p = l + 64 * m;
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      acc_lo[m] = v0;
+      acc_hi[m] = v1;
+    }
+  }
+  const double2 *twist_l = twist + l;  // twist[l + 64 m] = twist_l[64 m]
+
+  for (int i = 0; i < n_small; ++i) {
+    const int a = (int)at[i];
+    const double2 *G = bsk_e6 + ((size_t)i * 4 + r) * M;  // row 0, column r; row 1 at + 2*M
+
+    // ---- rotation through the wave's buffer, digit, twist ----
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      stage[l + 64 * m] = acc_lo[m];
+      stage[l + 64 * m + M] = acc_hi[m];
+    }
+    double2 x[16];
+    if (a != 0) {
+#pragma unroll
+      for (int mg = 0; mg < 16; mg += 4) {
+        #pragma unroll
+        for (int m = mg; m < mg + 4; ++m) {
+          const int p = l + 64 * m;
+          const uint64_t d0 = rot_read<N>(stage, a, p) - acc_lo[m];
+          const uint64_t d1 = rot_read<N>(stage, a, p + M) - acc_hi[m];
+          x[m] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twist_l[64 * m]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x[m] = make_double2(0.0, 0.0);
+    }
+    
+    // ---- forward FFT ----
+    bfly16_stage<true, 3>(x, [&](int m) { return twA[(m & 7) * 64 + l]; });
+        bfly16_stage<true, 2>(x, [&](int m) { return twA[(8 + (m & 3)) * 64 + l]; });
+    bfly16_stage<true, 1>(x, [&](int m) { return twA[(12 + (m & 1)) * 64 + l]; });
+    bfly16_stage<true, 0>(x, [&](int) { return twA[14 * 64 + l]; });
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wbuf[swz6(l + 64 * m)] = x[m];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = wbuf[swz6(((l >> 2) << 6) | (m << 2) | lo2)];
+    bfly16_stage<true, 3>(x, [&](int m) { return twB[(m & 7) * 4 + lo2]; });
+    bfly16_stage<true, 2>(x, [&](int m) { return twB[(8 + (m & 3)) * 4 + lo2]; });
+    bfly16_stage<true, 1>(x, [&](int m) { return twB[(12 + (m & 1)) * 4 + lo2]; });
+    bfly16_stage<true, 0>(x, [&](int) { return twB[14 * 4 + lo2]; });
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wbuf[swz6(((l >> 2) << 6) | (m << 2) | lo2)] = x[m];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = wbuf[swz6((l << 4) | m)];
+    bfly16_passC<true>(x);
+
+    // ---- spectrum exchange between the two waves of this ciphertext, external product ----
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wbuf[m * 64 + l] = x[m];
+    // GGSW column r, software-pipelined in groups of 4 points (2 groups in flight)
+    double2 ga0[4], ga1[4], gb0[4], gb1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      ga0[m] = G[(size_t)m * 64 + l];
+      ga1[m] = G[(size_t)2 * M + (size_t)m * 64 + l];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mg = 0; mg < 16; mg += 8) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        gb0[m] = G[(size_t)(mg + 4 + m) * 64 + l];
+        gb1[m] = G[(size_t)2 * M + (size_t)(mg + 4 + m) * 64 + l];
+      }
+      #pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double2 other = obuf[(mg + m) * 64 + l];
+        x[mg + m] = r == 0 ? ext_mac(x[mg + m], other, ga0[m], ga1[m]) : ext_mac(other, x[mg + m], ga0[m], ga1[m]);
+      }
+            if (mg == 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          ga0[m] = G[(size_t)(8 + m) * 64 + l];
+          ga1[m] = G[(size_t)2 * M + (size_t)(8 + m) * 64 + l];
+        }
+      }
+      #pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double2 other = obuf[(mg + 4 + m) * 64 + l];
+        x[mg + 4 + m] = r == 0 ? ext_mac(x[mg + 4 + m], other, gb0[m], gb1[m]) : ext_mac(other, x[mg + 4 + m], gb0[m], gb1[m]);
+      }
+          }
+    __syncthreads();  // the partner wave has read my spectrum: my buffer may be reused
+
+    // ---- inverse FFT ----
+    bfly16_passC<false>(x);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wbuf[swz6((l << 4) | m)] = x[m];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = wbuf[swz6(((l >> 2) << 6) | (m << 2) | lo2)];
+    bfly16_stage<false, 0>(x, [&](int) { return twB[14 * 4 + lo2]; });
+    bfly16_stage<false, 1>(x, [&](int m) { return twB[(12 + (m & 1)) * 4 + lo2]; });
+    bfly16_stage<false, 2>(x, [&](int m) { return twB[(8 + (m & 3)) * 4 + lo2]; });
+    bfly16_stage<false, 3>(x, [&](int m) { return twB[(m & 7) * 4 + lo2]; });
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wbuf[swz6(((l >> 2) << 6) | (m << 2) | lo2)] = x[m];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = wbuf[swz6(l + 64 * m)];
+    bfly16_stage<false, 0>(x, [&](int) { return twA[14 * 64 + l]; });
+    bfly16_stage<false, 1>(x, [&](int m) { return twA[(12 + (m & 1)) * 64 + l]; });
+    bfly16_stage<false, 2>(x, [&](int m) { return twA[(8 + (m & 3)) * 64 + l]; });
+    bfly16_stage<false, 3>(x, [&](int m) { return twA[(m & 7) * 64 + l]; });
+
+    // ---- untwist, round to the torus, accumulate in registers ----
+#pragma unroll
+    for (int mg = 0; mg < 16; mg += 4) {
+      #pragma unroll
+      for (int m = mg; m < mg + 4; ++m) {
+        const double2 v = cmul_conj(x[m], twist_l[64 * m]);
+        acc_lo[m] += torus_from_f64_scaled(v.x, scale);
+        acc_hi[m] += torus_from_f64_scaled(v.y, scale);
+      }
+    }
+      }
+
+  // ---- sample extract ----
+  if (valid) {
+    uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+    if (r == 0) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int p = l + 64 * m;
+        if (p == 0) out[0] = acc_lo[m];
+        else out[N - p] = (uint64_t)0 - acc_lo[m];
+        out[N - p - M] = (uint64_t)0 - acc_hi[m];
+      }
+    } else if (l == 0) {
+      out[N] = acc_lo[0];
+    }
+  }
+}
+
+// engine layout for variant 6: [poly][m(16)][l(64)], point p = 16 l + m
+__global__ void bsk_to_engine6_layout_kernel(const double2 *__restrict__ canon, double2 *__restrict__ out) {
+  constexpr int M = 1024;
+  const int l = threadIdx.x;
+  const double2 *src = canon + (size_t)blockIdx.x * M;
+  double2 *dst = out + (size_t)blockIdx.x * M;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) dst[m * 64 + l] = src[(l << 4) | m];
+}
+
 // engine layout of the Fourier BSK for variant 2: [poly][e][q] with the point
 // p = fft_point<LOGM, LO_last3, 3>(q, e) of the last 3-bit pass (the layout the spectrum
 // is in when the external product runs).  grid = polynomials, block = M/8.
