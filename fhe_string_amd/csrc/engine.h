@@ -29,11 +29,10 @@ struct fhes_ctx {
   // keys
   bool keys_loaded = false;
   uint64_t *ksk = nullptr;   // [big][ks_level][ks_stride]
+  uint64_t *ksk_bias = nullptr;  // [ks_stride]: (B/2) * sum_{i,l} ksk[i][l][j]  (biased-digit keyswitch)
   int ks_stride = 0;
   double2 *bsk_f = nullptr;  // canonical [n][2][2][M]
   double2 *bsk_e = nullptr;  // engine layout for blind-rotate variants 2/3: [n][2][2][8][M/8]
-  double2 *bsk_e4 = nullptr; // engine layout for variant 4: [n][2][2][4][M/4]
-  double2 *bsk_e6 = nullptr; // engine layout for variant 6: [n][2][2][16][64]
   double2 *twist = nullptr, *tw = nullptr;
 
   // LUT registry

@@ -155,7 +155,7 @@ static int launch_keyswitch(fhes_ctx *ctx, const dev::NodeDesc &d) {
   const int jpt = ctx->ks_stride / 256;
 #define KS_LAUNCH(J)                                                                              \
   hipLaunchKernelGGL((dev::keyswitch_kernel<J>), grid, block, 0, ctx->stream, d, ctx->arena,     \
-                     ctx->ct_stride, dm.big, ctx->ksk, dm.ks_level, dm.ks_base_log,              \
+                     ctx->ct_stride, dm.big, ctx->ksk, ctx->ksk_bias, dm.ks_level, dm.ks_base_log, \
                      ctx->ks_stride, dm.n, cps, ctx->ks_out)
   switch (jpt) {
     case 1: KS_LAUNCH(1); break;
@@ -223,50 +223,11 @@ static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
-template <int MINW>
-static int launch_br_v4(fhes_ctx *ctx, const dev::NodeDesc &d) {
-  constexpr int N = 2048, M = N / 2;
-  const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_v4_kernel<11, 23, MINW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 2), lds, ctx->stream, d, ctx->arena,
-                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e4,
-                     ctx->lut_polys, ctx->twist, ctx->tw);
-  FHES_HIP(hipGetLastError());
-  return FHES_OK;
-}
-
-static int launch_br_v6(fhes_ctx *ctx, const dev::NodeDesc &d) {
-  constexpr int M = 1024;
-  const size_t lds = (size_t)8 * dev::V6_WBUF * 16 + (size_t)15 * 64 * 16 + (size_t)15 * 4 * 16 + (size_t)4 * ctx->ks_stride * 2;
-  auto kern = dev::blind_rotate_v6_kernel<23>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((d.v_count + 3) / 4), dim3(512), lds, ctx->stream, d, ctx->arena,
-                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e6,
-                     ctx->lut_polys, ctx->twist, ctx->tw);
-  FHES_HIP(hipGetLastError());
-  return FHES_OK;
-}
-
 // variant: 0 = auto (latency kernel for launches that fit one workgroup per CU, throughput
 // kernel otherwise), 1 / 2 / 3 = force
 static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
   int variant = ctx->br_variant;
   if (variant == 0) variant = d.v_count <= ctx->n_cus + ctx->n_cus / 4 ? 2 : 3;
-  if (variant >= 4 && (ctx->dims.N != 2048 || ctx->dims.n + 1 > 768)) variant = 3;
-  if (variant == 4) return launch_br_v4<4>(ctx, d);
-  if (variant == 5) return launch_br_v4<2>(ctx, d);
-  if (variant == 6) return launch_br_v6(ctx, d);
   if (ctx->dims.N == 2048)
     return variant == 1 ? launch_br_v1<11>(ctx, d) : variant == 2 ? launch_br_v2<11>(ctx, d) : launch_br_v3<11>(ctx, d);
   return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 2 ? launch_br_v2<8>(ctx, d) : launch_br_v3<8>(ctx, d);
@@ -453,7 +414,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e); (void)hipFree(ctx->bsk_e4); (void)hipFree(ctx->bsk_e6);
+  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->lut_polys);
   (void)hipFree(ctx->ks_out); (void)hipFree(ctx->desc_buf);
   for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
@@ -475,6 +436,13 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
       memcpy(&padded[r * ctx->ks_stride], ksk + r * (d.n + 1), sizeof(uint64_t) * (d.n + 1));
     if (!ctx->ksk) FHES_HIP(hipMalloc(&ctx->ksk, padded.size() * 8));
     FHES_HIP(hipMemcpy(ctx->ksk, padded.data(), padded.size() * 8, hipMemcpyHostToDevice));
+    std::vector<uint64_t> bias(ctx->ks_stride, 0);
+    for (size_t r = 0; r < rows; r++)
+      for (int j = 0; j <= d.n; j++) bias[j] += padded[r * ctx->ks_stride + j];
+    const uint64_t half_base = 1ull << (d.ks_base_log - 1);
+    for (auto &v : bias) v *= half_base;
+    if (!ctx->ksk_bias) FHES_HIP(hipMalloc(&ctx->ksk_bias, bias.size() * 8));
+    FHES_HIP(hipMemcpy(ctx->ksk_bias, bias.data(), bias.size() * 8, hipMemcpyHostToDevice));
   }
   // bootstrapping key -> Fourier domain on the device
   {
@@ -495,14 +463,6 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
     else
       hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<8>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e);
     FHES_HIP(hipGetLastError());
-    if (d.N == 2048) {
-      if (!ctx->bsk_e4) FHES_HIP(hipMalloc(&ctx->bsk_e4, npoly * d.M * 16));
-      hipLaunchKernelGGL((dev::bsk_to_engine4_layout_kernel<11>), dim3(npoly), dim3(d.M / 4), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e4);
-      FHES_HIP(hipGetLastError());
-      if (!ctx->bsk_e6) FHES_HIP(hipMalloc(&ctx->bsk_e6, npoly * d.M * 16));
-      hipLaunchKernelGGL(dev::bsk_to_engine6_layout_kernel, dim3(npoly), dim3(64), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e6);
-      FHES_HIP(hipGetLastError());
-    }
     FHES_HIP(hipStreamSynchronize(ctx->stream));
     FHES_HIP(hipFree(tmp));
   }
@@ -617,7 +577,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  if (v < 0 || v > 6) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
+  if (v < 0 || v > 3) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
   ctx->br_variant = v;
   return FHES_OK;
 }

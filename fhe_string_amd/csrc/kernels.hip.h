@@ -234,10 +234,13 @@ template <int JPT>
 __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64_t *__restrict__ arena,
                                                         int ct_stride, int big,
                                                         const uint64_t *__restrict__ ksk,
+                                                        const uint64_t *__restrict__ ksk_bias,
                                                         int ks_level, int ks_base_log, int ks_stride,
                                                         int n_small, int coeffs_per_split,
                                                         uint64_t *__restrict__ ks_out) {
-  __shared__ __attribute__((aligned(8))) int8_t dig[KS_IC][KS_MAXLV][KS_TB];
+  // digits are staged biased: u = d + B/2 in [0, B), so that the product u * K needs no sign
+  // handling; sum_{i,l} (B/2) * K[i][l][j] is the precomputed `ksk_bias[j]` (added once).
+  __shared__ __attribute__((aligned(8))) uint8_t dig[KS_IC][KS_MAXLV][KS_TB];
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
   const int i_begin = blockIdx.y * coeffs_per_split;
@@ -247,11 +250,13 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
   const int total = ks_level * ks_base_log;
   const int B = 1 << ks_base_log;
 
-  uint64_t acc[KS_TB][JPT];
+  // sum u*K split into a 64-bit sum of u*K_lo and a 32-bit sum of u*K_hi (mod 2^32)
+  uint64_t acc_lo[KS_TB][JPT];
+  uint32_t acc_hi[KS_TB][JPT];
 #pragma unroll
   for (int b = 0; b < KS_TB; ++b)
 #pragma unroll
-    for (int q = 0; q < JPT; ++q) acc[b][q] = 0;
+    for (int q = 0; q < JPT; ++q) { acc_lo[b][q] = 0; acc_hi[b][q] = 0; }
 
   for (int chunk = i_begin; chunk < i_end; chunk += KS_IC) {
     // stage the digits of KS_TB x KS_IC mask coefficients
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
         int dd = (int)(v & (uint32_t)(B - 1));
         v >>= ks_base_log;
         if (dd >= B / 2) { dd -= B; v += 1; }
-        dig[ii][l][b] = (int8_t)dd;
+        dig[ii][l][b] = (uint8_t)(dd + B / 2);
       }
     }
     __syncthreads();
@@ -284,9 +289,12 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
         const uint64_t packed = *reinterpret_cast<const uint64_t *>(&dig[ii][l][0]);
 #pragma unroll
         for (int b = 0; b < KS_TB; ++b) {
-          const int64_t dd = (int64_t)(int8_t)(packed >> (8 * b));
+          const uint32_t u = (uint32_t)(packed >> (8 * b)) & 0xFFu;
 #pragma unroll
-          for (int q = 0; q < JPT; ++q) acc[b][q] -= (uint64_t)dd * kv[q];
+          for (int q = 0; q < JPT; ++q) {
+            acc_lo[b][q] += (uint64_t)u * (uint32_t)kv[q];          // v_mad_u64_u32
+            acc_hi[b][q] += u * (uint32_t)(kv[q] >> 32);            // v_mul_lo_u32 + v_add
+          }
         }
       }
     }
@@ -302,16 +310,19 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
 #pragma unroll
     for (int q = 0; q < JPT; ++q) {
       const int j = tid + 256 * q;
-      uint64_t v = acc[b][q];
-      if (j == n_small && blockIdx.y == 0) {  // body of the input combination
-        uint64_t body = d.consts[node];
-        for (int t = d.term_ptr[node]; t < d.term_ptr[node + 1]; ++t) {
-          const uint64_t *src = arena + (size_t)resolve(d, inst, d.term_idx[t]) * ct_stride;
-          body += (uint64_t)d.term_coef[t] * src[big];
+      uint64_t val = (uint64_t)0 - (acc_lo[b][q] + ((uint64_t)acc_hi[b][q] << 32));  // - sum u*K
+      if (blockIdx.y == 0 && j <= n_small) {
+        val += ksk_bias[j];  // + (B/2) * sum K
+        if (j == n_small) {  // body of the input combination
+          uint64_t body = d.consts[node];
+          for (int t = d.term_ptr[node]; t < d.term_ptr[node + 1]; ++t) {
+            const uint64_t *src = arena + (size_t)resolve(d, inst, d.term_idx[t]) * ct_stride;
+            body += (uint64_t)d.term_coef[t] * src[big];
+          }
+          val += body;
         }
-        v += body;
       }
-      if (j <= n_small && v != 0) atomicAdd(reinterpret_cast<unsigned long long *>(dst + j), (unsigned long long)v);
+      if (j <= n_small && val != 0) atomicAdd(reinterpret_cast<unsigned long long *>(dst + j), (unsigned long long)val);
     }
   }
 }
@@ -846,545 +857,6 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
   for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
   if (tid == 0) out[N] = acc[N];
-}
-
-// ------------------------------------------------------------------------------------------
-// K2+K3 (variant 4): 4 points per thread, 2 * M/4 threads per ciphertext (N = 2048: 512 threads,
-// 8 waves).  Same arithmetic as variants 1-3 (same bits).  Half the per-thread state of the
-// 8-point variants -> <= 128 registers, so two workgroups (16 waves) share a CU and every SIMD
-// has 4 waves to interleave.  Passes own 2 index bits: {9,8} {7,6} {5,4} {3,2} through LDS,
-// bits 1 and 0 are lane bits and run on DPP quad permutes (their twiddles are 1 and -i).
-// LDS: acc u64[2][N] | fbuf double2[2][M] | a_tilde u16
-// ------------------------------------------------------------------------------------------
-template <int LOGM, int LO>
-__device__ __forceinline__ int fft_point4(int q, int e) {  // 2-bit pass, e = 0..3, no group bits
-  return ((q >> LO) << (LO + 2)) | (e << LO) | (q & ((1 << LO) - 1));
-}
-__device__ __forceinline__ int fswz4(int p) {  // conflict-free for all four 2-bit pass layouts
-  const int h = (p >> 4) & 3;
-  return p ^ (h << 2) ^ ((h & 1) << 3);
-}
-__device__ __forceinline__ double dpp_swap2(double v) {  // value of lane ^ 2
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-  hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-
-template <int LOGM, int LO>
-__device__ __forceinline__ void load_pass_twiddles4(double2 (&w)[3], int q, const double2 *__restrict__ tw) {
-  // stage on bit LO+1: butterflies e = 0,1 -> w[0], w[1];  stage on bit LO: e = 0 (and 2) -> w[2]
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int fb = k < 2 ? 1 : 0, e = k < 2 ? k : 0;
-    const int beta = LO + fb, sh = LOGM - 1 - beta;
-    const int p = fft_point4<LOGM, LO>(q, e);
-    w[k] = tw[(p & ((1 << beta) - 1)) << sh];
-  }
-}
-
-template <bool FWD>
-__device__ __forceinline__ void fft_butterflies4(double2 (&x)[4], const double2 (&w)[3]) {
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const int fb = FWD ? (1 - st) : st;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (e & (1 << fb)) continue;
-      const int e1 = e | (1 << fb);
-      const double2 tw = fb == 1 ? w[e & 1] : w[2];
-      const double2 u = x[e], v = x[e1];
-      if (FWD) {
-        const double2 d = make_double2(u.x - v.x, u.y - v.y);
-        x[e] = make_double2(u.x + v.x, u.y + v.y);
-        x[e1] = cmul(d, tw);
-      } else {
-        const double2 vv = cmul_conj(v, tw);
-        x[e] = make_double2(u.x + vv.x, u.y + vv.y);
-        x[e1] = make_double2(u.x - vv.x, u.y - vv.y);
-      }
-    }
-  }
-}
-
-// forward (DIF) stages on index bits 1 and 0 = lane bits 1 and 0.
-//   bit 1: pair (L, L^2), twiddle = 1 when lane bit 0 is clear, -i when it is set
-//   bit 0: pair (L, L^1), twiddle = 1
-// s1 / s0 = -1.0 on lanes whose bit 1 / bit 0 is set, else +1.0;  rot = lane bits 1 and 0 both set
-__device__ __forceinline__ void fft_quad_stages_fwd(double2 (&x)[4], double s1, double s0, bool rot) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    double re = __builtin_fma(x[e].x, s1, dpp_swap2(x[e].x));  // u + v  |  u - v
-    double im = __builtin_fma(x[e].y, s1, dpp_swap2(x[e].y));
-    const double r2 = rot ? im : re;   // (u - v) * (-i) = (im, -re)
-    const double i2 = rot ? -re : im;
-    x[e].x = __builtin_fma(r2, s0, dpp_swap1(r2));
-    x[e].y = __builtin_fma(i2, s0, dpp_swap1(i2));
-  }
-}
-// inverse (DIT): bit 0 first (twiddle 1), then bit 1 with conj twiddle (+i on the rot lanes)
-__device__ __forceinline__ void fft_quad_stages_inv(double2 (&x)[4], double s1, double s0, bool rot) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const double re = __builtin_fma(x[e].x, s0, dpp_swap1(x[e].x));
-    const double im = __builtin_fma(x[e].y, s0, dpp_swap1(x[e].y));
-    const double r2 = rot ? -im : re;  // v * conj(-i) = v * i = (-im, re)
-    const double i2 = rot ? re : im;
-    x[e].x = __builtin_fma(r2, s1, dpp_swap2(r2));
-    x[e].y = __builtin_fma(i2, s1, dpp_swap2(i2));
-  }
-}
-
-template <int LOGN, int BL, int MINW>
-__global__ __launch_bounds__(512, MINW) void blind_rotate_v4_kernel(
-    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
-    int ks_stride, int n_small, const double2 *__restrict__ bsk_e4 /* [i][row][col][4][M/4] */,
-    const uint64_t *__restrict__ lut_polys, const double2 *__restrict__ twist,
-    const double2 *__restrict__ tw) {
-  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 4;
-  static_assert(LOGM == 10, "variant 4 is written for N = 2048");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N]
-  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][M]
-  uint16_t *at = reinterpret_cast<uint16_t *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16);
-
-  const int tid = threadIdx.x;
-  const int r = tid / TP;
-  const int q = tid % TP;
-  const double s0 = (q & 1) ? -1.0 : 1.0, s1 = (q & 2) ? -1.0 : 1.0;
-  const bool rot = (q & 3) == 3;
-  const int vidx = d.v0 + blockIdx.x;
-  const int inst = vidx / d.count, node = d.first + vidx % d.count;
-
-  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
-  for (int j = tid; j <= n_small; j += blockDim.x)
-    at[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
-  __syncthreads();
-
-  constexpr int LO_A = 8, LO_B = 6, LO_C = 4, LO_D = 2;
-  double2 wA[3], wB[3], wC[3], wD[3];
-  load_pass_twiddles4<LOGM, LO_A>(wA, q, tw);
-  load_pass_twiddles4<LOGM, LO_B>(wB, q, tw);
-  load_pass_twiddles4<LOGM, LO_C>(wC, q, tw);
-  load_pass_twiddles4<LOGM, LO_D>(wD, q, tw);
-  const double2 *twist_q = twist + q;  // twist[fft_point4<LOGM, LO_A>(q, e)] = twist_q[e * TP]
-
-  {
-    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
-    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int p = q + e * TP;
-      uint64_t v0 = 0, v1 = 0;
-      if (r == 1) {
-        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
-        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
-      }
-      acc[(size_t)r * N + p] = v0;
-      acc[(size_t)r * N + p + M] = v1;
-    }
-  }
-  __syncthreads();
-
-  uint64_t *acc_r = acc + (size_t)r * N;
-  double2 *buf_r = fbuf + (size_t)r * M;
-  const double2 *buf_o = fbuf + (size_t)(1 - r) * M;
-  const double scale = 1.0 / (double)M;
-
-  for (int i = 0; i < n_small; ++i) {
-    const int a = (int)at[i];
-    if (a == 0) continue;
-
-    double2 g0[4], g1[4];
-    {
-      const double2 *G = bsk_e4 + (size_t)i * 4 * M;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        g0[e] = G[((size_t)(0 * 2 + r) * 4 + e) * TP + q];
-        g1[e] = G[((size_t)(1 * 2 + r) * 4 + e) * TP + q];
-      }
-    }
-    double2 x[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int p = q + e * TP;
-      const uint64_t d0 = rot_read<N>(acc_r, a, p) - acc_r[p];
-      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - acc_r[p + M];
-      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twist_q[e * TP]);
-    }
-
-    // ---- forward FFT: A | B | C | D through LDS, bits 1,0 on DPP ----
-    fft_butterflies4<true>(x, wA);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_A>(q, e))] = x[e];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_B>(q, e))];
-    fft_butterflies4<true>(x, wB);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_B>(q, e))] = x[e];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_C>(q, e))];
-    fft_butterflies4<true>(x, wC);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_C>(q, e))] = x[e];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_D>(q, e))];
-    fft_butterflies4<true>(x, wD);
-    fft_quad_stages_fwd(x, s1, s0, rot);
-
-    // ---- exchange spectra between the halves ([e][q] order), external product ----
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) buf_r[(size_t)e * TP + q] = x[e];
-    __syncthreads();
-    if (r == 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = ext_mac(x[e], buf_o[(size_t)e * TP + q], g0[e], g1[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = ext_mac(buf_o[(size_t)e * TP + q], x[e], g0[e], g1[e]);
-    }
-    __syncthreads();
-
-    // ---- inverse FFT ----
-    fft_quad_stages_inv(x, s1, s0, rot);
-    fft_butterflies4<false>(x, wD);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_D>(q, e))] = x[e];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_C>(q, e))];
-    fft_butterflies4<false>(x, wC);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_C>(q, e))] = x[e];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_B>(q, e))];
-    fft_butterflies4<false>(x, wB);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) buf_r[fswz4(fft_point4<LOGM, LO_B>(q, e))] = x[e];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = buf_r[fswz4(fft_point4<LOGM, LO_A>(q, e))];
-    fft_butterflies4<false>(x, wA);
-
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int p = q + e * TP;
-      const double2 v = cmul_conj(x[e], twist_q[e * TP]);
-      acc_r[p] += torus_from_f64_scaled(v.x, scale);
-      acc_r[p + M] += torus_from_f64_scaled(v.y, scale);
-    }
-    __syncthreads();
-  }
-
-  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
-  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
-  if (tid == 0) out[N] = acc[N];
-}
-
-// engine layout for variant 4: [poly][e(4)][q(M/4)], point p = fft_point4<LOGM, 2>(q, e)
-template <int LOGN>
-__global__ void bsk_to_engine4_layout_kernel(const double2 *__restrict__ canon, double2 *__restrict__ out) {
-  constexpr int M = (1 << LOGN) / 2, LOGM = LOGN - 1, TP = M / 4;
-  const int q = threadIdx.x;
-  const double2 *src = canon + (size_t)blockIdx.x * M;
-  double2 *dst = out + (size_t)blockIdx.x * M;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) dst[(size_t)e * TP + q] = src[fft_point4<LOGM, 2>(q, e)];
-}
-
-// ------------------------------------------------------------------------------------------
-// K2+K3 (variant 6): one WAVE per polynomial, 16 points per lane, 4 ciphertexts per 512-thread
-// workgroup (wave w: ciphertext slot w>>1, polynomial w&1).  Same arithmetic, same bits.
-//   * the three FFT passes own index bits {9..6}, {5..2}, {1,0}; the two transposes between
-//     them go through a per-wave 16 KB LDS buffer and need NO barrier (a wave's LDS operations
-//     execute in order); the only workgroup barriers are the two around the spectrum exchange
-//     between the two polynomials of a ciphertext;
-//   * the accumulator lives in registers; the rotation X^a reads it back through the same
-//     per-wave buffer;
-//   * pass-A twiddles [15][64] and pass-B twiddles [15][4] are shared LDS tables;
-//   * no iteration is skipped (a == 0 is an exact no-op) so that all waves see the same barriers.
-// LDS: wbuf double2[8][1088] | twA double2[15][64] | twB double2[15][4] | a_tilde u16[4][ks_stride]
-// ------------------------------------------------------------------------------------------
-// additive skew (one 16-byte slot of padding per 16 points): every layout's address is
-// lane_base + constant(m), LB / LC accesses and all writes are conflict-free, LA reads 2-way
-__device__ __forceinline__ int swz6(int p) { return p + (p >> 4); }
-constexpr int V6_WBUF = 1088;  // double2 slots per wave buffer (1024 + 64 padding)
-
-template <bool FWD, int RB, typename TW>
-__device__ __forceinline__ void bfly16_stage(double2 (&x)[16], TW twof) {
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    if (m & (1 << RB)) continue;
-    const int m1 = m | (1 << RB);
-    const double2 w = twof(m);
-    const double2 u = x[m], v = x[m1];
-    if (FWD) {
-      const double2 dd = make_double2(u.x - v.x, u.y - v.y);
-      x[m] = make_double2(u.x + v.x, u.y + v.y);
-      x[m1] = cmul(dd, w);
-    } else {
-      const double2 vv = cmul_conj(v, w);
-      x[m] = make_double2(u.x + vv.x, u.y + vv.y);
-      x[m1] = make_double2(u.x - vv.x, u.y - vv.y);
-    }
-  }
-}
-
-// pass C: index bits 1 (twiddle 1 for even m, -i for odd m) and 0 (twiddle 1), register bits 1, 0
-template <bool FWD>
-__device__ __forceinline__ void bfly16_passC(double2 (&x)[16]) {
-  if (FWD) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      if (m & 2) continue;
-      const double2 u = x[m], v = x[m | 2];
-      const double2 dd = make_double2(u.x - v.x, u.y - v.y);
-      x[m] = make_double2(u.x + v.x, u.y + v.y);
-      x[m | 2] = (m & 1) ? make_double2(dd.y, -dd.x) : dd;  // * (-i)
-    }
-#pragma unroll
-    for (int m = 0; m < 16; m += 2) {
-      const double2 u = x[m], v = x[m | 1];
-      x[m] = make_double2(u.x + v.x, u.y + v.y);
-      x[m | 1] = make_double2(u.x - v.x, u.y - v.y);
-    }
-  } else {
-#pragma unroll
-    for (int m = 0; m < 16; m += 2) {
-      const double2 u = x[m], v = x[m | 1];
-      x[m] = make_double2(u.x + v.x, u.y + v.y);
-      x[m | 1] = make_double2(u.x - v.x, u.y - v.y);
-    }
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      if (m & 2) continue;
-      const double2 u = x[m], v = x[m | 2];
-      const double2 vv = (m & 1) ? make_double2(-v.y, v.x) : v;  // * conj(-i) = * i
-      x[m] = make_double2(u.x + vv.x, u.y + vv.y);
-      x[m | 2] = make_double2(u.x - vv.x, u.y - vv.y);
-    }
-  }
-}
-
-template <int BL>
-__global__ __launch_bounds__(512, 2) void blind_rotate_v6_kernel(
-    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
-    int ks_stride, int n_small, const double2 *__restrict__ bsk_e6 /* [i][row][col][16][64] */,
-    const uint64_t *__restrict__ lut_polys, const double2 *__restrict__ twist,
-    const double2 *__restrict__ tw) {
-  constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double2 *wbuf_all = reinterpret_cast<double2 *>(smem_raw);                              // [8][M]
-  double2 *twA = reinterpret_cast<double2 *>(smem_raw + (size_t)8 * V6_WBUF * 16);         // [15][64]
-  double2 *twB = twA + 15 * 64;                                                            // [15][4]
-  uint16_t *at_all = reinterpret_cast<uint16_t *>(twB + 15 * 4);                           // [4][ks_stride]
-
-  const int tid = threadIdx.x;
-  const int w = tid >> 6, l = tid & 63;
-  const int c = w >> 1, r = w & 1;
-  const int lo2 = l & 3;
-  const int rel_raw = blockIdx.x * 4 + c;
-  const bool valid = rel_raw < d.v_count;
-  const int rel = valid ? rel_raw : d.v_count - 1;  // idle slots shadow the last ciphertext
-  const int vidx = d.v0 + rel;
-  const int inst = vidx / d.count, node = d.first + vidx % d.count;
-
-  // ---- tables and modulus switch ----
-  for (int k = w; k < 15; k += 8) {
-    int idx;
-    if (k < 8) idx = l + 64 * k;
-    else if (k < 12) idx = (l + 64 * (k - 8)) << 1;
-    else if (k < 14) idx = (l + 64 * (k - 12)) << 2;
-    else idx = l << 3;
-    twA[k * 64 + l] = tw[idx];
-  }
-  if (tid < 60) {
-    const int k = tid >> 2, q2 = tid & 3;
-    int idx;
-    if (k < 8) idx = ((k << 2) | q2) << 4;
-    else if (k < 12) idx = (((k - 8) << 2) | q2) << 5;
-    else if (k < 14) idx = (((k - 12) << 2) | q2) << 6;
-    else idx = q2 << 7;
-    twB[k * 4 + q2] = tw[idx];
-  }
-  {
-    uint16_t *at_c = at_all + (size_t)c * ks_stride;
-    const uint64_t *ks = ks_out + (size_t)rel * ks_stride;
-    for (int j = (r << 6) | l; j <= n_small; j += 128)
-      at_c[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
-  }
-  __syncthreads();
-  const uint16_t *at = at_all + (size_t)c * ks_stride;
-
-  double2 *wbuf = wbuf_all + (size_t)w * V6_WBUF;
-  const double2 *obuf = wbuf_all + (size_t)(w ^ 1) * V6_WBUF;
-  uint64_t *stage = reinterpret_cast<uint64_t *>(wbuf);  // u64[N] view of the same 16 KB
-  const double scale = 1.0 / (double)M;
-
-  // ---- acc = (0, X^{-b~} * LUT): coefficients p = l + 64 m and p + M of polynomial r ----
-  uint64_t acc_lo[16], acc_hi[16];
-  {
-    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
-    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const int p = l + 64 * m;
-      uint64_t v0 = 0, v1 = 0;
-      if (r == 1) {
-        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
-        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
-      }
-      acc_lo[m] = v0;
-      acc_hi[m] = v1;
-    }
-  }
-  const double2 *twist_l = twist + l;  // twist[l + 64 m] = twist_l[64 m]
-
-  for (int i = 0; i < n_small; ++i) {
-    const int a = (int)at[i];
-    const double2 *G = bsk_e6 + ((size_t)i * 4 + r) * M;  // row 0, column r; row 1 at + 2*M
-
-    // ---- rotation through the wave's buffer, digit, twist ----
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      stage[l + 64 * m] = acc_lo[m];
-      stage[l + 64 * m + M] = acc_hi[m];
-    }
-    double2 x[16];
-    if (a != 0) {
-#pragma unroll
-      for (int mg = 0; mg < 16; mg += 4) {
-        #pragma unroll
-        for (int m = mg; m < mg + 4; ++m) {
-          const int p = l + 64 * m;
-          const uint64_t d0 = rot_read<N>(stage, a, p) - acc_lo[m];
-          const uint64_t d1 = rot_read<N>(stage, a, p + M) - acc_hi[m];
-          x[m] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twist_l[64 * m]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int m = 0; m < 16; ++m) x[m] = make_double2(0.0, 0.0);
-    }
-    
-    // ---- forward FFT ----
-    bfly16_stage<true, 3>(x, [&](int m) { return twA[(m & 7) * 64 + l]; });
-        bfly16_stage<true, 2>(x, [&](int m) { return twA[(8 + (m & 3)) * 64 + l]; });
-    bfly16_stage<true, 1>(x, [&](int m) { return twA[(12 + (m & 1)) * 64 + l]; });
-    bfly16_stage<true, 0>(x, [&](int) { return twA[14 * 64 + l]; });
-#pragma unroll
-    for (int m = 0; m < 16; ++m) wbuf[swz6(l + 64 * m)] = x[m];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) x[m] = wbuf[swz6(((l >> 2) << 6) | (m << 2) | lo2)];
-    bfly16_stage<true, 3>(x, [&](int m) { return twB[(m & 7) * 4 + lo2]; });
-    bfly16_stage<true, 2>(x, [&](int m) { return twB[(8 + (m & 3)) * 4 + lo2]; });
-    bfly16_stage<true, 1>(x, [&](int m) { return twB[(12 + (m & 1)) * 4 + lo2]; });
-    bfly16_stage<true, 0>(x, [&](int) { return twB[14 * 4 + lo2]; });
-#pragma unroll
-    for (int m = 0; m < 16; ++m) wbuf[swz6(((l >> 2) << 6) | (m << 2) | lo2)] = x[m];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) x[m] = wbuf[swz6((l << 4) | m)];
-    bfly16_passC<true>(x);
-
-    // ---- spectrum exchange between the two waves of this ciphertext, external product ----
-#pragma unroll
-    for (int m = 0; m < 16; ++m) wbuf[m * 64 + l] = x[m];
-    // GGSW column r, software-pipelined in groups of 4 points (2 groups in flight)
-    double2 ga0[4], ga1[4], gb0[4], gb1[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      ga0[m] = G[(size_t)m * 64 + l];
-      ga1[m] = G[(size_t)2 * M + (size_t)m * 64 + l];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mg = 0; mg < 16; mg += 8) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        gb0[m] = G[(size_t)(mg + 4 + m) * 64 + l];
-        gb1[m] = G[(size_t)2 * M + (size_t)(mg + 4 + m) * 64 + l];
-      }
-      #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const double2 other = obuf[(mg + m) * 64 + l];
-        x[mg + m] = r == 0 ? ext_mac(x[mg + m], other, ga0[m], ga1[m]) : ext_mac(other, x[mg + m], ga0[m], ga1[m]);
-      }
-            if (mg == 0) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          ga0[m] = G[(size_t)(8 + m) * 64 + l];
-          ga1[m] = G[(size_t)2 * M + (size_t)(8 + m) * 64 + l];
-        }
-      }
-      #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const double2 other = obuf[(mg + 4 + m) * 64 + l];
-        x[mg + 4 + m] = r == 0 ? ext_mac(x[mg + 4 + m], other, gb0[m], gb1[m]) : ext_mac(other, x[mg + 4 + m], gb0[m], gb1[m]);
-      }
-          }
-    __syncthreads();  // the partner wave has read my spectrum: my buffer may be reused
-
-    // ---- inverse FFT ----
-    bfly16_passC<false>(x);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) wbuf[swz6((l << 4) | m)] = x[m];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) x[m] = wbuf[swz6(((l >> 2) << 6) | (m << 2) | lo2)];
-    bfly16_stage<false, 0>(x, [&](int) { return twB[14 * 4 + lo2]; });
-    bfly16_stage<false, 1>(x, [&](int m) { return twB[(12 + (m & 1)) * 4 + lo2]; });
-    bfly16_stage<false, 2>(x, [&](int m) { return twB[(8 + (m & 3)) * 4 + lo2]; });
-    bfly16_stage<false, 3>(x, [&](int m) { return twB[(m & 7) * 4 + lo2]; });
-#pragma unroll
-    for (int m = 0; m < 16; ++m) wbuf[swz6(((l >> 2) << 6) | (m << 2) | lo2)] = x[m];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) x[m] = wbuf[swz6(l + 64 * m)];
-    bfly16_stage<false, 0>(x, [&](int) { return twA[14 * 64 + l]; });
-    bfly16_stage<false, 1>(x, [&](int m) { return twA[(12 + (m & 1)) * 64 + l]; });
-    bfly16_stage<false, 2>(x, [&](int m) { return twA[(8 + (m & 3)) * 64 + l]; });
-    bfly16_stage<false, 3>(x, [&](int m) { return twA[(m & 7) * 64 + l]; });
-
-    // ---- untwist, round to the torus, accumulate in registers ----
-#pragma unroll
-    for (int mg = 0; mg < 16; mg += 4) {
-      #pragma unroll
-      for (int m = mg; m < mg + 4; ++m) {
-        const double2 v = cmul_conj(x[m], twist_l[64 * m]);
-        acc_lo[m] += torus_from_f64_scaled(v.x, scale);
-        acc_hi[m] += torus_from_f64_scaled(v.y, scale);
-      }
-    }
-      }
-
-  // ---- sample extract ----
-  if (valid) {
-    uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
-    if (r == 0) {
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const int p = l + 64 * m;
-        if (p == 0) out[0] = acc_lo[m];
-        else out[N - p] = (uint64_t)0 - acc_lo[m];
-        out[N - p - M] = (uint64_t)0 - acc_hi[m];
-      }
-    } else if (l == 0) {
-      out[N] = acc_lo[0];
-    }
-  }
-}
-
-// engine layout for variant 6: [poly][m(16)][l(64)], point p = 16 l + m
-__global__ void bsk_to_engine6_layout_kernel(const double2 *__restrict__ canon, double2 *__restrict__ out) {
-  constexpr int M = 1024;
-  const int l = threadIdx.x;
-  const double2 *src = canon + (size_t)blockIdx.x * M;
-  double2 *dst = out + (size_t)blockIdx.x * M;
-#pragma unroll
-  for (int m = 0; m < 16; ++m) dst[m * 64 + l] = src[(l << 4) | m];
 }
 
 // engine layout of the Fourier BSK for variant 2: [poly][e][q] with the point
