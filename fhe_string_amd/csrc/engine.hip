@@ -208,7 +208,7 @@ static int launch_br_v2(fhes_ctx *ctx, const dev::NodeDesc &d) {
 template <int LOGN>
 static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
-  const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
+  const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)(M / 2) * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
   auto kern = dev::blind_rotate_v3_kernel<LOGN, 23>;
   static bool attr_set = false;
   if (!attr_set) {

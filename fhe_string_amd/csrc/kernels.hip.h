@@ -701,7 +701,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
 //   * the 1/M scale is folded into the rounding FMAs (exact: power of two).
 // (A first version kept the twiddle table in LDS: strided ds_read_b128 gave 1.1 G bank-conflict
 //  cycles per launch and the LDS pipe was 55 % busy -- twiddles stay in registers.)
-// LDS: acc u64[2][N] | fbuf double2[2][M] | a_tilde u16
+// LDS: acc u64[2][N] | fbuf double2[2][M] | stage twiddle tables double2[M/2] | a_tilde u16
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t torus_from_f64_scaled(double v, double s) {
   // rint(v * s) mod 2^64 with s a power of two; same value as torus_from_f64_fast(v * s)
@@ -717,6 +717,37 @@ __device__ __forceinline__ uint64_t torus_from_f64_scaled(double v, double s) {
   return ((uint64_t)(hi32 + mhi) << 32) | (uint64_t)lo;
 }
 
+// butterflies of a 3-bit pass with twiddles from the per-stage LDS tables
+//   T[2^beta + j] = tw[j << (LOGM-1-beta)],  j < 2^beta,  beta = 1 .. LOGM-2
+// (consecutive or broadcast addresses -> conflict-free); the top stage (beta = LOGM-1) of the
+// first pass takes its 4 twiddles from registers.
+template <int LOGM, bool FWD, int LO>
+__device__ __forceinline__ void fft_butterflies_tab(double2 (&x)[8], int q, const double2 *T, const double2 (&wtop)[4]) {
+#pragma unroll
+  for (int st = 0; st < 3; ++st) {
+    const int fb = FWD ? (2 - st) : st;
+    const int beta = LO + fb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e & (1 << fb)) continue;
+      const int e1 = e | (1 << fb);
+      double2 w;
+      if (beta == LOGM - 1) w = wtop[e & 3];
+      else w = T[(1 << beta) + (fft_point<LOGM, LO, 3>(q, e) & ((1 << beta) - 1))];
+      const double2 u = x[e], v = x[e1];
+      if (FWD) {
+        const double2 dd = make_double2(u.x - v.x, u.y - v.y);
+        x[e] = make_double2(u.x + v.x, u.y + v.y);
+        x[e1] = cmul(dd, w);
+      } else {
+        const double2 vv = cmul_conj(v, w);
+        x[e] = make_double2(u.x + vv.x, u.y + vv.y);
+        x[e1] = make_double2(u.x - vv.x, u.y - vv.y);
+      }
+    }
+  }
+}
+
 template <int LOGN, int BL>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v3_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
@@ -728,7 +759,8 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N]
   double2 *fbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][M]
-  uint16_t *at = reinterpret_cast<uint16_t *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16);
+  double2 *T = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16);  // [M/2] stage tables
+  uint16_t *at = reinterpret_cast<uint16_t *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)(M / 2) * 16);
 
   const int tid = threadIdx.x;
   const int r = tid / TP;
@@ -740,13 +772,16 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
   for (int j = tid; j <= n_small; j += blockDim.x)
     at[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  for (int idx = 2 + tid; idx < M / 2; idx += blockDim.x) {
+    const int beta = 31 - __builtin_clz(idx);  // idx = 2^beta + j
+    T[idx] = tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
+  }
   __syncthreads();
 
   constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
-  double2 wA[7], wB[7], wC[7];
-  load_pass_twiddles<LOGM, LO_A>(wA, q, tw);
-  load_pass_twiddles<LOGM, LO_B>(wB, q, tw);
-  if (NP == 3) load_pass_twiddles<LOGM, LO_C>(wC, q, tw);
+  double2 wtop[4];  // stage LOGM-1 of pass A: tw[q + TP * e], e = 0..3
+#pragma unroll
+  for (int e = 0; e < 4; ++e) wtop[e] = tw[fft_point<LOGM, LO_A, 3>(q, e) & (M / 2 - 1)];
   const double2 *twist_q = twist + q;  // twist[fft_point<LOGM, LO_A, 3>(q, e)] = twist_q[e * TP]
 
   {
@@ -795,13 +830,13 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     }
 
     // ---- forward FFT ----
-    fft_butterflies_reg<true>(x, wA);
+    fft_butterflies_tab<LOGM, true, LO_A>(x, q, T, wtop);
 #pragma unroll
     for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
-    fft_butterflies_reg<true>(x, wB);
+    fft_butterflies_tab<LOGM, true, LO_B>(x, q, T, wtop);
     if (NP == 3) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
@@ -809,7 +844,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
     }
-    if (NP == 3) fft_butterflies_reg<true>(x, wC);
+    if (NP == 3) fft_butterflies_tab<LOGM, true, LO_C>(x, q, T, wtop);
     fft_stage_bit0_dpp(x, sgn);
 
     // ---- exchange spectra through fbuf ([e][q] order), external product ----
@@ -829,20 +864,20 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     // ---- inverse FFT ----
     fft_stage_bit0_dpp(x, sgn);
     if (NP == 3) {
-      fft_butterflies_reg<false>(x, wC);
+      fft_butterflies_tab<LOGM, false, LO_C>(x, q, T, wtop);
 #pragma unroll
       for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
     }
-    fft_butterflies_reg<false>(x, wB);
+    fft_butterflies_tab<LOGM, false, LO_B>(x, q, T, wtop);
 #pragma unroll
     for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
-    fft_butterflies_reg<false>(x, wA);
+    fft_butterflies_tab<LOGM, false, LO_A>(x, q, T, wtop);
 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
