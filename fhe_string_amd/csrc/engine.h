@@ -34,6 +34,7 @@ struct fhes_ctx {
   double2 *bsk_f = nullptr;  // canonical [n][2][2][M]
   double2 *bsk_e = nullptr;  // engine layout for blind-rotate variants 2/3: [n][2][2][8][M/8]
   double2 *twist = nullptr, *tw = nullptr;
+  double2 *twist_inv = nullptr;  // twist * (2/N): untwist factors with the inverse-FFT scale folded in
 
   // LUT registry
   uint64_t *lut_polys = nullptr;  // [lut_capacity][N]

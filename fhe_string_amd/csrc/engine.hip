@@ -218,7 +218,7 @@ static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d) {
   }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
-                     ctx->lut_polys, ctx->twist, ctx->tw);
+                     ctx->lut_polys, ctx->twist, ctx->twist_inv, ctx->tw);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
@@ -400,6 +400,12 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   if ((e = hipMemcpy(ctx->twist, twist.data(), twist.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy twist");
   if ((e = hipMemcpy(ctx->tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy tw");
   {
+    std::vector<double> ti(twist);
+    for (auto &v : ti) v *= 1.0 / (double)d.M;  // power of two: exact
+    if ((e = hipMalloc(&ctx->twist_inv, ti.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(twist_inv)");
+    if ((e = hipMemcpy(ctx->twist_inv, ti.data(), ti.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy twist_inv");
+  }
+  {
     std::lock_guard<std::mutex> lk(g_live_mu);
     g_live.insert(ctx);
   }
@@ -415,7 +421,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
-  (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->lut_polys);
+  (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->lut_polys);
   (void)hipFree(ctx->ks_out); (void)hipFree(ctx->desc_buf);
   for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
   for (auto &ev : ctx->ev_free) (void)hipEventDestroy(ev);

@@ -698,25 +698,11 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
 // workgroup's barriers / LDS round trips are covered by the other's f64 work:
 //   * the thread's own accumulator coefficients are re-read from LDS (frees 32 registers);
 //   * the two halves exchange spectra through the FFT buffer (two extra barriers);
-//   * the 1/M scale is folded into the rounding FMAs (exact: power of two).
+//   * the 1/M scale is folded into a pre-scaled untwist table (exact: power of two).
 // (A first version kept the twiddle table in LDS: strided ds_read_b128 gave 1.1 G bank-conflict
 //  cycles per launch and the LDS pipe was 55 % busy -- twiddles stay in registers.)
 // LDS: acc u64[2][N] | fbuf double2[2][M] | stage twiddle tables double2[M/2] | a_tilde u16
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t torus_from_f64_scaled(double v, double s) {
-  // rint(v * s) mod 2^64 with s a power of two; same value as torus_from_f64_fast(v * s)
-  const double C0 = 0x1.8p116, C1 = 0x1.8p84, C2 = 0x1.8p52;
-  const double h0 = __builtin_fma(v, s, C0) - C0;
-  const double z = __builtin_fma(v, s, -h0);
-  const double t1 = z + C1;
-  const double rem = z - (t1 - C1);
-  const double t2 = rem + C2;
-  const uint32_t hi32 = (uint32_t)__double2loint(t1);
-  const uint32_t lo = (uint32_t)__double2loint(t2);
-  const uint32_t mhi = ((uint32_t)__double2hiint(t2) & 0xFFFFFu) - 0x80000u;
-  return ((uint64_t)(hi32 + mhi) << 32) | (uint64_t)lo;
-}
-
 // butterflies of a 3-bit pass with twiddles from the per-stage LDS tables
 //   T[2^beta + j] = tw[j << (LOGM-1-beta)],  j < 2^beta,  beta = 1 .. LOGM-2
 // (consecutive or broadcast addresses -> conflict-free); the top stage (beta = LOGM-1) of the
@@ -752,7 +738,8 @@ template <int LOGN, int BL>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v3_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
     int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
-    const double2 *__restrict__ twist, const double2 *__restrict__ tw) {
+    const double2 *__restrict__ twist, const double2 *__restrict__ twist_inv /* twist / M */,
+    const double2 *__restrict__ tw) {
   constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
   constexpr int NP = (LOGM - 1) / 3;
   static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
@@ -783,6 +770,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 #pragma unroll
   for (int e = 0; e < 4; ++e) wtop[e] = tw[fft_point<LOGM, LO_A, 3>(q, e) & (M / 2 - 1)];
   const double2 *twist_q = twist + q;  // twist[fft_point<LOGM, LO_A, 3>(q, e)] = twist_q[e * TP]
+  const double2 *twist_inv_q = twist_inv + q;  // same factors times 1/M (power of two: exact)
 
   {
     const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
@@ -804,7 +792,6 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   uint64_t *acc_r = acc + (size_t)r * N;
   double2 *buf_r = fbuf + (size_t)r * M;
   const double2 *buf_o = fbuf + (size_t)(1 - r) * M;
-  const double scale = 1.0 / (double)M;
 
   for (int i = 0; i < n_small; ++i) {
     const int a = (int)at[i];
@@ -882,9 +869,9 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      const double2 v = cmul_conj(x[e], twist_q[e * TP]);
-      acc_r[p] += torus_from_f64_scaled(v.x, scale);
-      acc_r[p + M] += torus_from_f64_scaled(v.y, scale);
+      const double2 v = cmul_conj(x[e], twist_inv_q[e * TP]);
+      acc_r[p] += torus_from_f64_fast(v.x);
+      acc_r[p + M] += torus_from_f64_fast(v.y);
     }
     __syncthreads();
   }
