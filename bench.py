@@ -5,7 +5,7 @@
   python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of `find` over one batch of B independent (input, pattern) pairs that are
-already resident in HBM (default B = 160: every one of the 69 dependent levels then fills the 256
+already resident in HBM (default B = 170: every one of the 69 dependent levels then fills the 256
 CUs several times over; `--batch 1` times a single find).  The single-find wall-clock is measured too (untimed region)
 and reported as `find_wall_ms_single`.  With N > 1 (launched by torch.distributed.run, one process
 per GPU) every rank runs the same workload on its own B strings: independent strings shard with no
@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="blind-rotate kernel variant (0 = auto)")
-    ap.add_argument("--batch", type=int, default=160, help="independent (input, pattern) pairs per step and rank")
+    ap.add_argument("--batch", type=int, default=170, help="independent (input, pattern) pairs per step and rank (9 * 170 = 1530 bootstraps fill 3 x 512 workgroup slots)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
