@@ -122,20 +122,29 @@ Blk Ops::any_true(std::vector<Blk> v) {
 // ---- comparisons -----------------------------------------------------------------------------
 Blk Ops::eq(const Radix &x, const Radix &y) {
   if (x.size() != y.size()) throw std::logic_error("eq: operand sizes differ");
+  // Pack block pairs (lo + M*hi, a 4-bit value) and look up [px - py == 0] on the signed
+  // difference: for a negative difference the negacyclic lookup returns -f(16 + d) = 0, so one
+  // bootstrap compares two blocks of each operand.
   std::vector<Blk> e;
-  for (size_t i = 0; i < x.size(); i++) {
-    if (same_value(x[i], y[i])) continue;
-    if (x[i].trivial() && y[i].trivial()) {
-      e.push_back(b.trivial(x[i].cst == y[i].cst));
-    } else if (y[i].trivial()) {
-      const uint64_t c = (uint64_t)y[i].cst;
-      e.push_back(b.pbs(x[i], [c](uint64_t v) { return v == c ? 1 : 0; }));
-    } else if (x[i].trivial()) {
-      const uint64_t c = (uint64_t)x[i].cst;
-      e.push_back(b.pbs(y[i], [c](uint64_t v) { return v == c ? 1 : 0; }));
+  for (size_t i = 0; i < x.size(); i += 2) {
+    const bool two = i + 1 < x.size();
+    const bool same = same_value(x[i], y[i]) && (!two || same_value(x[i + 1], y[i + 1]));
+    if (same) continue;
+    Radix xs(x.begin() + i, x.begin() + i + (two ? 2 : 1)), ys(y.begin() + i, y.begin() + i + (two ? 2 : 1));
+    Blk px = pack_pairs(xs)[0], py = pack_pairs(ys)[0];
+    if (px.trivial() && py.trivial()) {
+      e.push_back(b.trivial(px.cst == py.cst));
+    } else if (py.trivial()) {
+      const uint64_t c = (uint64_t)py.cst;
+      e.push_back(b.pbs(px, [c](uint64_t v) { return v == c ? 1 : 0; }));
+    } else if (px.trivial()) {
+      const uint64_t c = (uint64_t)px.cst;
+      e.push_back(b.pbs(py, [c](uint64_t v) { return v == c ? 1 : 0; }));
     } else {
-      e.push_back(b.bivar(x[i], y[i], b.params().message_bits,
-                          [](uint64_t p, uint64_t q) { return p == q ? 1 : 0; }));
+      if (px.noise + py.noise > Builder::kNoiseCap) throw std::logic_error("eq: operands too noisy");
+      Blk diff = b.sub_raw(px, py);
+      e.push_back(b.pbs(diff, [](uint64_t v) { return v == 0 ? 1 : 0; }, /*signed_input=*/true));
+      e.back().deg = 1;
     }
   }
   return all_true(e);
