@@ -60,7 +60,20 @@ bench_line = None
 p = os.path.join(src, "bench_line.json")
 if os.path.exists(p) and os.path.getsize(p):
     bench_line = json.loads(open(p).read().strip().splitlines()[-1])
+# cross-check with bench.py's own HIP-event timing: the profiled command runs 1 warm-up + `steps`
+# batched steps (plus a few single-find launches), bench.py reports launches * launch_ms for `steps`
+check = None
+if bench_line and "roofline" in bench_line:
+    rl = bench_line["roofline"]
+    steps = bench_line.get("steps", 1)
+    warm = bench_line.get("warmup", 0)
+    bench_total = rl["launches"] * rl["launch_ms"] * (steps + warm) / max(steps, 1)
+    prof_total = sum(v["total_ms"] for k, v in kern.items() if "blind_rotate_v3" in k)
+    check = {"bench_hip_event_total_ms_scaled_to_all_batched_runs": round(bench_total, 1),
+             "rocprof_blind_rotate_v3_total_ms": round(prof_total, 1),
+             "ratio": round(prof_total / bench_total, 4) if bench_total else None}
 out = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (under rocprofv3)",
+       "duration_cross_check": check,
        "kernels": kern, "bench_line_under_profiler": bench_line}
 json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 br = [k for k in kern if "blind_rotate" in k]
