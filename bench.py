@@ -76,11 +76,19 @@ def main():
 
     import torch
     dist = None
+    # FHES_BENCH_REHEARSAL=1: exercise the multi-process path on a box with ONE GPU (every rank
+    # uses device 0, gloo instead of RCCL).  Never set by the driver; numbers from it are not
+    # scaling results.
+    rehearsal = os.environ.get("FHES_BENCH_REHEARSAL") == "1"
+    device_index = 0 if rehearsal else local_rank
     if world_size > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if rehearsal:
+            dist_mod.init_process_group(backend="gloo")
+        else:
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         dist = dist_mod
 
     from fhe_string_amd import build
@@ -101,7 +109,7 @@ def main():
     bsk = np.zeros(lib.fhes_bsk_words(C.byref(params)), dtype=np.uint64)
     ksk = np.zeros(lib.fhes_ksk_words(C.byref(params)), dtype=np.uint64)
     check(lib.fhes_client_key_make_server_keys(ck, bsk.ctypes.data, ksk.ctypes.data))
-    ctx = check_ptr(lib.fhes_ctx_create(C.byref(params), local_rank))   # no CPU fallback
+    ctx = check_ptr(lib.fhes_ctx_create(C.byref(params), device_index))   # no CPU fallback
     check(lib.fhes_upload_keys(ctx, bsk.ctypes.data, ksk.ctypes.data))
     del bsk, ksk
     check(lib.fhes_set_kernel_variant(ctx, args.variant))
@@ -204,7 +212,7 @@ def main():
 
     dt_max = dt
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{device_index}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_max = float(t.item())
 
@@ -241,6 +249,7 @@ def main():
                        "strings_per_step_per_rank": B,
                        "parallelism": f"{world_size} rank(s) x {B} independent strings per step"},
             "result_ok": bool(ok),
+            **({"rehearsal": "all ranks on device 0 over gloo: not a scaling result"} if rehearsal else {}),
             "find_wall_ms_single": round(single_ms, 3),
             "pbs_per_s_single_find": round(pbs_per_find / (single_ms * 1e-3), 1),
             "find_wall_ms_single_logdepth": round(log_ms, 3),
