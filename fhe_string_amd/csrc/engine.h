@@ -16,6 +16,8 @@ struct fhes_ctx {
   fhes::Dims dims;
   int device = 0;
   int n_cus = 256;
+  uint64_t uid = 0;          // unique per context (program images are keyed by it, not by address)
+  unsigned attr_done = 0;    // bit v: max-dynamic-LDS attribute set for blind-rotate variant v on this device
   hipStream_t stream = nullptr;
   std::mutex mu;
 

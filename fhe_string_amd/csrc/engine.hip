@@ -174,11 +174,10 @@ static int launch_br_v1(fhes_ctx *ctx, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)((ctx->dims.n + 1 + 3) & ~3) * 4;
   auto kern = dev::blind_rotate_v1_kernel<LOGN, 23>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(ctx->attr_done & (1u << 1))) {  // per context: the attribute is per device
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    ctx->attr_done |= 1u << 1;
   }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_f,
@@ -192,11 +191,10 @@ static int launch_br_v2(fhes_ctx *ctx, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const size_t lds = (size_t)2 * N * 8 + (size_t)4 * M * 16 + (size_t)((ctx->dims.n + 1 + 3) & ~3) * 4;
   auto kern = dev::blind_rotate_v2_kernel<LOGN, 23>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(ctx->attr_done & (1u << 2))) {  // per context: the attribute is per device
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    ctx->attr_done |= 1u << 2;
   }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
@@ -210,11 +208,10 @@ static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)(M / 2) * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
   auto kern = dev::blind_rotate_v3_kernel<LOGN, 23>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(ctx->attr_done & (1u << 3))) {  // per context: the attribute is per device
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    ctx->attr_done |= 1u << 3;
   }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
@@ -407,6 +404,8 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   }
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
+    static uint64_t next_uid = 1;
+    ctx->uid = next_uid++;
     g_live.insert(ctx);
   }
   return ctx;

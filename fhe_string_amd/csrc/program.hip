@@ -27,7 +27,7 @@ struct fhes_program {
   int32_t n_slots = 0, n_pbs_levels = 0;
   bool has_linear_level = false;
   std::mutex mu;
-  std::map<fhes_ctx *, DeviceImage> images;
+  std::map<uint64_t, DeviceImage> images;  // keyed by fhes_ctx::uid
 };
 
 static void flatten(fhes_program *fp) {
@@ -146,7 +146,7 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
     if (in_handles[i] < 0 || in_handles[i] >= ctx->capacity) return fail(FHES_ERR_INVALID, "program_run: bad input handle");
 
   // ---- device image (once per ctx) ----
-  auto it = fp->images.find(ctx);
+  auto it = fp->images.find(ctx->uid);
   if (it == fp->images.end()) {
     DeviceImage img;
     img.device = ctx->device;
@@ -184,7 +184,7 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
     img.arrays.lut_ids = (const int32_t *)(img.buf + o_l);
     img.arrays.out_idx = (const int32_t *)(img.buf + o_o);
     img.arrays.n_slots = n_slots;
-    it = fp->images.emplace(ctx, img).first;
+    it = fp->images.emplace(ctx->uid, img).first;
   }
   DeviceImage &img = it->second;
   if (img.slot_map_cap < (size_t)n_inst * n_slots) {
