@@ -90,6 +90,10 @@ SIGNATURES = {
     "fhes_usize_decrypt": (C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
     "fhes_bool_decrypt": (C.c_int, [_P, _P, _i32p]),
     "fhes_ct_decrypt_blocks": (C.c_int, [_P, _P, _P]),
+    "fhes_client_key_serialize": (C.c_int64, [_P, _P, C.c_int64]),
+    "fhes_client_key_deserialize": (_P, [_P, C.c_int64]),
+    "fhes_ct_serialize": (C.c_int64, [_P, _P, C.c_int64]),
+    "fhes_ct_deserialize": (_P, [_P, C.c_int64]),
     "fhes_string_op": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _i32p]),
 }
 

@@ -54,6 +54,22 @@ class ClientKey:
         check(_L().fhes_usize_decrypt(self._h, v._h, C.byref(out)))
         return out.value
 
+    def to_bytes(self):
+        n = check(_L().fhes_client_key_serialize(self._h, None, 0))
+        buf = (C.c_uint8 * n)()
+        check(_L().fhes_client_key_serialize(self._h, buf, n))
+        return bytes(buf)
+
+    @staticmethod
+    def from_bytes(data):
+        ck = ClientKey.__new__(ClientKey)
+        arr = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        ck._h = check_ptr(_L().fhes_client_key_deserialize(arr, len(data)))
+        ck.params = Params()
+        check(_L().fhes_client_key_params(ck._h, C.byref(ck.params)))
+        ck.l = None
+        return ck
+
     def __del__(self):
         try:
             _L().fhes_client_key_destroy(self._h)
@@ -121,6 +137,17 @@ class _Ct:
     @property
     def num_blocks(self):
         return _L().fhes_ct_num_blocks(self._h)
+
+    def to_bytes(self):
+        n = check(_L().fhes_ct_serialize(self._h, None, 0))
+        buf = (C.c_uint8 * n)()
+        check(_L().fhes_ct_serialize(self._h, buf, n))
+        return bytes(buf)
+
+    @classmethod
+    def from_bytes(cls, data):
+        arr = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        return cls(check_ptr(_L().fhes_ct_deserialize(arr, len(data))))
 
 
 def _op(sk, name, *args, ints=(), max_outs=4):

@@ -297,6 +297,55 @@ int fhes_client_key_make_server_keys(const fhes_client_key *ck, uint64_t *bsk, u
   return FHES_OK;
 }
 
+// ---- serialisation of the client key ---------------------------------------------------------
+static const char kMagic[4] = {'F', 'H', 'E', 'S'};
+static const uint32_t kVersion = 1;
+
+int64_t fhes_client_key_serialize(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len) {
+  if (!ck) return fail(FHES_ERR_INVALID, "null argument");
+  const Dims d(ck->p);
+  const int64_t bits = (int64_t)d.big + d.n;
+  const int64_t total = 4 + 4 + 4 + (int64_t)sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8 + (bits + 7) / 8;
+  if (!buf) return total;
+  if (buf_len < total) return fail(FHES_ERR_INVALID, "buffer too small (%lld needed)", (long long)total);
+  uint8_t *w = buf;
+  auto put = [&](const void *src, size_t n) { memcpy(w, src, n); w += n; };
+  const uint32_t kind = 1;
+  put(kMagic, 4); put(&kVersion, 4); put(&kind, 4); put(&ck->p, sizeof(fhes_params));
+  put(&ck->l, 8); put(&ck->nb_char, 4); put(&ck->nb_usize, 4); put(&ck->seed, 8); put(&ck->enc_counter, 8);
+  memset(w, 0, (size_t)((bits + 7) / 8));
+  for (int64_t i = 0; i < bits; i++) {
+    const uint64_t bit = i < d.big ? ck->big_sk[i] : ck->small_sk[i - d.big];
+    if (bit) w[i / 8] |= (uint8_t)(1u << (i % 8));
+  }
+  return total;
+}
+
+fhes_client_key *fhes_client_key_deserialize(const uint8_t *buf, int64_t len) {
+  const int64_t head = 4 + 4 + 4 + (int64_t)sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8;
+  if (!buf || len < head || memcmp(buf, kMagic, 4) != 0) { fail(FHES_ERR_INVALID, "not an FHES blob"); return nullptr; }
+  const uint8_t *r = buf + 4;
+  auto get = [&](void *dst, size_t n) { memcpy(dst, r, n); r += n; };
+  uint32_t version, kind;
+  get(&version, 4); get(&kind, 4);
+  if (version != kVersion || kind != 1) { fail(FHES_ERR_INVALID, "unsupported version / kind"); return nullptr; }
+  auto *ck = new fhes_client_key;
+  get(&ck->p, sizeof(fhes_params));
+  std::string why;
+  if (!params_valid(ck->p, &why)) { delete ck; fail(FHES_ERR_INVALID, "invalid parameters: %s", why.c_str()); return nullptr; }
+  get(&ck->l, 8); get(&ck->nb_char, 4); get(&ck->nb_usize, 4); get(&ck->seed, 8); get(&ck->enc_counter, 8);
+  const Dims d(ck->p);
+  const int64_t bits = (int64_t)d.big + d.n;
+  if (len < head + (bits + 7) / 8) { delete ck; fail(FHES_ERR_INVALID, "truncated blob"); return nullptr; }
+  ck->big_sk.resize(d.big);
+  ck->small_sk.resize(d.n);
+  for (int64_t i = 0; i < bits; i++) {
+    const uint64_t bit = (r[i / 8] >> (i % 8)) & 1u;
+    if (i < d.big) ck->big_sk[i] = bit; else ck->small_sk[i - d.big] = bit;
+  }
+  return ck;
+}
+
 int fhes_client_encrypt_blocks(fhes_client_key *ck, const uint8_t *values, int64_t count,
                                uint64_t *out) {
   if (!ck || !values || !out || count < 0) return fail(FHES_ERR_INVALID, "bad argument");

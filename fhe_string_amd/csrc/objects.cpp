@@ -228,6 +228,41 @@ int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out) {
   return FHES_OK;
 }
 
+int64_t fhes_ct_serialize(fhes_ct *ct, uint8_t *buf, int64_t buf_len) {
+  if (!ct) return fail(FHES_ERR_INVALID, "null argument");
+  const int64_t total = 4 + 4 + 4 + 4 + 8 + (int64_t)ct->n_blocks * ct->ct_words * 8;
+  if (!buf) return total;
+  if (buf_len < total) return fail(FHES_ERR_INVALID, "buffer too small (%lld needed)", (long long)total);
+  int rc = ensure_host(ct);
+  if (rc) return rc;
+  const uint32_t version = 1, kind = 2;
+  uint8_t *w = buf;
+  auto put = [&](const void *src, size_t n) { memcpy(w, src, n); w += n; };
+  put("FHES", 4); put(&version, 4); put(&kind, 4); put(&ct->n_blocks, 4); put(&ct->ct_words, 8);
+  put(ct->host.data(), ct->host.size() * 8);
+  return total;
+}
+
+fhes_ct *fhes_ct_deserialize(const uint8_t *buf, int64_t len) {
+  if (!buf || len < 24 || memcmp(buf, "FHES", 4) != 0) { fail(FHES_ERR_INVALID, "not an FHES blob"); return nullptr; }
+  uint32_t version, kind;
+  memcpy(&version, buf + 4, 4);
+  memcpy(&kind, buf + 8, 4);
+  if (version != 1 || kind != 2) { fail(FHES_ERR_INVALID, "unsupported version / kind"); return nullptr; }
+  auto *ct = new fhes_ct;
+  memcpy(&ct->n_blocks, buf + 12, 4);
+  memcpy(&ct->ct_words, buf + 16, 8);
+  if (ct->n_blocks < 0 || ct->ct_words < 2 || ct->ct_words > (1 << 20) ||
+      len < 24 + (int64_t)ct->n_blocks * ct->ct_words * 8) {
+    delete ct;
+    fail(FHES_ERR_INVALID, "truncated or corrupt blob");
+    return nullptr;
+  }
+  ct->host.resize((size_t)ct->n_blocks * ct->ct_words);
+  memcpy(ct->host.data(), buf + 24, ct->host.size() * 8);
+  return ct;
+}
+
 int fhes_ct_decrypt_blocks(const fhes_client_key *ck, fhes_ct *c, uint8_t *values) {
   if (!ck || !c || !values) return fail(FHES_ERR_INVALID, "bad argument");
   std::vector<uint8_t> vals;

@@ -213,6 +213,15 @@ int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out);
 /* raw decoded value (message + carry + padding bit) of every block; values[num_blocks] */
 int fhes_ct_decrypt_blocks(const fhes_client_key *ck, fhes_ct *c, uint8_t *values);
 
+/* ---- serialisation (the reference derives serde on ClientKey / FheString / FheUsize:
+ * client_key.rs:15, ciphertext/mod.rs:30,42,401).  Versioned little-endian format:
+ *   "FHES" | u32 version | u32 kind (1 client key, 2 ciphertext) | fhes_params (52 bytes) | payload
+ * fhes_*_serialize returns the byte size; call with buf == NULL to query it. */
+int64_t fhes_client_key_serialize(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len);
+fhes_client_key *fhes_client_key_deserialize(const uint8_t *buf, int64_t len);
+int64_t fhes_ct_serialize(fhes_ct *ct, uint8_t *buf, int64_t buf_len);
+fhes_ct *fhes_ct_deserialize(const uint8_t *buf, int64_t len);
+
 /* Generic operation dispatch: op names and operand order as in fhes_op_signature.  `args` are
  * the ciphertext operands (S and U, in signature order), `iargs` the clear integers (I).
  * Results are returned in `outs` (caller destroys), one object per part of

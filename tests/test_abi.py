@@ -79,3 +79,22 @@ def test_compile_rejects_bad_requests(libs):
     assert not lib.fhes_program_compile(C.byref(p), b"no_such_op", sh.ctypes.data_as(C.c_void_p), 2, 4)
     assert b"unknown operation" in lib.fhes_last_error()
     assert not lib.fhes_program_compile(C.byref(p), b"find", sh.ctypes.data_as(C.c_void_p), 1, 4)
+
+
+def test_serialisation_round_trips(libs):
+    from fhe_string_amd.api import ClientKey, FheString, FheUsize, toy_params
+    ck = ClientKey(toy_params(), l=63, seed=9)
+    s = FheString.new(ck, "hello", 7)
+    blob = s.to_bytes()
+    assert blob[:4] == b"FHES" and len(blob) == 24 + 32 * 257 * 8
+    s2 = FheString.from_bytes(blob)
+    ck2 = ClientKey.from_bytes(ck.to_bytes())
+    assert s2.decrypt(ck2) == "hello" and s2.num_blocks == 32
+    assert ck2.num_blocks_usize == ck.num_blocks_usize == 3
+    assert FheUsize.from_bytes(FheUsize.new(ck, 37).to_bytes()).decrypt(ck2) == 37
+    import pytest
+    from fhe_string_amd._lib import FheError
+    with pytest.raises(FheError):
+        FheString.from_bytes(blob[:100])
+    with pytest.raises(FheError):
+        ClientKey.from_bytes(b"nope" + blob[4:])
