@@ -203,19 +203,20 @@ static int launch_br_v2(fhes_ctx *ctx, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
-template <int LOGN>
-static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d) {
+template <int LOGN, bool DIAG>
+static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d, unsigned long long *diag = nullptr) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)(M / 2) * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_v3_kernel<LOGN, 23>;
-  if (!(ctx->attr_done & (1u << 3))) {  // per context: the attribute is per device
+  auto kern = dev::blind_rotate_v3_kernel<LOGN, 23, DIAG>;
+  const unsigned bit = DIAG ? 4 : 3;
+  if (!(ctx->attr_done & (1u << bit))) {  // per context: the attribute is per device
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ctx->attr_done |= 1u << 3;
+    ctx->attr_done |= 1u << bit;
   }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
-                     ctx->lut_polys, ctx->twist, ctx->twist_inv, ctx->tw);
+                     ctx->lut_polys, ctx->twist, ctx->twist_inv, ctx->tw, diag);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
@@ -226,8 +227,8 @@ static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
   int variant = ctx->br_variant;
   if (variant == 0) variant = d.v_count <= ctx->n_cus ? 2 : 3;  // v2: 3.4 ms alone; v3: 2 per CU in 6.3 ms
   if (ctx->dims.N == 2048)
-    return variant == 1 ? launch_br_v1<11>(ctx, d) : variant == 2 ? launch_br_v2<11>(ctx, d) : launch_br_v3<11>(ctx, d);
-  return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 2 ? launch_br_v2<8>(ctx, d) : launch_br_v3<8>(ctx, d);
+    return variant == 1 ? launch_br_v1<11>(ctx, d) : variant == 2 ? launch_br_v2<11>(ctx, d) : launch_br_v3<11, false>(ctx, d);
+  return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 2 ? launch_br_v2<8>(ctx, d) : launch_br_v3<8, false>(ctx, d);
 }
 
 static int take_event(fhes_ctx *ctx, hipEvent_t *e) {
@@ -602,6 +603,59 @@ int fhes_debug_fft_tables(const fhes_params *p, double *twist, double *tw) {
   memcpy(twist, a.data(), a.size() * 8);
   memcpy(tw, b.data(), b.size() * 8);
   return FHES_OK;
+}
+
+// Developer hook: runs the throughput blind-rotate kernel in its DIAGNOSTIC build (s_memtime
+// stamps at every phase / barrier boundary) on `count` copies of a bootstrap of `in_handle` and
+// returns the average shader cycles per CMUX iteration spent in each of the 17 phases
+// (out[17]; order as FHES_STAMP in kernels.hip.h).  Never used by the product path.
+int fhes_debug_phase_profile(fhes_ctx *ctx, int32_t count, int32_t in_handle, double *out) {
+  if (!ctx || !out || count <= 0 || in_handle < 0 || in_handle >= ctx->capacity) return fail(FHES_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
+  if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
+  if (ctx->dims.N != 2048) return fail(FHES_ERR_UNSUPPORTED, "phase profile is built for N = 2048");
+  if (ctx->lut_tables.empty()) {
+    std::vector<uint64_t> t(ctx->dims.space());
+    for (size_t i = 0; i < t.size(); i++) t[i] = i;
+    if (lut_register_locked(ctx, t.data(), (int32_t)t.size()) < 0) return FHES_ERR_STATE;
+  }
+  const int32_t scratch = arena_alloc_locked(ctx, count);
+  if (scratch < 0) return scratch;
+  std::vector<int32_t> tp(count + 1), ti(count, in_handle), lut(count, 0), outh(count);
+  std::vector<int64_t> tc(count, 1);
+  std::vector<uint64_t> cs(count, 0);
+  for (int i = 0; i <= count; i++) tp[i] = i;
+  for (int i = 0; i < count; i++) outh[i] = scratch + i;
+  DevNodeArrays a;
+  int rc = stage_desc(ctx, count, tp.data(), ti.data(), tc.data(), cs.data(), lut.data(), outh.data(), &a);
+  if (rc == FHES_OK) rc = ensure_ks_out(ctx, count);
+  unsigned long long *diag = nullptr;
+  const size_t words = (size_t)count * 4 * 17;
+  if (rc == FHES_OK) {
+    dev::NodeDesc d = make_desc(a, 0, count, 0, count);
+    rc = launch_keyswitch(ctx, d);
+    if (rc == FHES_OK) {
+      hipError_t e = hipMalloc(&diag, words * 8);
+      if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(diag)");
+    }
+    if (rc == FHES_OK) rc = launch_br_v3<11, true>(ctx, d, diag);
+  }
+  if (rc == FHES_OK) {
+    std::vector<unsigned long long> h(words);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), diag, words * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = hip_fail(e, "diag copy");
+    else {
+      for (int k = 0; k < 17; k++) out[k] = 0;
+      for (size_t w = 0; w < (size_t)count * 4; w++)
+        for (int k = 0; k < 17; k++) out[k] += (double)h[w * 17 + k];
+      for (int k = 0; k < 17; k++) out[k] /= (double)count * 4 * ctx->dims.n;
+    }
+  }
+  if (diag) (void)hipFree(diag);
+  arena_free_locked(ctx, scratch, count);
+  return rc;
 }
 
 int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles, uint32_t *a_tilde) {

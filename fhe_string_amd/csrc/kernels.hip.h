@@ -65,11 +65,15 @@ __device__ __forceinline__ double i64_to_f64(uint64_t v) {
   const unsigned lo = (unsigned)v;
   return __builtin_fma((double)hi, 0x1p32, (double)lo);
 }
-// one-level closest-representable signed digit (base 2^BL) as f64
+// one-level closest-representable signed digit (base 2^BL) as f64:
+//   v = ((x >> (63-BL)) + 1) >> 1  (mod 2^BL, read as a signed BL-bit number)
+// Only the high dword matters (63-BL >= 32): adding the rounding bit 2^(31-BL) to it and shifting
+// arithmetically by 32-BL gives exactly that signed value (the 32-bit wrap is the mod 2^BL).
 template <int BL>
 __device__ __forceinline__ double digit1_f64(uint64_t x) {
-  const uint32_t v = (uint32_t)(((x >> (64 - BL - 1)) + 1) >> 1);
-  const int d = ((int)(v << (32 - BL))) >> (32 - BL);  // sign-extend BL bits
+  static_assert(BL >= 1 && BL <= 31, "single-level digit must fit the high dword");
+  const uint32_t hi = (uint32_t)(x >> 32);
+  const int d = (int)(hi + (1u << (31 - BL))) >> (32 - BL);
   return (double)d;
 }
 // (X^a * p)[j] for a in [1, 2N), polynomial in LDS/global
@@ -734,12 +738,12 @@ __device__ __forceinline__ void fft_butterflies_tab(double2 (&x)[8], int q, cons
   }
 }
 
-template <int LOGN, int BL>
+template <int LOGN, int BL, bool DIAG>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v3_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
     int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
     const double2 *__restrict__ twist, const double2 *__restrict__ twist_inv /* twist / M */,
-    const double2 *__restrict__ tw) {
+    const double2 *__restrict__ tw, unsigned long long *__restrict__ diag) {
   constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
   constexpr int NP = (LOGM - 1) / 3;
   static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
@@ -793,10 +797,39 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   double2 *buf_r = fbuf + (size_t)r * M;
   const double2 *buf_o = fbuf + (size_t)(1 - r) * M;
 
+  // diagnostic build only: cycles per phase, accumulated over the iterations
+  unsigned long long ph[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = 0;
+#define FHES_STAMP(K)                                                              \
+  if (DIAG) {                                                                      \
+    unsigned long long t_now;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    ph[K] += t_now - t_prev;                                                       \
+    t_prev = t_now;                                                                \
+  }
+  if (DIAG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory"); }
+
   for (int i = 0; i < n_small; ++i) {
     const int a = (int)at[i];
     if (a == 0) continue;
 
+    // Global loads complete in issue order (vmcnt), so the twist factors are requested FIRST
+    // and the GGSW prefetch only after they have been consumed: waiting for the twist then
+    // never waits for the (HBM / Infinity-Cache latency) GGSW loads.
+    double2 twv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) twv[e] = twist_q[e * TP];
+    double2 x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      const uint64_t d0 = rot_read<N>(acc_r, a, p) - acc_r[p];
+      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - acc_r[p + M];
+      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twv[e]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // GGSW column r of this iteration, consumed after the forward FFT
     double2 g0[8], g1[8];
     {
@@ -807,27 +840,23 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
         g1[e] = G[((size_t)(1 * 2 + r) * 8 + e) * TP + q];
       }
     }
-    double2 x[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      const uint64_t d0 = rot_read<N>(acc_r, a, p) - acc_r[p];
-      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - acc_r[p + M];
-      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twist_q[e * TP]);
-    }
-
+    FHES_STAMP(0)  // prefetch issue + rotation reads + digits + twist
     // ---- forward FFT ----
     fft_butterflies_tab<LOGM, true, LO_A>(x, q, T, wtop);
 #pragma unroll
     for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
+    FHES_STAMP(1)  // pass A + LDS write
     __syncthreads();
+    FHES_STAMP(2)  // barrier 1
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
     fft_butterflies_tab<LOGM, true, LO_B>(x, q, T, wtop);
     if (NP == 3) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+      FHES_STAMP(3)  // read + pass B + write
       __syncthreads();
+      FHES_STAMP(4)  // barrier 2
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
     }
@@ -835,10 +864,14 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     fft_stage_bit0_dpp(x, sgn);
 
     // ---- exchange spectra through fbuf ([e][q] order), external product ----
+    FHES_STAMP(5)  // read + pass C + DPP stage
     __syncthreads();  // every thread of this half has taken its pass inputs out of buf_r
+    FHES_STAMP(6)  // barrier 3
 #pragma unroll
     for (int e = 0; e < 8; ++e) buf_r[(size_t)e * TP + q] = x[e];
+    FHES_STAMP(7)  // spectrum write
     __syncthreads();
+    FHES_STAMP(8)  // barrier 4
     if (r == 0) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], buf_o[(size_t)e * TP + q], g0[e], g1[e]);
@@ -846,7 +879,14 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = ext_mac(buf_o[(size_t)e * TP + q], x[e], g0[e], g1[e]);
     }
+    // untwist factors (pre-scaled by 1/M): requested now, while the GGSW registers are dead,
+    // consumed after the inverse FFT
+    double2 twi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) twi[e] = twist_inv_q[e * TP];
+    FHES_STAMP(9)  // read other spectrum + external product (waits for the GGSW prefetch)
     __syncthreads();  // the other half has read my spectrum: buf_r may be overwritten
+    FHES_STAMP(10)  // barrier 5
 
     // ---- inverse FFT ----
     fft_stage_bit0_dpp(x, sgn);
@@ -854,14 +894,18 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       fft_butterflies_tab<LOGM, false, LO_C>(x, q, T, wtop);
 #pragma unroll
       for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+      FHES_STAMP(11)  // DPP stage + inverse pass C + write
       __syncthreads();
+      FHES_STAMP(12)  // barrier 6
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
     }
     fft_butterflies_tab<LOGM, false, LO_B>(x, q, T, wtop);
 #pragma unroll
     for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+    FHES_STAMP(13)  // read + inverse pass B + write
     __syncthreads();
+    FHES_STAMP(14)  // barrier 7
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
     fft_butterflies_tab<LOGM, false, LO_A>(x, q, T, wtop);
@@ -869,11 +913,19 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      const double2 v = cmul_conj(x[e], twist_inv_q[e * TP]);
+      const double2 v = cmul_conj(x[e], twi[e]);
       acc_r[p] += torus_from_f64_fast(v.x);
       acc_r[p + M] += torus_from_f64_fast(v.y);
     }
+    FHES_STAMP(15)  // read + inverse pass A + untwist + rounding + accumulator update
     __syncthreads();
+    FHES_STAMP(16)  // barrier 8
+  }
+#undef FHES_STAMP
+  if (DIAG && diag && (tid & 63) == 0) {
+    unsigned long long *dst = diag + ((size_t)blockIdx.x * (blockDim.x / 64) + tid / 64) * 17;
+#pragma unroll
+    for (int kk = 0; kk < 17; ++kk) dst[kk] = ph[kk];
   }
 
   uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;

@@ -145,6 +145,9 @@ int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t br_variant);
  * FFT tables twist[N/2][2], twiddle[N/4][2]. */
 int fhes_debug_bsk_fourier(fhes_ctx *ctx, double *out);
 int fhes_debug_fft_tables(const fhes_params *p, double *twist, double *twiddle);
+/* developer hook: average shader cycles per CMUX iteration in each of the 17 phases of the
+ * throughput blind-rotate kernel (diagnostic build with s_memtime stamps), out[17] */
+int fhes_debug_phase_profile(fhes_ctx *ctx, int32_t count, int32_t in_handle, double *out);
 /* test hook: keyswitch+modswitch only; a_tilde out is [count][n+1] u32 */
 int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles,
                          uint32_t *a_tilde);
