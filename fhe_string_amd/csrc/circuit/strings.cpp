@@ -27,19 +27,18 @@ struct S {
   Radix usize(uint64_t v) const { return o.trivial_radix(v, Bu); }     // FheUsize::new_trivial mod.rs:426
   Radix usize_from_bool(const Blk &x) const { return o.bool_to_radix(x, Bu); }  // mod.rs:431
 
-  // logic.rs:41-51
+  // logic.rs:41-51: any(v) = [sum_i v_i > 0].  The reference widens every boolean to a radix,
+  // sums the radixes and compares with 0; for boolean addends that is the same function as
+  // summing up to 15 of them inside ONE block (degree <= 15 fits the carry space) and looking
+  // up [s > 0], repeated over chunks -- no carry extraction, no radix comparison.
   Blk any(const std::vector<Blk> &v) {
     if (v.empty()) return o.trivial_bool(false);
-    std::vector<Radix> r;
-    for (const Blk &x : v) r.push_back(o.bool_to_radix(x, Bu));
-    return o.scalar_cmp(o.sum(r, Bu), 0, Cmp::GT);
+    return o.any_true(v);
   }
-  // logic.rs:54-65
+  // logic.rs:54-65: all(v) = [sum_i v_i == |v|], same reduction with [s == chunk size]
   Blk all(const std::vector<Blk> &v) {
     if (v.empty()) return o.trivial_bool(true);
-    std::vector<Radix> r;
-    for (const Blk &x : v) r.push_back(o.bool_to_radix(x, Bu));
-    return o.scalar_eq(o.sum(r, Bu), v.size());
+    return o.all_true(v);
   }
   // logic.rs:13-16: bool -> radix, then a radix multiplication
   Radix if_then_else_zero(const Blk &a, const Radix &x) { return o.mul(o.bool_to_radix(a, (int)x.size()), x); }
