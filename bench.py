@@ -249,6 +249,7 @@ def main():
                        "strings_per_step_per_rank": B,
                        "parallelism": f"{world_size} rank(s) x {B} independent strings per step"},
             "result_ok": bool(ok),
+            "finds_per_s": round(B * world_size * args.steps / dt_max, 2),
             **({"rehearsal": "all ranks on device 0 over gloo: not a scaling result"} if rehearsal else {}),
             "find_wall_ms_single": round(single_ms, 3),
             "pbs_per_s_single_find": round(pbs_per_find / (single_ms * 1e-3), 1),
