@@ -207,3 +207,23 @@ def test_logdepth_find_equals_faithful_find(libs):
     _, p_fast = run_plain("find_logdepth", "x" * 64, None, "xxxx", None)
     _, p_ref = run_plain("find", "x" * 64, None, "xxxx", None)
     assert p_fast.n_levels < 20 < p_ref.n_levels
+
+
+def test_split_family_matches_the_references_own_algorithm(libs):
+    """bug-compatible parity: random inputs, including overlapping patterns and matches at
+    position 0 where the reference's rsplit differs from std (search.rs:114-152)"""
+    from tests.ref_model import ref_split
+    rnd = random.Random(23)
+    n_std_diff = 0
+    for trial in range(60):
+        la = rnd.randint(0, 7)
+        a = "".join(rnd.choice("xa") for _ in range(la))
+        p = "".join(rnd.choice("xa") for _ in range(rnd.randint(1, 3)))
+        a_pad = rnd.choice([None, la + rnd.randint(0, 2)])
+        p_pad = rnd.choice([None, len(p) + rnd.randint(0, 1)])
+        for op in ("split", "rsplit", "split_inclusive", "split_terminator", "rsplit_terminator"):
+            got = run_plain(op, a, a_pad, p, p_pad)[0]
+            assert got == ref_split(op, a, a_pad, p, p_pad), (op, a, a_pad, p, p_pad)
+        n_std_diff += run_plain("rsplit", a, a_pad, p, p_pad)[0] != list(reversed(a.rsplit(p)))
+    assert run_plain("rsplit", "xxa", None, "xx", None)[0] == ["xxa"]      # the reference's quirk, reproduced
+    assert n_std_diff > 0

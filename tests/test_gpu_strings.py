@@ -198,3 +198,56 @@ def run_api_ext(ck, sk, case):
 def test_reference_tables_ext_on_gpu(case, keys):
     ck, sk = keys
     assert run_api_ext(ck, sk, case) == case["expect"], case
+
+
+def test_random_operations_fuzz_on_gpu(keys):
+    """seeded random strings through every operation of the API at the real parameter set;
+    decrypted results must equal Python restatements of Rust's std::str semantics"""
+    import random
+    ck, sk = keys
+    rnd = random.Random(0xF4E5F022)
+    E = lambda s, pad=None: api.FheString.new(ck, s, pad)
+    U = lambda v: api.FheUsize.new(ck, v)
+    B = ck.decrypt_bool
+    for trial in range(14):
+        la = rnd.randint(1, 6)
+        a = "".join(rnd.choice("abx ") for _ in range(la))
+        p = "".join(rnd.choice("abx") for _ in range(rnd.randint(1, 2)))
+        if trial % 2 == 0 and la >= 2:
+            k = rnd.randint(0, la - 1)
+            p = a[k:k + rnd.randint(1, 2)]
+        pad = rnd.choice([None, la + rnd.randint(0, 2)])
+        ctx = (a, p, pad)
+        A, P = E(a, pad), E(p)
+        i = a.find(p)
+        assert A.find(sk, P).decrypt(ck) == (None if i < 0 else i), ctx
+        assert A.find(sk, P, logdepth=True).decrypt(ck) == (None if i < 0 else i), ctx
+        j = a.rfind(p)
+        assert A.rfind(sk, P).decrypt(ck) == (None if j < 0 else j), ctx
+        assert B(A.contains(sk, P)) == (p in a), ctx
+        assert B(A.starts_with(sk, P)) == a.startswith(p), ctx
+        assert B(A.lt(sk, P)) == (a < p) and B(A.ge(sk, P)) == (a >= p), ctx
+        assert B(A.eq(sk, E(a, la + 1))) is True and B(A.ne(sk, P)) == (a != p), ctx
+        assert A.len(sk).decrypt(ck) == la, ctx
+        assert A.split(sk, P).decrypt(ck) == a.split(p), ctx
+        from tests.ref_model import ref_split   # the reference's own rsplit differs from std (DESIGN.md 5.7)
+        assert A.rsplit(sk, P).decrypt(ck) == ref_split("rsplit", a, pad, p, None), ctx
+        n = rnd.randint(0, 3)
+        assert A.splitn(sk, U(n), P).decrypt(ck) == (a.split(p, n - 1) if n else []), ctx + (n,)
+        assert A.split_once(sk, P).decrypt(ck) == ((a[:i], a[i + len(p):]) if i >= 0 else None), ctx
+        assert A.strip_prefix(sk, P).decrypt(ck) == (a[len(p):] if a.startswith(p) else None), ctx
+        assert A.strip_suffix(sk, P).decrypt(ck) == (a[:la - len(p)] if a.endswith(p) else None), ctx
+        assert A.trim(sk).decrypt(ck) == a.strip(" "), ctx
+        assert A.split_ascii_whitespace(sk).decrypt(ck) == a.split(), ctx
+        assert A.to_uppercase(sk).decrypt(ck) == a.upper(), ctx
+        r = rnd.choice(["y", "zz"])
+        res = a.replace(p, r)
+        assert A.replace(sk, P, E(r), len(res)).decrypt(ck) == res, ctx + (r,)
+        resn = a.replace(p, r, n)
+        assert A.replacen(sk, P, E(r), U(n), len(resn)).decrypt(ck) == resn, ctx + (r, n)
+        k = rnd.randint(0, la)
+        assert A.char_at(sk, U(k)).decrypt(ck) == (ord(a[k]) if k < la else 0), ctx + (k,)
+        assert A.substr_from(sk, U(k)).decrypt(ck) == a[k:], ctx + (k,)
+        assert A.substr_end(sk, U(k), U(la)).decrypt(ck) == a[k:la], ctx + (k,)
+        assert A.insert(sk, U(k), P).decrypt(ck) == a[:k] + p + a[k:], ctx + (k,)
+        assert A.add(sk, P).decrypt(ck) == a + p, ctx
