@@ -221,6 +221,31 @@ class FheStringSliceVector:
             res.append(s_dec[a:b] if a <= b <= len(s_dec) else "")  # get(start..end).unwrap_or_default()
         return res
 
+    def _parts(self):
+        return (self._is_some, self._starts, self._ends)
+
+    def len(self, k):
+        """split.rs:32-43"""
+        return FheUsize(_op(k, "slices_len", *self._parts())[0])
+
+    def get(self, k, i):
+        """split.rs:46-83 (as written there: Some only if the hit is the LAST entry)"""
+        o = _op(k, "slices_get", *self._parts(), self.s, i)
+        return FheOption(BooleanBlock(o[0]), FheString(o[1]))
+
+    def truncate(self, k, i):
+        """split.rs:86-113 (in place, like the reference's &mut self)"""
+        o = _op(k, "slices_truncate", *self._parts(), i)
+        self._is_some, self._starts, self._ends = _Ct(o[0]), _Ct(o[1]), _Ct(o[2])
+
+    def reverse(self):
+        """split.rs:229-231 (needs the server key only to reach the device: no bootstraps)"""
+        raise TypeError("use reverse_with(k)")
+
+    def reverse_with(self, k):
+        o = _op(k, "slices_reverse", *self._parts())
+        self._is_some, self._starts, self._ends = _Ct(o[0]), _Ct(o[1]), _Ct(o[2])
+
 
 def _decrypt_digits(ck, ct):
     """message digits (mod message_modulus) of every block of `ct`"""
@@ -400,6 +425,10 @@ class FheString(_Ct):
 
     def insert(self, k, index, s):
         return FheString(_op(k, "insert", self, index, s)[0])
+
+    def repeat(self, k, n, l):
+        """insert.rs:20-44: `self` repeated `n` (FheUsize) times, up to length `l` (clear)"""
+        return FheString(_op(k, "repeat", self, n, ints=(l,))[0])
 
 
 class StringEncryption:

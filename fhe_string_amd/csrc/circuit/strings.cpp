@@ -379,6 +379,28 @@ struct S {
     return v;
   }
 
+  // insert.rs:20-44.  v[i] = i < n*len ? self[i % len] : 0.  `i` is public and len <= max_len is a
+  // public bound, so `rem_parallelized` + `char_at` collapse into one one-hot gather over the
+  // possible lengths: self[i % len] = sum_d [len == d] * self[i % d]  (len == 0 selects nothing,
+  // and i < n*0 is false anyway).
+  Str repeat(const Str &a, const Radix &n, size_t l, size_t max_len_key) {
+    l = std::min(l, max_len_key);
+    Radix self_len = len(a);
+    Radix n_mul_len = o.mul(n, self_len);
+    std::vector<Blk> len_is;
+    for (size_t d = 1; d <= max_len(a); d++) len_is.push_back(o.scalar_eq(self_len, d));
+    Str v;
+    for (size_t i = 0; i < l; i++) {
+      Blk i_lt = o.scalar_cmp(n_mul_len, i, Cmp::GT);
+      std::vector<Radix> terms;
+      for (size_t d = 1; d <= max_len(a); d++) terms.push_back(if_then_else_zero(len_is[d - 1], a[i % d]));
+      Radix c = terms.empty() ? term_char() : sum_exclusive(terms, Bc);
+      v.push_back(if_then_else_zero(i_lt, c));
+    }
+    v.push_back(term_char());
+    return v;
+  }
+
   // insert.rs:48-124
   Str insert(const Str &a, const Radix &index, const Str &bstr, size_t max_len_key) {
     const size_t l = std::min(max_len(a) + max_len(bstr), max_len_key);
@@ -422,6 +444,30 @@ struct S {
       n = o.add(n, usize_from_bool(vi.is_some));
       vi.is_some = is_some;
     }
+  }
+  // split.rs:32-43
+  Radix slices_len(const std::vector<Slice> &v) {
+    std::vector<Radix> r;
+    for (const Slice &vi : v) r.push_back(usize_from_bool(vi.is_some));
+    if (r.empty()) return usize(0);
+    return o.sum(r, Bu);
+  }
+  // split.rs:46-83, as written: the fold OVERWRITES acc.is_some in every step (so the result is
+  // Some only when the element asked for is the last entry of the vector) and takes the entry's
+  // position j, not its stored start, as the start of the slice.
+  std::pair<Blk, Str> slices_get(const std::vector<Slice> &v, const Str &src, const Radix &i) {
+    Radix n = usize(0);
+    Blk acc_some = o.trivial_bool(false);
+    Radix acc_start = usize(0), acc_end = usize(0);
+    for (size_t j = 0; j < v.size(); j++) {
+      Blk i_eq_n = o.eq(i, n);
+      Blk is_some = o.bitand_(i_eq_n, v[j].is_some);
+      acc_start = o.if_then_else(is_some, usize(j), acc_start);
+      acc_end = o.if_then_else(is_some, v[j].end, acc_end);
+      acc_some = is_some;
+      n = o.add(n, usize_from_bool(v[j].is_some));
+    }
+    return {acc_some, substr_end(src, acc_start, acc_end)};
   }
   // split.rs:147-173
   void expand_first(std::vector<Slice> &v) {
@@ -507,9 +553,11 @@ void push_all(std::vector<Blk> &out, const Radix &r) {
 
 }  // namespace
 
-// Operand signature of every operation: S = FheString, U = FheUsize, I = clear integer.
-// `shape` lists, in operand order, the slot count of each S operand and the value of each I
-// operand (U operands contribute nothing: they are num_blocks_usize blocks).
+// Operand signature of every operation: S = FheString, U = FheUsize, I = clear integer, V =
+// FheStringSliceVector (three ciphertext operands: is_some[n], start[n][Bu], end[n][Bu]).
+// `shape` lists, in operand order, the slot count of each S operand, the element count of each V
+// operand and the value of each I operand (U operands contribute nothing: they are
+// num_blocks_usize blocks).
 struct OpSig { const char *name; const char *sig; };
 static const OpSig kOps[] = {
     {"find", "SS"}, {"find_logdepth", "SS"}, {"rfind", "SS"}, {"contains", "SS"}, {"starts_with", "SS"}, {"ends_with", "SS"},
@@ -521,7 +569,9 @@ static const OpSig kOps[] = {
     {"char_at", "SU"}, {"substr_to", "SU"}, {"substr_from", "SU"}, {"substr_end", "SUU"}, {"truncate", "SU"},
     {"trim", "S"}, {"trim_start", "S"}, {"trim_end", "S"}, {"strip_prefix", "SS"}, {"strip_suffix", "SS"},
     {"to_lowercase", "S"}, {"to_uppercase", "S"},
-    {"replace", "SSSI"}, {"replacen", "SSSUI"}, {"add", "SS"}, {"insert", "SUS"},
+    {"replace", "SSSI"}, {"replacen", "SSSUI"}, {"add", "SS"}, {"insert", "SUS"}, {"repeat", "SUI"},
+    // FheStringSliceVector methods (split.rs:30-113): V = the vector (is_some[n], start[n], end[n])
+    {"slices_len", "V"}, {"slices_get", "VSU"}, {"slices_truncate", "VU"}, {"slices_reverse", "V"},
 };
 
 const char *op_signature(const std::string &op) {
@@ -588,7 +638,7 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
   if (!sig) throw std::invalid_argument("unknown operation '" + op + "'");
   const std::string sg = sig;
   size_t need = 0;
-  for (char c : sg) need += (c == 'S' || c == 'I');
+  for (char c : sg) need += (c == 'S' || c == 'I' || c == 'V');
   if (shape.size() != need)
     throw std::invalid_argument("operation '" + op + "' (signature " + sg + ") needs " + std::to_string(need) + " shape entries");
   int32_t n_inputs = 0;
@@ -597,6 +647,7 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
     for (char c : sg) {
       if (c == 'S') { if (shape[k] < 1) throw std::invalid_argument("a string has at least its terminator slot"); n_inputs += shape[k++] * Bc; }
       else if (c == 'U') n_inputs += Bu;
+      else if (c == 'V') { if (shape[k] < 0) throw std::invalid_argument("negative element count"); n_inputs += shape[k++] * (1 + 2 * Bu); }
       else { if (shape[k] < 0) throw std::invalid_argument("negative integer argument"); k++; }
     }
   }
@@ -606,6 +657,7 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
   std::vector<Str> strs;
   std::vector<Radix> us;
   std::vector<int64_t> ints;
+  std::vector<S::Slice> vec;
   {
     int32_t next = 0;
     size_t k = 0;
@@ -623,6 +675,12 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
         Radix r;
         for (int q = 0; q < Bu; q++) r.push_back(b.input(next++, msg_mod - 1));
         us.push_back(r);
+      } else if (c == 'V') {
+        const int n = shape[k++];
+        vec.resize(n);
+        for (int e = 0; e < n; e++) vec[e].is_some = b.input(next++, 1);
+        for (int e = 0; e < n; e++) for (int q = 0; q < Bu; q++) vec[e].start.push_back(b.input(next++, msg_mod - 1));
+        for (int e = 0; e < n; e++) for (int q = 0; q < Bu; q++) vec[e].end.push_back(b.input(next++, msg_mod - 1));
       } else ints.push_back(shape[k++]);
     }
   }
@@ -690,6 +748,19 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
     put_str(s.insert(strs[0], s.len(strs[0]), strs[1], max_len_key));
   } else if (op == "insert") {  // insert.rs:48
     put_str(s.insert(strs[0], us[0], strs[1], max_len_key));
+  } else if (op == "repeat") {  // insert.rs:20
+    put_str(s.repeat(strs[0], us[0], (size_t)ints[0], max_len_key));
+  } else if (op == "slices_len") put_radix(s.slices_len(vec));
+  else if (op == "slices_get") {
+    auto r = s.slices_get(vec, strs[0], us[0]);
+    put_bool(r.first);
+    put_str(r.second);
+  } else if (op == "slices_reverse") {  // split.rs:229-231
+    std::reverse(vec.begin(), vec.end());
+    put_slices(vec);
+  } else if (op == "slices_truncate") {
+    s.truncate_slices(vec, us[0]);
+    put_slices(vec);
   } else if (op == "split_ascii_whitespace") put_slices(s.split_ascii_whitespace(strs[0]));
   else {
     // split family (split.rs:339-411); output: is_some[n], start[n][Bu], end[n][Bu]

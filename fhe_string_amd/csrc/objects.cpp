@@ -291,6 +291,16 @@ int fhes_string_op(fhes_server_key *sk, const char *op, fhes_ct *const *args, in
       continue;
     }
     if (ai >= n_args || !args[ai]) return fail(FHES_ERR_INVALID, "operation '%s' (signature %s): missing operand %d", op, sig, ai);
+    if (*c == 'V') {  // is_some[n], start[n][Bu], end[n][Bu]
+      if (ai + 2 >= n_args || !args[ai + 1] || !args[ai + 2]) return fail(FHES_ERR_INVALID, "operation '%s' (signature %s): a slice vector is three operands", op, sig);
+      const int32_t n = args[ai]->n_blocks;
+      if (args[ai + 1]->n_blocks != n * sk->nb_usize || args[ai + 2]->n_blocks != n * sk->nb_usize)
+        return fail(FHES_ERR_INVALID, "operands %d..%d are not a slice vector", ai, ai + 2);
+      shape.push_back(n);
+      key += ":v" + std::to_string(n);
+      ai += 3;
+      continue;
+    }
     if (*c == 'S') {
       if (args[ai]->n_blocks % sk->nb_char) return fail(FHES_ERR_INVALID, "operand %d is not a string", ai);
       shape.push_back(args[ai]->n_blocks / sk->nb_char);

@@ -156,8 +156,13 @@ int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles
 typedef struct fhes_program fhes_program;
 
 /* Operand signature of an operation: one letter per operand in the order of the reference's
- * method arguments (self first): S = FheString, U = FheUsize, I = clear integer.  E.g.
- * "find" -> "SS", "splitn" -> "SUS" (self, n, pattern), "replacen" -> "SSSUI".  NULL if unknown. */
+ * method arguments (self first): S = FheString, U = FheUsize, I = clear integer, V =
+ * FheStringSliceVector (split.rs:21-28), which is THREE ciphertext operands is_some[n],
+ * start[n][Bu], end[n][Bu] as returned by the split family.  E.g. "find" -> "SS", "splitn" ->
+ * "SUS" (self, n, pattern), "replacen" -> "SSSUI", "repeat" -> "SUI" (insert.rs:20),
+ * "slices_len" -> "V" (split.rs:32), "slices_get" -> "VSU" (v, v.s, i; split.rs:46),
+ * "slices_truncate" -> "VU" (split.rs:86), "slices_reverse" -> "V" (split.rs:229).
+ * NULL if unknown. */
 const char *fhes_op_signature(const char *op);
 /* Compile a string operation for static shapes (host only, no device needed).
  *   op: the reference's method name (see fhe_string_amd/csrc/circuit/strings.cpp: kOps)
@@ -226,7 +231,8 @@ int64_t fhes_ct_serialize(fhes_ct *ct, uint8_t *buf, int64_t buf_len);
 fhes_ct *fhes_ct_deserialize(const uint8_t *buf, int64_t len);
 
 /* Generic operation dispatch: op names and operand order as in fhes_op_signature.  `args` are
- * the ciphertext operands (S and U, in signature order), `iargs` the clear integers (I).
+ * the ciphertext operands (S, U and the three parts of each V, in signature order), `iargs` the
+ * clear integers (I).
  * Results are returned in `outs` (caller destroys), one object per part of
  * fhes_program_out_parts: FheOption<T> -> {is_some, val}; split family -> {is_some[n],
  * start[n][Bu], end[n][Bu]} over `self`; split_once -> {is_some, prefix, suffix}. */

@@ -155,6 +155,9 @@ for a, p, r, pad, n in [("aaa", "a", "b", None, 2), ("abdb", "b", "c", 4, 1), ("
 # tests/insert.rs:22-43 (add)
 for a, b in [("abc", "def"), ("abc", ""), ("", "def"), ("", "")]:
     addx("add", [S(a), S(b)], a + b, "tests/insert.rs:22-43")
+# tests/insert.rs:64-112 (repeat): operands (self, n, l)
+for a, n, l in [("abc", 0, 8), ("abc", 1, 8), ("abc", 2, 8)]:
+    addx("repeat", [S(a), {"u": n}, {"i": l}], a * n, "tests/insert.rs:64-112")
 # tests/convert.rs:15-24
 for a in ["ABC", "Abc", "abc def"]:
     addx("to_lowercase", [S(a)], a.lower(), "tests/convert.rs:15-24")

@@ -128,6 +128,12 @@ def build_inputs(lib, op, args, bu):
             digits.append(blk)
         elif c == "U":
             digits.append(usize_blocks(a["u"], bu))
+        elif c == "V":      # {"v": [(is_some, start, end), ...]}
+            v = a["v"]
+            shape.append(len(v))
+            digits.append(np.array([int(e[0]) for e in v], dtype=np.uint8))
+            for k in (1, 2):
+                digits.append(np.concatenate([usize_blocks(e[k], bu) for e in v]) if v else np.zeros(0, dtype=np.uint8))
         else:
             shape.append(a["i"])
     return shape, (np.concatenate(digits) if digits else np.zeros(0, dtype=np.uint8))
@@ -143,7 +149,8 @@ def blocks_to_str(vals, bc=4, msg_mod=4):
 
 
 STRING_RESULT = {"trim", "trim_start", "trim_end", "substr_to", "substr_from", "substr_end", "truncate",
-                 "to_lowercase", "to_uppercase", "replace", "replacen", "add", "insert"}
+                 "to_lowercase", "to_uppercase", "replace", "replacen", "add", "insert", "repeat"}
+OPTION_STRING_SLICES = {"slices_get"}
 OPTION_STRING = {"strip_prefix", "strip_suffix"}
 OPTION_PAIR = {"split_once", "rsplit_once"}
 
@@ -156,7 +163,13 @@ def decode_generic(op, outs, parts, bu, self_str=None):
         off += n
     if op in STRING_RESULT:
         return blocks_to_str(chunks[0])
-    if op in OPTION_STRING:
+    if op == "slices_len":
+        return radix_value(chunks[0])
+    if op in ("slices_truncate", "slices_reverse"):   # raw entries (is_some, start, end)
+        n = parts[0]
+        return [(chunks[0][i] & 1, radix_value(chunks[1][i * bu:(i + 1) * bu]), radix_value(chunks[2][i * bu:(i + 1) * bu]))
+                for i in range(n)]
+    if op in OPTION_STRING or op in OPTION_STRING_SLICES:
         return blocks_to_str(chunks[1]) if chunks[0][0] & 1 else None
     if op in OPTION_PAIR:
         return [blocks_to_str(chunks[1]), blocks_to_str(chunks[2])] if chunks[0][0] & 1 else None

@@ -107,3 +107,44 @@ def ref_split(op, a, a_pad, p, p_pad):
     else:
         raise ValueError(op)
     return decrypt_slices(a, v)
+
+
+# ---- FheStringSliceVector methods over raw entries [(is_some, start, end)] ---------------------
+def raw_split(op, a, a_pad, p, p_pad):
+    """the vector as the reference holds it (before decrypt), entries as (is_some, start, end)"""
+    A, P = slots(a, a_pad), slots(p, p_pad)
+    v = split_opt(A, P, op == "split_inclusive", op.startswith("rsplit"))
+    if op == "split_inclusive":
+        truncate_last_if_empty(v)
+    if op.startswith("rsplit"):
+        v = list(reversed(v))
+    return [(bool(x[0]), x[1], x[2]) for x in v]
+
+
+def slices_len(v):                           # split.rs:32-43
+    return sum(1 for e in v if e[0])
+
+
+def slices_truncate(v, i):                   # split.rs:86-113
+    out, n = [], 0
+    for ok, s, e in v:
+        out.append((bool(ok and n < i), s, e))
+        n += int(ok)
+    return out
+
+
+def slices_get(v, a, a_pad, i, bu=4):        # split.rs:46-83: is_some is overwritten per step, start = j
+    A = slots(a, a_pad)
+    n, some, start, end = 0, False, 0, 0
+    for j, (ok, _, e) in enumerate(v):
+        some = bool(ok and i == n)
+        if some:
+            start, end = j, e
+        n += int(ok)
+    # substr_end(start, end) mod.rs:198-213: v[k] = start + k < end ? self[start + k] : 0
+    mod = 4 ** bu
+    out = []
+    for k in range(len(A)):
+        t = (start + k) % mod
+        out.append(A[t] if (t < end and t < len(A)) else 0)
+    return "".join(chr(c) for c in out if c) if some else None

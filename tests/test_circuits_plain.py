@@ -227,3 +227,33 @@ def test_split_family_matches_the_references_own_algorithm(libs):
         n_std_diff += run_plain("rsplit", a, a_pad, p, p_pad)[0] != list(reversed(a.rsplit(p)))
     assert run_plain("rsplit", "xxa", None, "xx", None)[0] == ["xxa"]      # the reference's quirk, reproduced
     assert n_std_diff > 0
+
+
+def test_slice_vector_methods_and_repeat(libs):
+    """FheStringSliceVector::{len,get,truncate,reverse} (split.rs:30-113, 229) and repeat
+    (insert.rs:20-44) against plain restatements of the reference's code"""
+    from tests import ref_model as rm
+    rnd = random.Random(5)
+    n_some = 0
+    for trial in range(12):
+        a = "".join(rnd.choice("xab") for _ in range(rnd.randint(0, 6)))
+        p = rnd.choice(["x", "xa", "a", ""])
+        a_pad = rnd.choice([None, len(a) + 1])
+        op = rnd.choice(["split", "rsplit", "split_inclusive"])
+        v = rm.raw_split(op, a, a_pad, p, None)
+        V = {"v": v}
+        assert run_ext("slices_len", [V])[0] == rm.slices_len(v)
+        i = rnd.randint(0, 3)
+        assert run_ext("slices_truncate", [V, {"u": i}])[0] == [(int(x[0]), x[1], x[2]) for x in rm.slices_truncate(v, i)]
+        assert run_ext("slices_reverse", [V])[0] == [(int(x[0]), x[1], x[2]) for x in reversed(v)]
+        for i in range(0, rm.slices_len(v) + 1):
+            got = run_ext("slices_get", [V, S(a, a_pad), {"u": i}])[0]
+            assert got == rm.slices_get(v, a, a_pad, i), (op, a, a_pad, p, i)
+            n_some += got is not None
+    assert n_some > 0
+    for trial in range(10):
+        a = "".join(rnd.choice("ab") for _ in range(rnd.randint(0, 4)))
+        pad = rnd.choice([None, len(a) + 2])
+        n, l = rnd.randint(0, 4), rnd.randint(0, 12)
+        want = (a * n)[:l]
+        assert run_ext("repeat", [S(a, pad), {"u": n}, {"i": l}])[0] == want, (a, pad, n, l)

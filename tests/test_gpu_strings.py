@@ -251,3 +251,24 @@ def test_random_operations_fuzz_on_gpu(keys):
         assert A.substr_end(sk, U(k), U(la)).decrypt(ck) == a[k:la], ctx + (k,)
         assert A.insert(sk, U(k), P).decrypt(ck) == a[:k] + p + a[k:], ctx + (k,)
         assert A.add(sk, P).decrypt(ck) == a + p, ctx
+
+
+@pytest.mark.gpu
+def test_slice_vector_methods_on_gpu(keys):
+    """FheStringSliceVector::{len,get,truncate,reverse} (split.rs:30-113, 229) through the API"""
+    from tests import ref_model as rm
+    ck, sk = keys
+    for op, a, pad, p in [("split", "axbxc", None, "x"), ("rsplit", "axbxc", 7, "x"), ("split", "xxa", None, "xx"),
+                          ("split_inclusive", "abab", None, "b")]:
+        A, P = api.FheString.new(ck, a, pad), api.FheString.new(ck, p)
+        raw = rm.raw_split(op, a, pad, p, None)
+        dec = lambda v: rm.decrypt_slices(a, [list(e) for e in v])
+        v = getattr(A, op)(sk, P)
+        assert v.decrypt(ck) == dec(raw)
+        assert v.len(sk).decrypt(ck) == rm.slices_len(raw)
+        for i in range(rm.slices_len(raw) + 1):
+            assert v.get(sk, api.FheUsize.new(ck, i)).decrypt(ck) == rm.slices_get(raw, a, pad, i), (op, a, p, i)
+        v.truncate(sk, api.FheUsize.new(ck, 2))
+        assert v.decrypt(ck) == dec(rm.slices_truncate(raw, 2))
+        v.reverse_with(sk)
+        assert v.decrypt(ck) == dec(list(reversed(rm.slices_truncate(raw, 2))))
