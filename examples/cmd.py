@@ -87,6 +87,7 @@ def main():
         (f'"{s}".replace("{p}", "{sub}")', lambda: rep, lambda: se.replace(sk, pe, sube, len(rep))),
         (f'"{s}".replacen("{p}", "{sub}", {n})', lambda: repn, lambda: se.replacen(sk, pe, sube, ne, len(repn))),
         (f'"{s}" + "{p}"', lambda: s + p, lambda: se.add(sk, pe)),
+        (f'"{s}".repeat({n})', lambda: s * n, lambda: se.repeat(sk, ne, len(s * n))),
     ]
     t_total = time.time()
     for name, std, fhe in cases:
