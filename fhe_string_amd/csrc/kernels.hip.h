@@ -865,19 +865,20 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 
     // ---- exchange spectra through fbuf ([e][q] order), external product ----
     FHES_STAMP(5)  // read + pass C + DPP stage
-    __syncthreads();  // every thread of this half has taken its pass inputs out of buf_r
-    FHES_STAMP(6)  // barrier 3
+    FHES_STAMP(6)  // (barrier 3 removed)
+    // spectrum written IN PLACE (the slots this thread read its pass-C inputs from): no other
+    // thread reads or writes those slots before the barrier, so no barrier is needed here
 #pragma unroll
-    for (int e = 0; e < 8; ++e) buf_r[(size_t)e * TP + q] = x[e];
+    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
     FHES_STAMP(7)  // spectrum write
     __syncthreads();
     FHES_STAMP(8)  // barrier 4
     if (r == 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], buf_o[(size_t)e * TP + q], g0[e], g1[e]);
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], buf_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], g0[e], g1[e]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(buf_o[(size_t)e * TP + q], x[e], g0[e], g1[e]);
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(buf_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], x[e], g0[e], g1[e]);
     }
     // untwist factors (pre-scaled by 1/M): requested now, while the GGSW registers are dead,
     // consumed after the inverse FFT
