@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libfhe_string_amd.so")
 class Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "lwe_dim", "glwe_dim", "poly_size", "pbs_base_log", "pbs_level", "ks_base_log",
-        "ks_level", "message_bits", "carry_bits")] + [
+        "ks_level", "message_bits", "carry_bits", "grouping_factor")] + [
         ("lwe_noise_std", C.c_double), ("glwe_noise_std", C.c_double)]
 
     def ct_words(self):
@@ -38,6 +38,8 @@ _i32p = C.POINTER(C.c_int32)
 SIGNATURES = {
     "fhes_params_default": (C.c_int, [_PP]),
     "fhes_params_toy": (C.c_int, [_PP]),
+    "fhes_params_multibit": (C.c_int, [_PP, C.c_int32]),
+    "fhes_params_toy_multibit": (C.c_int, [_PP, C.c_int32]),
     "fhes_ct_words": (C.c_int64, [_PP]),
     "fhes_bsk_words": (C.c_int64, [_PP]),
     "fhes_ksk_words": (C.c_int64, [_PP]),

@@ -7,7 +7,8 @@
 namespace fhes {
 namespace circ {
 
-Builder::Builder(const fhes_params &p, int32_t n_inputs) : p_(p), n_inputs_(n_inputs) {}
+Builder::Builder(const fhes_params &p, int32_t n_inputs)
+    : p_(p), n_inputs_(n_inputs), noise_cap_(p.grouping_factor > 1 ? 34.0 : 256.0) {}
 
 Blk Builder::input(int32_t i, uint32_t deg) const {
   if (i < 0 || i >= n_inputs_) throw std::logic_error("input index out of range");
@@ -118,7 +119,7 @@ Blk Builder::pbs(const Blk &in, const std::function<uint64_t(uint64_t)> &f, bool
     return trivial(t[in.cst]);
   }
   if (!signed_input && in.deg >= (uint32_t)sp) throw std::logic_error("pbs: input degree exceeds the plaintext space");
-  if (in.noise > kNoiseCap) throw std::logic_error("pbs: input noise exceeds the cap");
+  if (in.noise > noise_cap_) throw std::logic_error("pbs: input noise exceeds the cap");
   uint32_t out_deg = 0;
   if (signed_input) out_deg = full_max;
   else
@@ -157,7 +158,7 @@ Blk Builder::clean(const Blk &a) {
 
 Blk Builder::tame(const Blk &a, int64_t coef) {
   if (a.trivial()) return a;
-  if (a.noise * (double)(coef * coef) > kNoiseCap / 2) return clean(a);
+  if (a.noise * (double)(coef * coef) > noise_cap_ / 2) return clean(a);
   return a;
 }
 

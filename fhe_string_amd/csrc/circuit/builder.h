@@ -88,12 +88,15 @@ class Builder {
 
   Program finish(const std::vector<Blk> &outputs, const std::string &name);
 
-  static constexpr double kNoiseCap = 256.0;
+  // largest input variance of a lookup, in units of one fresh PBS output:
+  // 256 for the classic set (sigma_f = 2^49), 34 for the multi-bit sets (sigma_f = 2^50.6)
+  double noise_cap() const { return noise_cap_; }
 
  private:
   int32_t lut_id(const Table &t);
   fhes_params p_;
   int32_t n_inputs_;
+  double noise_cap_;
   std::vector<Node> nodes_;
   std::vector<Table> luts_;
   std::map<Table, int32_t> lut_index_;

@@ -53,12 +53,12 @@ Blk Ops::bitor_(const Blk &x, const Blk &y) {
 }
 
 // chunks of booleans whose sum stays a valid lookup input
-static std::vector<std::vector<Blk>> bool_chunks(const std::vector<Blk> &v, int space) {
+static std::vector<std::vector<Blk>> bool_chunks(const std::vector<Blk> &v, int space, double cap) {
   std::vector<std::vector<Blk>> out;
   std::vector<Blk> cur;
   double noise = 0;
   for (const Blk &x : v) {
-    if ((int)cur.size() == space - 1 || noise + x.noise > Builder::kNoiseCap) {
+    if ((int)cur.size() == space - 1 || noise + x.noise > cap) {
       out.push_back(cur);
       cur.clear();
       noise = 0;
@@ -83,7 +83,7 @@ Blk Ops::all_true(std::vector<Blk> v) {
   if (w.empty()) return b.trivial(1);
   while (w.size() > 1) {
     std::vector<Blk> next;
-    for (auto &chunk : bool_chunks(w, b.space())) {
+    for (auto &chunk : bool_chunks(w, b.space(), b.noise_cap())) {
       if (chunk.size() == 1) { next.push_back(chunk[0]); continue; }
       Blk s = chunk[0];
       for (size_t i = 1; i < chunk.size(); i++) s = b.add(s, chunk[i]);
@@ -108,7 +108,7 @@ Blk Ops::any_true(std::vector<Blk> v) {
   if (w.empty()) return b.trivial(0);
   while (w.size() > 1) {
     std::vector<Blk> next;
-    for (auto &chunk : bool_chunks(w, b.space())) {
+    for (auto &chunk : bool_chunks(w, b.space(), b.noise_cap())) {
       if (chunk.size() == 1) { next.push_back(chunk[0]); continue; }
       Blk s = chunk[0];
       for (size_t i = 1; i < chunk.size(); i++) s = b.add(s, chunk[i]);
@@ -141,13 +141,32 @@ Blk Ops::eq(const Radix &x, const Radix &y) {
       const uint64_t c = (uint64_t)px.cst;
       e.push_back(b.pbs(py, [c](uint64_t v) { return v == c ? 1 : 0; }));
     } else {
-      if (px.noise + py.noise > Builder::kNoiseCap) throw std::logic_error("eq: operands too noisy");
+      fit_packed_pair(xs, ys, px, py);
       Blk diff = b.sub_raw(px, py);
       e.push_back(b.pbs(diff, [](uint64_t v) { return v == 0 ? 1 : 0; }, /*signed_input=*/true));
       e.back().deg = 1;
     }
   }
   return all_true(e);
+}
+
+// The signed difference of two packed pairs is one lookup input: if it would carry more than the
+// noise cap, re-bootstrap the noisiest blocks first (all four clean: 2 * (1 + M*M) units).
+void Ops::fit_packed_pair(Radix &xs, Radix &ys, Blk &px, Blk &py) {
+  for (int guard = 0; px.noise + py.noise > b.noise_cap() && guard < 8; ++guard) {
+    Blk *worst = nullptr;
+    double w = 0;
+    for (Radix *r : {&xs, &ys})
+      for (size_t i = 0; i < r->size(); i++) {
+        const double c = (i == 0 ? 1.0 : (double)M * M) * (*r)[i].noise;
+        if (!(*r)[i].trivial() && (*r)[i].noise > 1.0 && c > w) { w = c; worst = &(*r)[i]; }
+      }
+    if (!worst) break;
+    *worst = b.clean(*worst);
+    px = pack_pairs(xs)[0];
+    py = pack_pairs(ys)[0];
+  }
+  if (px.noise + py.noise > b.noise_cap()) throw std::logic_error("packed comparison: operands too noisy for this parameter set");
 }
 
 std::vector<Blk> Ops::pack_pairs(const Radix &x) {
@@ -235,7 +254,11 @@ Blk Ops::cmp(const Radix &x, const Radix &y, Cmp op) {
       // x - y in (-16, 16) uses the padding bit: the lookup of a negative value returns
       // -f(.), so f = [v != 0] yields {-1, 0, +1}; adding 1 gives the sign encoding.
       Blk pxj = px[j], pyj = py[j];
-      if (pxj.noise + pyj.noise > Builder::kNoiseCap) throw std::logic_error("cmp: operands too noisy");
+      {
+        const size_t lo = 2 * j, hi = std::min(x.size(), 2 * j + 2);
+        Radix xs(x.begin() + lo, x.begin() + hi), ys(y.begin() + lo, y.begin() + hi);
+        fit_packed_pair(xs, ys, pxj, pyj);
+      }
       Blk diff = b.sub_raw(pxj, pyj);
       Blk r = b.pbs(diff, [](uint64_t v) { return v != 0 ? 1 : 0; }, /*signed_input=*/true);
       Blk s = b.add_const(r, 1);
@@ -307,7 +330,7 @@ Radix Ops::propagate(std::vector<Blk> s) {
       continue;
     }
     if (t.deg >= (uint32_t)b.space()) throw std::logic_error("propagate: degree overflow");
-    if (t.noise > Builder::kNoiseCap) throw std::logic_error("propagate: noise overflow");
+    if (t.noise > b.noise_cap()) throw std::logic_error("propagate: noise overflow");
     out.push_back(b.pbs(t, [m](uint64_t v) { return v % m; }));
     carry = (i + 1 < s.size()) ? b.pbs(t, [m](uint64_t v) { return v / m; }) : b.trivial(0);
   }
@@ -370,7 +393,7 @@ static Radix sum_columns(Ops &o, std::vector<std::vector<Blk>> cols) {
         size_t j = i + 1;
         while (j < col.size()) {
           Blk t = b.tame(col[j], 1);
-          if (s.deg + t.deg >= (uint32_t)b.space() || s.noise + t.noise > Builder::kNoiseCap) break;
+          if (s.deg + t.deg >= (uint32_t)b.space() || s.noise + t.noise > b.noise_cap()) break;
           s = b.add(s, t);
           j++;
         }

@@ -52,6 +52,7 @@ class Ops {
  private:
   Radix propagate(std::vector<Blk> s);                     // ripple carry propagation
   std::vector<Blk> pack_pairs(const Radix &x);
+  void fit_packed_pair(Radix &xs, Radix &ys, Blk &px, Blk &py);
   Blk reduce_signs(std::vector<Blk> signs, Cmp op);
 };
 

@@ -264,7 +264,7 @@ struct S {
       for (const Radix &r : v) {
         if (r[c].trivial() && r[c].cst == 0) continue;
         Blk t = o.b.tame(r[c], 1);
-        if (acc.noise + t.noise > Builder::kNoiseCap) { acc = o.b.clean(acc); }
+        if (acc.noise + t.noise > o.b.noise_cap()) { acc = o.b.clean(acc); }
         deg = std::max(deg, std::max(acc.deg, t.deg));
         acc = o.b.add(acc, t);
         acc.deg = deg;

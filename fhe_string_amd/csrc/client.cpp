@@ -41,6 +41,8 @@ bool params_valid(const fhes_params &p, std::string *why) {
   if (p.ks_level < 1 || p.ks_base_log < 1 || p.ks_level * p.ks_base_log > 63) return bad("bad KS decomposition");
   if (p.message_bits < 1 || p.carry_bits < 0 || p.message_bits + p.carry_bits > 6) return bad("bad message/carry bits");
   if ((1 << (p.message_bits + p.carry_bits)) > p.poly_size) return bad("plaintext space larger than polynomial");
+  if (p.grouping_factor < 0 || p.grouping_factor > 3) return bad("grouping_factor must be 0/1 (classic), 2 or 3");
+  if (p.grouping_factor > 1 && p.lwe_dim % p.grouping_factor) return bad("lwe_dim must be a multiple of grouping_factor");
   return true;
 }
 
@@ -149,8 +151,30 @@ int fhes_params_default(fhes_params *o) {
   o->ks_level = 5;
   o->message_bits = 2;
   o->carry_bits = 2;
+  o->grouping_factor = 1;
   o->lwe_noise_std = 0.000007069849454709433;
   o->glwe_noise_std = 0.00000000000000029403601535432533;
+  return FHES_OK;
+}
+
+int fhes_params_multibit(fhes_params *o, int32_t g) {
+  if (!o) return fail(FHES_ERR_INVALID, "null params");
+  if (g != 2 && g != 3) return fail(FHES_ERR_INVALID, "grouping factor must be 2 or 3");
+  // PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_{2,3}_KS_PBS, tfhe-rs 0.5.  The crate is not in the
+  // container: n and the LWE noise are recalled (n = 764 / 765).  The PBS
+  // decomposition is NOT the recalled (2^18, 1 level): with it the oracle measures an output noise of
+  // 2^53 after 382 external products (rounding error 2^45 per coefficient and step), which leaves no
+  // room for a sum of bootstrapped blocks in front of the next lookup.  The classic set's (2^23, 1)
+  // gives 2^48 and is what this preset uses; fhes_params is plain data, callers may override.
+  fhes_params_default(o);
+  o->grouping_factor = g;
+  if (g == 2) {
+    o->lwe_dim = 764;
+    o->lwe_noise_std = 0.000006692125069956277;
+  } else {
+    o->lwe_dim = 765;
+    o->lwe_noise_std = 0.000006576067736703653;
+  }
   return FHES_OK;
 }
 
@@ -165,8 +189,18 @@ int fhes_params_toy(fhes_params *o) {
   o->ks_level = 5;
   o->message_bits = 2;
   o->carry_bits = 2;
+  o->grouping_factor = 1;
   o->lwe_noise_std = 0x1p-40;
   o->glwe_noise_std = 0x1p-55;
+  return FHES_OK;
+}
+
+int fhes_params_toy_multibit(fhes_params *o, int32_t g) {
+  if (!o) return fail(FHES_ERR_INVALID, "null params");
+  if (g != 2 && g != 3) return fail(FHES_ERR_INVALID, "grouping factor must be 2 or 3");
+  fhes_params_toy(o);
+  o->grouping_factor = g;
+  o->lwe_dim = g == 2 ? 32 : 33;
   return FHES_OK;
 }
 
@@ -174,7 +208,9 @@ int64_t fhes_ct_words(const fhes_params *p) { return p ? (int64_t)p->glwe_dim * 
 int64_t fhes_bsk_words(const fhes_params *p) {
   if (!p) return -1;
   int64_t kp1 = p->glwe_dim + 1;
-  return (int64_t)p->lwe_dim * p->pbs_level * kp1 * kp1 * p->poly_size;
+  const int g = p->grouping_factor > 1 ? p->grouping_factor : 1;
+  const int64_t n_ggsw = g > 1 ? (int64_t)(p->lwe_dim / g) << g : p->lwe_dim;
+  return n_ggsw * p->pbs_level * kp1 * kp1 * p->poly_size;
 }
 int64_t fhes_ksk_words(const fhes_params *p) {
   if (!p) return -1;
@@ -241,11 +277,23 @@ int fhes_client_key_make_server_keys(const fhes_client_key *ck, uint64_t *bsk, u
       if (ck->big_sk[(size_t)c * N + i]) ones[c].push_back(i);
 
   // ---- bootstrapping key: GGSW(s_small[i]) rows --------------------------------------
-  const long rows = (long)n * L * kp1;
+  // classic: GGSW i encrypts s_i.  multi-bit (grouping factor g): GGSW (group j, c) encrypts
+  // prod_t [s_{jg+t} == bit (g-1-t) of c]  (tfhe-rs generate_lwe_multi_bit_bootstrap_key)
+  const int gf = ck->p.grouping_factor > 1 ? ck->p.grouping_factor : 1;
+  const long n_ggsw = gf > 1 ? (long)(n / gf) << gf : n;
+  auto ggsw_plaintext = [&](long i) -> uint64_t {
+    if (gf == 1) return ck->small_sk[i];
+    const long j = i >> gf;
+    const int c = (int)(i & ((1 << gf) - 1));
+    uint64_t v = 1;
+    for (int t = 0; t < gf; t++) v &= (ck->small_sk[j * gf + t] == (uint64_t)((c >> (gf - 1 - t)) & 1)) ? 1u : 0u;
+    return v;
+  };
+  const long rows = n_ggsw * L * kp1;
   unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   auto bsk_worker = [&](unsigned tid) {
     for (long row_id = tid; row_id < rows; row_id += nthreads) {
-      const int i = (int)(row_id / (L * kp1));
+      const long i = row_id / (L * kp1);
       const int l = (int)((row_id / kp1) % L);
       const int row = (int)(row_id % kp1);
       uint64_t *glwe = bsk + (size_t)row_id * kp1 * N;  // [kp1][N]
@@ -261,7 +309,7 @@ int fhes_client_key_make_server_keys(const fhes_client_key *ck, uint64_t *bsk, u
           for (int j = N - s; j < N; j++) body[j + s - N] -= a[j];
         }
       }
-      if (ck->small_sk[i]) {
+      if (ggsw_plaintext(i)) {
         const uint64_t g_l = 1ull << (64 - d.pbs_base_log * (l + 1));
         glwe[(size_t)row * N] += g_l;
       }

@@ -33,10 +33,11 @@ struct fhes_ctx {
   uint64_t *ksk = nullptr;   // [big][ks_level][ks_stride]
   uint64_t *ksk_bias = nullptr;  // [ks_stride]: (B/2) * sum_{i,l} ksk[i][l][j]  (biased-digit keyswitch)
   int ks_stride = 0;
-  double2 *bsk_f = nullptr;  // canonical [n][2][2][M]
-  double2 *bsk_e = nullptr;  // engine layout for blind-rotate variants 2/3: [n][2][2][8][M/8]
+  double2 *bsk_f = nullptr;  // canonical [n_ggsw][2][2][M]   (multi-bit: [n/g][2^g][2][2][M])
+  double2 *bsk_e = nullptr;  // engine layout for blind-rotate variants 2/3 and multi-bit: [n_ggsw][2][2][8][M/8]
   double2 *twist = nullptr, *tw = nullptr;
   double2 *twist_inv = nullptr;  // twist * (2/N): untwist factors with the inverse-FFT scale folded in
+  double2 *root = nullptr;       // multi-bit only: exp(i*pi*t/N), t < 2N (Fourier image of a monomial)
 
   // LUT registry
   uint64_t *lut_polys = nullptr;  // [lut_capacity][N]

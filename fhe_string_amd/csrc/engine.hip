@@ -55,6 +55,7 @@ static bool kernels_support(const fhes_params &p, std::string *why) {
   if (p.poly_size != 2048 && p.poly_size != 256) { *why = "HIP kernels are instantiated for poly_size 2048 (and 256 for tests)"; return false; }
   if (p.ks_level > dev::KS_MAXLV || p.ks_base_log > 7) { *why = "keyswitch decomposition too large"; return false; }
   if (p.lwe_dim + 1 > 1024) { *why = "lwe_dim too large"; return false; }
+  if (p.grouping_factor > 3) { *why = "HIP kernels support grouping factors 2 and 3"; return false; }
   return true;
 }
 
@@ -221,9 +222,32 @@ static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d, unsigned long lon
   return FHES_OK;
 }
 
+template <int LOGN, int G>
+static int launch_br_mb(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  constexpr int N = 1 << LOGN, M = N / 2;
+  const int n_deg = (ctx->dims.n / G) * ((1 << G) - 1);
+  const size_t lds = (size_t)2 * M * 16 + (size_t)(M / 2) * 16 + (size_t)((n_deg + 7) & ~7) * 2;
+  auto kern = dev::blind_rotate_mb_kernel<LOGN, 23, G>;
+  const unsigned bit = 8 + G;
+  if (!(ctx->attr_done & (1u << bit))) {
+    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ctx->attr_done |= 1u << bit;
+  }
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
+                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
+                     ctx->lut_polys, ctx->twist, ctx->twist_inv, ctx->tw, ctx->root);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
 // variant: 0 = auto (latency kernel for launches that fit one workgroup per CU, throughput
 // kernel otherwise), 1 / 2 / 3 = force
 static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  if (ctx->dims.g > 1) {  // multi-bit parameter sets have one kernel
+    if (ctx->dims.N == 2048) return ctx->dims.g == 2 ? launch_br_mb<11, 2>(ctx, d) : launch_br_mb<11, 3>(ctx, d);
+    return ctx->dims.g == 2 ? launch_br_mb<8, 2>(ctx, d) : launch_br_mb<8, 3>(ctx, d);
+  }
   int variant = ctx->br_variant;
   if (variant == 0) variant = d.v_count <= ctx->n_cus ? 2 : 3;  // v2: 3.4 ms alone; v3: 2 per CU in 6.3 ms
   if (ctx->dims.N == 2048)
@@ -403,6 +427,21 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
     if ((e = hipMalloc(&ctx->twist_inv, ti.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(twist_inv)");
     if ((e = hipMemcpy(ctx->twist_inv, ti.data(), ti.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy twist_inv");
   }
+  if (d.g > 1) {  // Fourier images of monomials (oracle: same cosl/sinl, same exact entries)
+    std::vector<double> root((size_t)4 * d.N);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int t = 0; t < 2 * d.N; t++) {
+      const long double a = pi * (long double)t / (long double)d.N;
+      root[2 * t] = (double)cosl(a);
+      root[2 * t + 1] = (double)sinl(a);
+    }
+    root[0] = 1.0; root[1] = 0.0;
+    root[2 * (d.N / 2)] = 0.0; root[2 * (d.N / 2) + 1] = 1.0;
+    root[2 * d.N] = -1.0; root[2 * d.N + 1] = 0.0;
+    root[2 * (3 * d.N / 2)] = 0.0; root[2 * (3 * d.N / 2) + 1] = -1.0;
+    if ((e = hipMalloc(&ctx->root, root.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(root)");
+    if ((e = hipMemcpy(ctx->root, root.data(), root.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy root");
+  }
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
     static uint64_t next_uid = 1;
@@ -421,7 +460,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
-  (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->lut_polys);
+  (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->root); (void)hipFree(ctx->lut_polys);
   (void)hipFree(ctx->ks_out); (void)hipFree(ctx->desc_buf);
   for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
   for (auto &ev : ctx->ev_free) (void)hipEventDestroy(ev);
@@ -452,7 +491,7 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
   }
   // bootstrapping key -> Fourier domain on the device
   {
-    const size_t npoly = (size_t)d.n * 4;
+    const size_t npoly = (size_t)d.n_ggsw * 4;
     uint64_t *tmp = nullptr;
     FHES_HIP(hipMalloc(&tmp, npoly * d.N * 8));
     FHES_HIP(hipMemcpy(tmp, bsk, npoly * d.N * 8, hipMemcpyHostToDevice));
@@ -592,7 +631,7 @@ int fhes_debug_bsk_fourier(fhes_ctx *ctx, double *out) {
   if (!ctx || !out) return fail(FHES_ERR_INVALID, "null argument");
   if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
   FHES_HIP(hipSetDevice(ctx->device));
-  FHES_HIP(hipMemcpy(out, ctx->bsk_f, (size_t)ctx->dims.n * 4 * ctx->dims.M * 16, hipMemcpyDeviceToHost));
+  FHES_HIP(hipMemcpy(out, ctx->bsk_f, (size_t)ctx->dims.n_ggsw * 4 * ctx->dims.M * 16, hipMemcpyDeviceToHost));
   return FHES_OK;
 }
 

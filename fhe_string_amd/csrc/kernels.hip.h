@@ -934,6 +934,221 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   if (tid == 0) out[N] = acc[N];
 }
 
+// ------------------------------------------------------------------------------------------
+// K4: multi-bit blind rotate (grouping factor G = 2 or 3) + sample extract.  Same transforms,
+// rounding and FMA chains as the classic kernels, different step:
+//     bundle = G_0 + sum_{c=1}^{2^G-1} G_c * X^{deg_c}      (Fourier domain, c ascending)
+//     acc   <- bundle (x) acc                                (digits of acc itself; replaced)
+// with deg_c = modswitch(sum_t bit_{G-1-t}(c) * a_{jG+t}) -- the u64 mask elements are summed
+// first, then switched.  The accumulator never needs an LDS image (no rotation inside the loop):
+// it lives in registers; LDS holds only the FFT exchange buffer, the stage twiddles and the degrees.
+// Mapping as variant 3: 256 threads = two halves (output polynomial r) x 128 threads x 8 points,
+// two workgroups per CU.  Every exchange is written in place (a thread writes the slots it read),
+// so an iteration has 6 barriers and none at its end.
+// The Fourier image of X^d at spectrum slot p is root[(E(p) * d) mod 2N], E(p) = 1 - 4*bitrev(p),
+// root[t] = exp(i*pi*t/N): slot p holds the evaluation at twist * exp(-2*pi*i*bitrev(p)/M).
+// LDS: fbuf double2[2][M] | stage twiddle tables double2[M/2] | degrees u16[(n/G) * (2^G - 1)]
+// ------------------------------------------------------------------------------------------
+typedef unsigned int fhes_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  const fhes_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
+
+// acc += g * w with the operation order of cmul
+__device__ __forceinline__ double2 cfma(double2 g, double2 w, double2 acc) {
+  double re = __builtin_fma(g.x, w.x, acc.x);
+  re = __builtin_fma(-g.y, w.y, re);
+  double im = __builtin_fma(g.x, w.y, acc.y);
+  im = __builtin_fma(g.y, w.x, im);
+  return make_double2(re, im);
+}
+
+template <int LOGN, int BL, int G>
+__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_mb_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
+    int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
+    const double2 *__restrict__ twist, const double2 *__restrict__ twist_inv /* twist / M */,
+    const double2 *__restrict__ tw, const double2 *__restrict__ root /* [2N] */) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
+  constexpr int NP = (LOGM - 1) / 3, NC = 1 << G;
+  static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw);                                 // [2][M]
+  double2 *T = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * M * 16);               // [M/2] stage tables
+  uint16_t *degs = reinterpret_cast<uint16_t *>(smem_raw + (size_t)2 * M * 16 + (size_t)(M / 2) * 16);
+
+  const int tid = threadIdx.x;
+  const int r = tid / TP;
+  const int q = tid % TP;
+  const double sgn = (q & 1) ? -1.0 : 1.0;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+  const int n_groups = n_small / G;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  for (int idx = tid; idx < n_groups * (NC - 1); idx += blockDim.x) {
+    const int j = idx / (NC - 1), c = idx % (NC - 1) + 1;
+    uint64_t sum = 0;
+#pragma unroll
+    for (int t = 0; t < G; ++t)
+      if ((c >> (G - 1 - t)) & 1) sum += ks[j * G + t];
+    degs[idx] = (uint16_t)((((sum >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  }
+  for (int idx = 2 + tid; idx < M / 2; idx += blockDim.x) {
+    const int beta = 31 - __builtin_clz(idx);  // idx = 2^beta + j
+    T[idx] = tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
+  }
+  __syncthreads();
+
+  constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
+  double2 wtop[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) wtop[e] = tw[fft_point<LOGM, LO_A, 3>(q, e) & (M / 2 - 1)];
+  const double2 *twist_q = twist + q;
+  const double2 *twist_inv_q = twist_inv + q;
+  const __amdgpu_buffer_rsrc_t rs_g =
+      __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_groups * NC * 4 * M * 16), 0x00020000);
+  const unsigned voff_g = (unsigned)(r * 8 * TP + q) * 16u;  // G[((row*2 + r)*8 + e)*TP + q]
+  int sexp[8];  // E(p) of the slots this thread holds when the external product runs
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int p = fft_point<LOGM, LO_C, 3>(q, e);
+    const int f = (int)(__brev((unsigned)p) >> (32 - LOGM));
+    sexp[e] = (1 - 4 * f) & (2 * N - 1);
+  }
+
+  // ---- acc = (0, X^{-b~} * LUT), in registers: coefficients p and p + M of polynomial r ----
+  uint64_t own_lo[8], own_hi[8];
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int bt = (int)((((ks[n_small] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+    const int t = (2 * N - bt) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      own_lo[e] = v0;
+      own_hi[e] = v1;
+    }
+  }
+
+  double2 *buf_r = fbuf + (size_t)r * M;
+  const double2 *buf_o = fbuf + (size_t)(1 - r) * M;
+
+  for (int j = 0; j < n_groups; ++j) {
+    // ---- bundle, column r: b0 = row 0, b1 = row 1 ----
+    double2 b0[8], b1[8];
+    {
+      const unsigned so = (unsigned)j * (unsigned)(NC * 4 * M * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        b0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
+        b1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
+      }
+#pragma unroll
+      for (int c = 1; c < NC; ++c) {
+        const int deg = (int)degs[j * (NC - 1) + (c - 1)];
+        const unsigned soc = so + (unsigned)c * (unsigned)(4 * M * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const double2 w = root[(sexp[e] * deg) & (2 * N - 1)];
+          const double2 g0 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((0 * 16 + e) * TP * 16));
+          const double2 g1 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((1 * 16 + e) * TP * 16));
+          b0[e] = cfma(g0, w, b0[e]);
+          b1[e] = cfma(g1, w, b1[e]);
+        }
+      }
+    }
+
+    // ---- digits of the accumulator -> twist ----
+    double2 x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      x[e] = cmul(make_double2(digit1_f64<BL>(own_lo[e]), digit1_f64<BL>(own_hi[e])), twist_q[e * TP]);
+
+    // ---- forward FFT ----
+    fft_butterflies_tab<LOGM, true, LO_A>(x, q, T, wtop);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+    fft_butterflies_tab<LOGM, true, LO_B>(x, q, T, wtop);
+    if (NP == 3) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
+      fft_butterflies_tab<LOGM, true, LO_C>(x, q, T, wtop);
+    }
+    fft_stage_bit0_dpp(x, sgn);
+
+    // ---- spectra exchanged in place, external product with the bundle ----
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], buf_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], b0[e], b1[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(buf_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], x[e], b0[e], b1[e]);
+    }
+    double2 twi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) twi[e] = twist_inv_q[e * TP];
+    __syncthreads();  // the other half has read my spectrum
+
+    // ---- inverse FFT ----
+    fft_stage_bit0_dpp(x, sgn);
+    if (NP == 3) {
+      fft_butterflies_tab<LOGM, false, LO_C>(x, q, T, wtop);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+    }
+    fft_butterflies_tab<LOGM, false, LO_B>(x, q, T, wtop);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
+    fft_butterflies_tab<LOGM, false, LO_A>(x, q, T, wtop);
+
+    // ---- untwist, round to the torus: the new accumulator ----
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double2 v = cmul_conj(x[e], twi[e]);
+      own_lo[e] = torus_from_f64_fast(v.x);
+      own_hi[e] = torus_from_f64_fast(v.y);
+    }
+    // no barrier: the next write into fbuf goes to the slots this thread has just read
+  }
+
+  // ---- sample extract from registers: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int p = fft_point<LOGM, LO_A, 3>(q, e);
+    if (r == 0) {
+      if (p == 0) out[0] = own_lo[e];
+      else out[N - p] = (uint64_t)0 - own_lo[e];
+      out[N - (p + M)] = (uint64_t)0 - own_hi[e];
+    } else if (p == 0) {
+      out[N] = own_lo[e];
+    }
+  }
+}
+
 // engine layout of the Fourier BSK for variant 2: [poly][e][q] with the point
 // p = fft_point<LOGM, LO_last3, 3>(q, e) of the last 3-bit pass (the layout the spectrum
 // is in when the external product runs).  grid = polynomials, block = M/8.

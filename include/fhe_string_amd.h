@@ -46,7 +46,8 @@ extern "C" {
 #define FHES_ERR_PAD_TOO_LONG -13
 #define FHES_ERR_PAD_TOO_SHORT -14
 
-/* ---- parameters (tfhe ClassicPBSParameters; /root/reference/src/lib.rs:45,50) ---------- */
+/* ---- parameters (tfhe ClassicPBSParameters; /root/reference/src/lib.rs:45,50; with
+ * grouping_factor >= 2: tfhe MultiBitPBSParameters, BASELINE.json config 5) ----------------- */
 typedef struct fhes_params {
   int32_t lwe_dim;       /* n   */
   int32_t glwe_dim;      /* k   */
@@ -57,14 +58,22 @@ typedef struct fhes_params {
   int32_t ks_level;
   int32_t message_bits;  /* log2(message_modulus) */
   int32_t carry_bits;    /* log2(carry_modulus)   */
+  int32_t grouping_factor; /* 0 or 1: classic PBS; 2 or 3: multi-bit PBS (n % g == 0)        */
   double lwe_noise_std;
   double glwe_noise_std;
 } fhes_params;
 
 /* PARAM_MESSAGE_2_CARRY_2_KS_PBS (the set the reference fixes at lib.rs:45). */
 int fhes_params_default(fhes_params *out);
-/* Small set for CPU-only tests (N=256, n=48, tiny noise).  Not secure. */
+/* Small set for CPU-only tests (N=256, n=32, tiny noise).  Not secure. */
 int fhes_params_toy(fhes_params *out);
+/* PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_{2,3}_KS_PBS of tfhe-rs 0.5 (g = 2 or 3).  The
+ * reference cannot select these (lib.rs:50 takes ClassicPBSParameters); BASELINE.json config 5
+ * asks for them.  Key layout: BSK u64[n/g][2^g][level][k+1][k+1][N], GGSW c of a group encrypts
+ * prod_t [s_t == bit (g-1-t) of c]. */
+int fhes_params_multibit(fhes_params *out, int32_t grouping_factor);
+/* toy-sized multi-bit set for CPU-only tests (g = 2: n = 32, g = 3: n = 33).  Not secure. */
+int fhes_params_toy_multibit(fhes_params *out, int32_t grouping_factor);
 /* Words of one big-key LWE ciphertext (k*N + 1). */
 int64_t fhes_ct_words(const fhes_params *p);
 int64_t fhes_bsk_words(const fhes_params *p);

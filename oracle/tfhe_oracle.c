@@ -23,8 +23,12 @@ struct oracle_ctx {
   int big;            /* k*N */
   cplx *twist;        /* [M]   exp(+i*pi*j/N)          */
   cplx *tw;           /* [M/2] exp(-2*pi*i*t/M)        */
-  cplx *bsk_f;        /* [n][L][k+1][k+1][M]           */
+  cplx *bsk_f;        /* [n_ggsw][L][k+1][k+1][M]      */
   uint64_t *ksk;      /* [big][ks_level][n+1]          */
+  int g;              /* grouping factor (1 = classic) */
+  long n_ggsw;        /* n, or (n/g) * 2^g             */
+  cplx *root;         /* [2N] exp(+i*pi*t/N)  (multi-bit: Fourier image of a monomial) */
+  int32_t *slot_exp;  /* [M]  slot m of a spectrum is the evaluation at root^slot_exp[m] */
 };
 
 /* ---- canonical complex arithmetic ------------------------------- */
@@ -137,6 +141,31 @@ oracle_ctx *oracle_ctx_create(const oracle_params *p) {
   c->twist[0].re = 1.0; c->twist[0].im = 0.0;
   c->tw[0].re = 1.0; c->tw[0].im = 0.0;
   if (c->M >= 4) { c->tw[c->M / 4].re = 0.0; c->tw[c->M / 4].im = -1.0; }
+  c->g = p->grouping_factor > 1 ? p->grouping_factor : 1;
+  if (c->g > 3 || c->n % c->g) { oracle_ctx_destroy(c); return NULL; }
+  c->n_ggsw = c->g > 1 ? (long)(c->n / c->g) << c->g : c->n;
+  /* multi-bit tables.  The forward transform evaluates a polynomial at
+   *   x_f = twist * exp(-2 pi i f / M) = exp(i pi (1 - 4 f) / N),  f = 0 .. M-1,
+   * and stores the result bit-reversed (slot m holds f = bitrev(m)); X^d therefore has the
+   * spectrum root[(slot_exp[m] * d) mod 2N] with root[t] = exp(i pi t / N). */
+  c->root = (cplx *)malloc(sizeof(cplx) * 2 * c->N);
+  c->slot_exp = (int32_t *)malloc(sizeof(int32_t) * c->M);
+  for (int t = 0; t < 2 * c->N; t++) {
+    long double a = pi * (long double)t / (long double)c->N;
+    c->root[t].re = (double)cosl(a);
+    c->root[t].im = (double)sinl(a);
+  }
+  c->root[0].re = 1.0; c->root[0].im = 0.0;
+  c->root[c->N / 2].re = 0.0; c->root[c->N / 2].im = 1.0;
+  c->root[c->N].re = -1.0; c->root[c->N].im = 0.0;
+  c->root[3 * c->N / 2].re = 0.0; c->root[3 * c->N / 2].im = -1.0;
+  int logm = 0;
+  while ((1 << logm) < c->M) logm++;
+  for (int m = 0; m < c->M; m++) {
+    int f = 0;
+    for (int b = 0; b < logm; b++) f |= ((m >> b) & 1) << (logm - 1 - b);
+    c->slot_exp[m] = (int32_t)(((1 - 4 * f) % (2 * c->N) + 2 * c->N) % (2 * c->N));
+  }
   return c;
 }
 
@@ -146,12 +175,14 @@ void oracle_ctx_destroy(oracle_ctx *c) {
   free(c->tw);
   free(c->bsk_f);
   free(c->ksk);
+  free(c->root);
+  free(c->slot_exp);
   free(c);
 }
 
 int oracle_set_keys(oracle_ctx *c, const uint64_t *bsk, const uint64_t *ksk) {
   const int kp1 = c->k + 1;
-  size_t npoly = (size_t)c->n * c->L * kp1 * kp1;
+  size_t npoly = (size_t)c->n_ggsw * c->L * kp1 * kp1;
   free(c->bsk_f);
   free(c->ksk);
   c->bsk_f = (cplx *)malloc(sizeof(cplx) * npoly * c->M);
@@ -170,6 +201,8 @@ int oracle_set_keys(oracle_ctx *c, const uint64_t *bsk, const uint64_t *ksk) {
 const double *oracle_bsk_fourier(const oracle_ctx *c) { return (const double *)c->bsk_f; }
 const double *oracle_twist_table(const oracle_ctx *c) { return (const double *)c->twist; }
 const double *oracle_twiddle_table(const oracle_ctx *c) { return (const double *)c->tw; }
+const double *oracle_root_table(const oracle_ctx *c) { return (const double *)c->root; }
+const int32_t *oracle_slot_exp_table(const oracle_ctx *c) { return c->slot_exp; }
 
 void oracle_fft_forward_i64(const oracle_ctx *c, const int64_t *poly, double *spec) {
   poly_fwd(c, poly, (cplx *)spec);
@@ -318,6 +351,90 @@ void oracle_blind_rotate(const oracle_ctx *c, const uint32_t *at, const uint64_t
   free(rot); free(dig); free(D); free(O); free(delta);
 }
 
+/* Multi-bit blind rotate (tfhe-rs multi_bit_blind_rotate_assign, deterministic order).
+ * `small` is the keyswitched ciphertext BEFORE the modulus switch: the monomial degree of GGSW c
+ * of group j is modswitch(sum_t bit_t(c) * a_{jg+t}) -- sum first (mod 2^64), then switch.
+ *   bundle[row][col] = G_0 + sum_{c>=1} G_c * X^{deg_c}        (Fourier domain, c ascending,
+ *                      complex fused multiply-adds in the order of cmul)
+ *   acc <- bundle (x) acc : D_row = FFT(digits(acc[row])), out[col] = sum_row D_row*bundle[row][col],
+ *   acc[col] = round(IFFT(out[col]))  -- replaced, not accumulated.   (pbs_level == 1) */
+static inline uint32_t modswitch1(uint64_t v, int log2n) {
+  return (uint32_t)((((v >> (64 - log2n - 1)) + 1) >> 1) & (((uint64_t)1 << log2n) - 1));
+}
+
+void oracle_blind_rotate_multibit(const oracle_ctx *c, const uint64_t *small, const uint64_t *lut,
+                                  uint64_t *acc) {
+  const int N = c->N, M = c->M, k = c->k, kp1 = k + 1, L = c->L, n = c->n, g = c->g;
+  const int bl = c->p.pbs_base_log, total = bl * L, nc = 1 << g;
+  int log2n = 0;
+  while ((1 << log2n) < 2 * N) log2n++;
+  int64_t *dig = (int64_t *)malloc(sizeof(int64_t) * N * L);
+  cplx *D = (cplx *)malloc(sizeof(cplx) * M * kp1 * L);
+  cplx *Bn = (cplx *)malloc(sizeof(cplx) * M * kp1 * kp1 * L);
+  cplx *O = (cplx *)malloc(sizeof(cplx) * M);
+  const int64_t B = 1ll << bl;
+
+  memset(acc, 0, sizeof(uint64_t) * N * k);
+  poly_rotate(N, lut, (2 * N - (int)modswitch1(small[n], log2n)) % (2 * N), acc + (size_t)k * N);
+
+  for (int j = 0; j < n / g; j++) {
+    /* bundle */
+    const cplx *G0 = c->bsk_f + (size_t)j * nc * L * kp1 * kp1 * M;
+    memcpy(Bn, G0, sizeof(cplx) * M * kp1 * kp1 * L);
+    for (int cc = 1; cc < nc; cc++) {
+      uint64_t sum = 0;
+      for (int t = 0; t < g; t++)
+        if ((cc >> (g - 1 - t)) & 1) sum += small[(size_t)j * g + t];
+      const int deg = (int)modswitch1(sum, log2n);
+      const cplx *Gc = G0 + (size_t)cc * L * kp1 * kp1 * M;
+      for (int q = 0; q < L * kp1 * kp1; q++)
+        for (int m = 0; m < M; m++) {
+          const cplx w = c->root[(int)(((long)c->slot_exp[m] * deg) % (2 * N))];
+          const cplx x = Gc[(size_t)q * M + m];
+          cplx *b = Bn + (size_t)q * M + m;
+          b->re = fma(x.re, w.re, b->re);
+          b->re = fma(-x.im, w.im, b->re);
+          b->im = fma(x.re, w.im, b->im);
+          b->im = fma(x.im, w.re, b->im);
+        }
+    }
+    /* digits of the accumulator itself */
+    for (int cc = 0; cc < kp1; cc++) {
+      const uint64_t *ac = acc + (size_t)cc * N;
+      for (int jj = 0; jj < N; jj++) {
+        uint64_t v = ((ac[jj] >> (64 - total - 1)) + 1) >> 1;
+        v &= (1ull << total) - 1;
+        for (int l = L - 1; l >= 0; l--) {
+          int64_t d = (int64_t)(v & (uint64_t)(B - 1));
+          v >>= bl;
+          if (d >= B / 2) { d -= B; v += 1; }
+          dig[(size_t)l * N + jj] = d;
+        }
+      }
+      for (int l = 0; l < L; l++) poly_fwd(c, dig + (size_t)l * N, D + ((size_t)cc * L + l) * M);
+    }
+    for (int col = 0; col < kp1; col++) {
+      for (int m = 0; m < M; m++) {
+        double re = 0, im = 0;
+        int first = 1;
+        for (int row = 0; row < kp1; row++)
+          for (int l = 0; l < L; l++) {
+            const cplx d = D[((size_t)row * L + l) * M + m];
+            const cplx gg = Bn[(((size_t)l * kp1 + row) * kp1 + col) * M + m];
+            if (first) { re = d.re * gg.re; im = d.re * gg.im; first = 0; }
+            else { re = fma(d.re, gg.re, re); im = fma(d.re, gg.im, im); }
+            re = fma(-d.im, gg.im, re);
+            im = fma(d.im, gg.re, im);
+          }
+        O[m].re = re;
+        O[m].im = im;
+      }
+      poly_inv(c, O, acc + (size_t)col * N); /* every digit of this step is already in D */
+    }
+  }
+  free(dig); free(D); free(Bn); free(O);
+}
+
 void oracle_sample_extract(const oracle_ctx *c, const uint64_t *glwe, uint64_t *out) {
   const int N = c->N, k = c->k;
   for (int cc = 0; cc < k; cc++) {
@@ -333,8 +450,12 @@ void oracle_pbs(const oracle_ctx *c, const uint64_t *in, const uint64_t *lut, ui
   uint32_t *at = (uint32_t *)malloc(sizeof(uint32_t) * (c->n + 1));
   uint64_t *glwe = (uint64_t *)malloc(sizeof(uint64_t) * (c->k + 1) * c->N);
   oracle_keyswitch(c, in, small);
-  oracle_modswitch(c, small, at);
-  oracle_blind_rotate(c, at, lut, glwe);
+  if (c->g > 1) {
+    oracle_blind_rotate_multibit(c, small, lut, glwe);
+  } else {
+    oracle_modswitch(c, small, at);
+    oracle_blind_rotate(c, at, lut, glwe);
+  }
   oracle_sample_extract(c, glwe, out);
   free(small); free(at); free(glwe);
 }

@@ -44,6 +44,7 @@ typedef struct {
   int32_t ks_level;      /* 5                                            */
   int32_t message_bits;  /* 2                                            */
   int32_t carry_bits;    /* 2                                            */
+  int32_t grouping_factor; /* 0/1: classic CMUX blind rotate; 2/3: multi-bit */
   double lwe_noise_std;  /* std-dev relative to the torus (7.07e-6)      */
   double glwe_noise_std; /* 2.94e-16                                     */
 } oracle_params;
@@ -54,7 +55,8 @@ oracle_ctx *oracle_ctx_create(const oracle_params *p);
 void oracle_ctx_destroy(oracle_ctx *c);
 
 /* Key material, standard domain.
- *   bsk: u64 [n][pbs_level][k+1 (row)][k+1 (component)][N]
+ *   bsk: u64 [n][pbs_level][k+1 (row)][k+1 (component)][N]   (classic)
+ *        u64 [n/g][2^g][pbs_level][k+1][k+1][N]               (multi-bit)
  *   ksk: u64 [k*N][ks_level][n+1]
  * The BSK is transformed to the Fourier domain here (canonical forward FFT). */
 int oracle_set_keys(oracle_ctx *c, const uint64_t *bsk, const uint64_t *ksk);
@@ -82,6 +84,13 @@ void oracle_modswitch(const oracle_ctx *c, const uint64_t *small /*[n+1]*/,
                       uint32_t *a_tilde /*[n+1]*/);
 void oracle_blind_rotate(const oracle_ctx *c, const uint32_t *a_tilde, const uint64_t *lut_poly,
                          uint64_t *glwe /*[k+1][N]*/);
+/* multi-bit blind rotate (grouping_factor 2 or 3); `small` is the keyswitched ciphertext
+ * u64[n+1] before the modulus switch.  BSK layout: [n/g][2^g][level][k+1][k+1][N]. */
+void oracle_blind_rotate_multibit(const oracle_ctx *c, const uint64_t *small,
+                                  const uint64_t *lut_poly, uint64_t *glwe /*[k+1][N]*/);
+/* multi-bit tables: root[2N][2] = exp(i*pi*t/N), slot_exp[N/2] */
+const double *oracle_root_table(const oracle_ctx *c);
+const int32_t *oracle_slot_exp_table(const oracle_ctx *c);
 void oracle_sample_extract(const oracle_ctx *c, const uint64_t *glwe, uint64_t *out_big);
 /* keyswitch + modswitch + blind rotate + sample extract */
 void oracle_pbs(const oracle_ctx *c, const uint64_t *in_big, const uint64_t *lut_poly,

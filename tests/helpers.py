@@ -20,10 +20,15 @@ class World:
         self.lib = _lib.load(strict=False)
         self.orc = oracle_lib.load()
         self.p = Params()
-        check(getattr(self.lib, "fhes_params_" + which)(C.byref(self.p)))
+        if which[-1] in "23" and "multibit" in which:   # "multibit2", "toy_multibit3", ...
+            check(getattr(self.lib, "fhes_params_" + which[:-1])(C.byref(self.p), int(which[-1])))
+        else:
+            check(getattr(self.lib, "fhes_params_" + which)(C.byref(self.p)))
         self.W = self.p.ct_words()
         self.N = self.p.poly_size
         self.n = self.p.lwe_dim
+        g = self.p.grouping_factor
+        self.n_ggsw = (self.n // g) << g if g > 1 else self.n   # GGSWs in the bootstrapping key
         self.ck = check_ptr(self.lib.fhes_client_key_generate(C.byref(self.p), l, seed))
         self.bsk = np.zeros(self.lib.fhes_bsk_words(C.byref(self.p)), dtype=np.uint64)
         self.ksk = np.zeros(self.lib.fhes_ksk_words(C.byref(self.p)), dtype=np.uint64)

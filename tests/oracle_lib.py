@@ -28,6 +28,9 @@ def load():
         "oracle_modswitch": (None, [_P, _P, _P]),
         "oracle_blind_rotate": (None, [_P, _P, _P, _P]),
         "oracle_sample_extract": (None, [_P, _P, _P]),
+        "oracle_blind_rotate_multibit": (None, [_P, _P, _P, _P]),
+        "oracle_root_table": (_P, [_P]),
+        "oracle_slot_exp_table": (_P, [_P]),
         "oracle_pbs": (None, [_P, _P, _P, _P]),
         "oracle_exec_levels": (C.c_int, [_P, _P, C.c_size_t, C.c_int32] + [_P] * 8 + [C.c_int32]),
         "oracle_lwe_phase": (C.c_uint64, [_P, _P, C.c_int32]),

@@ -38,6 +38,16 @@ def test_parameter_sets_and_block_counts(libs):
     assert lib.fhes_ct_words(C.byref(p)) == 2049
     assert lib.fhes_bsk_words(C.byref(p)) * 8 == 48627712
     assert lib.fhes_ksk_words(C.byref(p)) * 8 == 60866560
+    for g, n in ((2, 764), (3, 765)):                           # multi-bit presets (config 5)
+        m = Params()
+        assert lib.fhes_params_multibit(C.byref(m), g) == 0
+        assert (m.lwe_dim, m.grouping_factor, m.poly_size) == (n, g, 2048)
+        assert lib.fhes_bsk_words(C.byref(m)) == (n // g) * (1 << g) * 4 * 2048
+    assert lib.fhes_params_multibit(C.byref(Params()), 4) < 0
+    bad = Params()
+    lib.fhes_params_multibit(C.byref(bad), 2)
+    bad.lwe_dim = 765                                           # not a multiple of the grouping factor
+    assert not lib.fhes_client_key_generate(C.byref(bad), 255, 1)
     for l, bu in [(255, 4), (256, 5), (512, 5), (1024, 6), (3, 1), (63, 3)]:   # lib.rs:51-62
         ck = lib.fhes_client_key_generate(C.byref(p), l, 7)
         assert lib.fhes_client_key_num_blocks_char(ck) == 4

@@ -10,7 +10,7 @@ from tests.helpers import ptr, world
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["toy", "default"])
+@pytest.fixture(scope="module", params=["toy", "default", "toy_multibit2", "toy_multibit3", "multibit2", "multibit3"])
 def w(request, libs):
     return world(request.param)
 
@@ -28,7 +28,7 @@ def test_fft_tables_match_oracle(w):
 
 def test_bsk_fourier_bit_exact(w):
     ctx = w.ctx()
-    cnt = w.n * 4 * (w.N // 2) * 2
+    cnt = w.n_ggsw * 4 * (w.N // 2) * 2
     dev = np.zeros(cnt)
     check(w.lib.fhes_debug_bsk_fourier(ctx, ptr(dev)))
     ref = np.ctypeslib.as_array(C.cast(w.orc.oracle_bsk_fourier(w.oc), C.POINTER(C.c_double)), (cnt,))

@@ -51,15 +51,16 @@ def test_fft_roundtrip_is_exact_for_small_integers(w):
     assert np.array_equal(back.view(np.int64), a)
 
 
-@pytest.mark.parametrize("which", ["toy", "default"])
+@pytest.mark.parametrize("which", ["toy", "default", "toy_multibit2", "toy_multibit3", "multibit2", "multibit3"])
 def test_pbs_evaluates_lookup_tables(which, libs):
     ww = world(which)
     vals = np.arange(16, dtype=np.uint8)
     cts = ww.encrypt(vals)
     assert np.array_equal(ww.decrypt(cts), vals)
     fns = [lambda x: (3 * x + 5) % 16, lambda x: x % 4, lambda x: x // 4, lambda x: int(x == 9)]
-    n = 16 if which == "toy" else 4
-    for f in fns[: (4 if which == "toy" else 2)]:
+    toy = which.startswith("toy")
+    n = 16 if toy else 4
+    for f in fns[: (4 if toy else 2)]:
         _, poly = ww.lut_poly(f)
         outs = np.stack([ww.oracle_pbs(cts[i], poly) for i in range(n)])
         assert list(ww.decrypt(outs)) == [f(int(v)) for v in vals[:n]]
@@ -88,6 +89,44 @@ def test_pbs_output_noise_is_small(libs):
         e = (int(ph) - (v << 59)) % (1 << 64)
         errs.append(float(e - (1 << 64) if e >= (1 << 63) else e))
     assert max(abs(e) for e in errs) < 2.0 ** 53, errs
+
+
+@pytest.mark.parametrize("which,bound", [("multibit2", 54.0), ("multibit3", 54.0)])
+def test_multibit_pbs_output_noise(which, bound, libs):
+    """multi-bit presets: fresh output noise (measured 2^50.5 / 2^50.8) against the budget the
+    circuit builder assumes for them (noise cap 34 units)"""
+    ww = world(which)
+    vals = [3, 7, 12, 0]
+    cts = ww.encrypt(np.array(vals, dtype=np.uint8))
+    _, poly = ww.lut_poly(lambda x: x)
+    sk = np.ascontiguousarray(np.ctypeslib.as_array(C.cast(ww.lib.fhes_client_key_big_sk(ww.ck), C.POINTER(C.c_uint64)), (ww.W - 1,)))
+    for i, v in enumerate(vals):
+        out = ww.oracle_pbs(cts[i], poly)
+        ph = ww.orc.oracle_lwe_phase(ptr(out), ptr(sk), ww.W - 1)
+        e = (int(ph) - (v << 59)) % (1 << 64)
+        e = e - (1 << 64) if e >= (1 << 63) else e
+        assert abs(e) < 2.0 ** bound, (which, v, e)
+
+
+def test_multibit_tables_and_key_layout(libs):
+    """root / slot-exponent tables and the one-hot meaning of the multi-bit GGSWs"""
+    ww = world("toy_multibit2")
+    N, M = ww.N, ww.N // 2
+    root = np.ctypeslib.as_array(C.cast(ww.orc.oracle_root_table(ww.oc), C.POINTER(C.c_double)), (4 * N,)).reshape(2 * N, 2)
+    sexp = np.ctypeslib.as_array(C.cast(ww.orc.oracle_slot_exp_table(ww.oc), C.POINTER(C.c_int32)), (M,))
+    t = np.arange(2 * N)
+    assert np.allclose(root[:, 0] + 1j * root[:, 1], np.exp(1j * np.pi * t / N), atol=1e-15)
+    assert tuple(root[N]) == (-1.0, 0.0) and tuple(root[N // 2]) == (0.0, 1.0)
+    # the spectrum of the monomial X^d computed by the oracle's own forward transform equals
+    # root[(slot_exp * d) mod 2N] (up to rounding)
+    for d in (1, 5, N - 1):
+        poly = np.zeros(N, dtype=np.int64)
+        poly[d] = 1
+        spec = np.zeros(2 * M)
+        ww.orc.oracle_fft_forward_i64(ww.oc, ptr(poly), ptr(spec))
+        want = root[(sexp.astype(np.int64) * d) % (2 * N)]
+        assert np.allclose(spec.reshape(M, 2), want, atol=1e-12), d
+    assert ww.n_ggsw == (ww.n // 2) * 4 and ww.bsk.size == ww.n_ggsw * 4 * N
 
 
 SMALL = [c for c in CASES if c["op"] in ("find", "rfind", "contains", "eq", "lt", "len", "starts_with", "is_empty")
