@@ -226,7 +226,8 @@ template <int LOGN, int G>
 static int launch_br_mb(fhes_ctx *ctx, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const int n_deg = (ctx->dims.n / G) * ((1 << G) - 1);
-  const size_t lds = (size_t)2 * M * 16 + (size_t)(M / 2) * 16 + (size_t)((n_deg + 7) & ~7) * 2;
+  constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
+  const size_t lds = (size_t)2 * SLOTS * 16 + (size_t)M * 16 + (size_t)((n_deg + 7) & ~7) * 2;
   auto kern = dev::blind_rotate_mb_kernel<LOGN, 23, G>;
   const unsigned bit = 8 + G;
   if (!(ctx->attr_done & (1u << bit))) {

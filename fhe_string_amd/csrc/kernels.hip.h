@@ -965,6 +965,34 @@ __device__ __forceinline__ double2 cfma(double2 g, double2 w, double2 acc) {
   return make_double2(re, im);
 }
 
+// butterflies of a 3-bit pass, every stage's twiddles from the LDS stage tables (T[M] entries)
+template <int LOGM, bool FWD, int LO>
+__device__ __forceinline__ void fft_butterflies_tab_all(double2 (&x)[8], int q, const double2 *T) {
+#pragma unroll
+  for (int st = 0; st < 3; ++st) {
+    const int fb = FWD ? (2 - st) : st;
+    const int beta = LO + fb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e & (1 << fb)) continue;
+      const int e1 = e | (1 << fb);
+      const double2 w = T[(1 << beta) + (fft_point<LOGM, LO, 3>(q, e) & ((1 << beta) - 1))];
+      const double2 u = x[e], v = x[e1];
+      if (FWD) {
+        const double2 dd = make_double2(u.x - v.x, u.y - v.y);
+        x[e] = make_double2(u.x + v.x, u.y + v.y);
+        x[e1] = cmul(dd, w);
+      } else {
+        const double2 vv = cmul_conj(v, w);
+        x[e] = make_double2(u.x + vv.x, u.y + vv.y);
+        x[e1] = make_double2(u.x - vv.x, u.y - vv.y);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ constexpr int fpad(int p) { return (p >> 7) * 142 + ((p >> 4) & 7) * 18 + (p & 15); }
+
 template <int LOGN, int BL, int G>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_mb_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
@@ -974,10 +1002,11 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
   constexpr int NP = (LOGM - 1) / 3, NC = 1 << G;
   static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
+  constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;  // padded slots per polynomial (fpad)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw);                                 // [2][M]
-  double2 *T = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * M * 16);               // [M/2] stage tables
-  uint16_t *degs = reinterpret_cast<uint16_t *>(smem_raw + (size_t)2 * M * 16 + (size_t)(M / 2) * 16);
+  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw);                                 // [2][SLOTS]
+  double2 *T = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * SLOTS * 16);           // [M] stage tables
+  uint16_t *degs = reinterpret_cast<uint16_t *>(smem_raw + (size_t)2 * SLOTS * 16 + (size_t)M * 16);
 
   const int tid = threadIdx.x;
   const int r = tid / TP;
@@ -996,28 +1025,22 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       if ((c >> (G - 1 - t)) & 1) sum += ks[j * G + t];
     degs[idx] = (uint16_t)((((sum >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
   }
-  for (int idx = 2 + tid; idx < M / 2; idx += blockDim.x) {
+  for (int idx = 2 + tid; idx < M; idx += blockDim.x) {
     const int beta = 31 - __builtin_clz(idx);  // idx = 2^beta + j
     T[idx] = tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
   }
   __syncthreads();
 
   constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
-  double2 wtop[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) wtop[e] = tw[fft_point<LOGM, LO_A, 3>(q, e) & (M / 2 - 1)];
   const double2 *twist_q = twist + q;
   const double2 *twist_inv_q = twist_inv + q;
   const __amdgpu_buffer_rsrc_t rs_g =
       __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_groups * NC * 4 * M * 16), 0x00020000);
   const unsigned voff_g = (unsigned)(r * 8 * TP + q) * 16u;  // G[((row*2 + r)*8 + e)*TP + q]
-  int sexp[8];  // E(p) of the slots this thread holds when the external product runs
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int p = fft_point<LOGM, LO_C, 3>(q, e);
-    const int f = (int)(__brev((unsigned)p) >> (32 - LOGM));
-    sexp[e] = (1 - 4 * f) & (2 * N - 1);
-  }
+  // E(p) of the slots this thread holds when the external product runs: p = point_C(q, e) has e in
+  // bits [LO_C, LO_C+3), so bitrev(p) = bitrev(point_C(q, 0)) + (bitrev3(e) << (LOGM - 3 - LO_C)) and
+  // E(p) * d = E(point_C(q, 0)) * d - bitrev3(e) * (d << (LOGM - 1 - LO_C))   (mod 2N)
+  const int sexp0 = (1 - 4 * (int)(__brev((unsigned)fft_point<LOGM, LO_C, 3>(q, 0)) >> (32 - LOGM))) & (2 * N - 1);
 
   // ---- acc = (0, X^{-b~} * LUT), in registers: coefficients p and p + M of polynomial r ----
   uint64_t own_lo[8], own_hi[8];
@@ -1038,30 +1061,47 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     }
   }
 
-  double2 *buf_r = fbuf + (size_t)r * M;
-  const double2 *buf_o = fbuf + (size_t)(1 - r) * M;
+  // one base slot per pass layout; element e lives at base + e * stride (immediate offsets)
+  constexpr int SA = fpad(1 << LO_A), SB = fpad(1 << LO_B), SC = fpad(1 << LO_C);
+  double2 *bufA = fbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_A, 3>(q, 0));
+  double2 *bufB = fbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_B, 3>(q, 0));
+  double2 *bufC = fbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
+  const double2 *bufCo = fbuf + (size_t)(1 - r) * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
 
   for (int j = 0; j < n_groups; ++j) {
-    // ---- bundle, column r: b0 = row 0, b1 = row 1 ----
+    // ---- bundle, column r: b0 = row 0, b1 = row 1.  Built two points at a time so that only the
+    // 2 * 2^G GGSW values and 2^G - 1 monomial factors of those points are in flight ----
     double2 b0[8], b1[8];
     {
       const unsigned so = (unsigned)j * (unsigned)(NC * 4 * M * 16);
+      int deg[NC];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        b0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
-        b1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
-      }
+      for (int c = 1; c < NC; ++c) deg[c] = __builtin_amdgcn_readfirstlane((int)degs[j * (NC - 1) + (c - 1)]);  // uniform -> SGPR
+      // batches keep at most ~22 loads (88 registers) in flight: G = 2: two points, all of c;
+      // G = 3: one point, c in two halves
+      constexpr int EB = G == 2 ? 2 : 1, CB = G == 2 ? NC - 1 : 4;
 #pragma unroll
-      for (int c = 1; c < NC; ++c) {
-        const int deg = (int)degs[j * (NC - 1) + (c - 1)];
-        const unsigned soc = so + (unsigned)c * (unsigned)(4 * M * 16);
+      for (int eb = 0; eb < 8; eb += EB) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const double2 w = root[(sexp[e] * deg) & (2 * N - 1)];
-          const double2 g0 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((0 * 16 + e) * TP * 16));
-          const double2 g1 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((1 * 16 + e) * TP * 16));
-          b0[e] = cfma(g0, w, b0[e]);
-          b1[e] = cfma(g1, w, b1[e]);
+        for (int cb = 1; cb < NC; cb += CB) {
+#pragma unroll
+          for (int e = eb; e < eb + EB; ++e) {
+            if (cb == 1) {
+              b0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
+              b1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
+            }
+#pragma unroll
+            for (int c = cb; c < cb + CB && c < NC; ++c) {
+              const unsigned soc = so + (unsigned)c * (unsigned)(4 * M * 16);
+              const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);  // constant after unrolling
+              const double2 w = root[(sexp0 * deg[c] - br3 * (deg[c] << (LOGM - 1 - LO_C))) & (2 * N - 1)];
+              const double2 g0 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((0 * 16 + e) * TP * 16));
+              const double2 g1 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((1 * 16 + e) * TP * 16));
+              b0[e] = cfma(g0, w, b0[e]);
+              b1[e] = cfma(g1, w, b1[e]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -1073,33 +1113,33 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       x[e] = cmul(make_double2(digit1_f64<BL>(own_lo[e]), digit1_f64<BL>(own_hi[e])), twist_q[e * TP]);
 
     // ---- forward FFT ----
-    fft_butterflies_tab<LOGM, true, LO_A>(x, q, T, wtop);
+    fft_butterflies_tab_all<LOGM, true, LO_A>(x, q, T);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
+    for (int e = 0; e < 8; ++e) bufA[e * SA] = x[e];
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
-    fft_butterflies_tab<LOGM, true, LO_B>(x, q, T, wtop);
+    for (int e = 0; e < 8; ++e) x[e] = bufB[e * SB];
+    fft_butterflies_tab_all<LOGM, true, LO_B>(x, q, T);
     if (NP == 3) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+      for (int e = 0; e < 8; ++e) bufB[e * SB] = x[e];
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
-      fft_butterflies_tab<LOGM, true, LO_C>(x, q, T, wtop);
+      for (int e = 0; e < 8; ++e) x[e] = bufC[e * SC];
+      fft_butterflies_tab_all<LOGM, true, LO_C>(x, q, T);
     }
     fft_stage_bit0_dpp(x, sgn);
 
     // ---- spectra exchanged in place, external product with the bundle ----
 #pragma unroll
-    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+    for (int e = 0; e < 8; ++e) bufC[e * SC] = x[e];
     __syncthreads();
     if (r == 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], buf_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], b0[e], b1[e]);
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], bufCo[e * SC], b0[e], b1[e]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(buf_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], x[e], b0[e], b1[e]);
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(bufCo[e * SC], x[e], b0[e], b1[e]);
     }
     double2 twi[8];
 #pragma unroll
@@ -1109,20 +1149,20 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     // ---- inverse FFT ----
     fft_stage_bit0_dpp(x, sgn);
     if (NP == 3) {
-      fft_butterflies_tab<LOGM, false, LO_C>(x, q, T, wtop);
+      fft_butterflies_tab_all<LOGM, false, LO_C>(x, q, T);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+      for (int e = 0; e < 8; ++e) bufC[e * SC] = x[e];
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+      for (int e = 0; e < 8; ++e) x[e] = bufB[e * SB];
     }
-    fft_butterflies_tab<LOGM, false, LO_B>(x, q, T, wtop);
+    fft_butterflies_tab_all<LOGM, false, LO_B>(x, q, T);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+    for (int e = 0; e < 8; ++e) bufB[e * SB] = x[e];
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
-    fft_butterflies_tab<LOGM, false, LO_A>(x, q, T, wtop);
+    for (int e = 0; e < 8; ++e) x[e] = bufA[e * SA];
+    fft_butterflies_tab_all<LOGM, false, LO_A>(x, q, T);
 
     // ---- untwist, round to the torus: the new accumulator ----
 #pragma unroll

@@ -17,7 +17,11 @@ def ptr(a):
 def main():
     lib = _lib.load(strict=False)
     p = Params()
-    check(lib.fhes_params_default(C.byref(p)))
+    which = sys.argv[3] if len(sys.argv) > 3 else "default"   # default | multibit2 | multibit3
+    if which.startswith("multibit"):
+        check(lib.fhes_params_multibit(C.byref(p), int(which[-1])))
+    else:
+        check(lib.fhes_params_default(C.byref(p)))
     ck = check_ptr(lib.fhes_client_key_generate(C.byref(p), 255, 1))
     bsk = np.zeros(lib.fhes_bsk_words(C.byref(p)), dtype=np.uint64)
     ksk = np.zeros(lib.fhes_ksk_words(C.byref(p)), dtype=np.uint64)
@@ -64,7 +68,7 @@ def main():
             dec = np.zeros(len(res), dtype=np.uint8)
             check(lib.fhes_client_decrypt_blocks(ck, ptr(res), len(res), ptr(dec)))
             ok = bool(np.array_equal(dec, (vals[:len(res)] + 1) % 16))
-            print(f"variant={variant} count={count:6d} wall={dt*1e3:9.3f} ms  ks={st.total_ks_ms/reps:8.3f} ms "
+            print(f"{which} variant={variant} count={count:6d} wall={dt*1e3:9.3f} ms  ks={st.total_ks_ms/reps:8.3f} ms "
                   f"br={st.total_br_ms/reps:9.3f} ms  PBS/s={count/dt:10.1f}  decrypt_ok={ok}", flush=True)
 
 
