@@ -25,11 +25,14 @@ def main():
     ap.add_argument("--filter", default=None)
     ap.add_argument("--l", type=int, default=255)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--params", choices=["classic", "multibit2", "multibit3"], default="classic",
+                    help="PARAM_MESSAGE_2_CARRY_2_KS_PBS or the multi-bit 2_2 sets (BASELINE.json config 5)")
     a = ap.parse_args()
 
     print("Generating keys...")
     t0 = time.time()
-    ck, sk = api.generate_keys_with_params(api.default_params(), a.l, seed=a.seed)
+    params = api.default_params() if a.params == "classic" else api.multibit_params(int(a.params[-1]))
+    ck, sk = api.generate_keys_with_params(params, a.l, seed=a.seed)
     print(f"Done. ({time.time() - t0:.2f}s)")
     s, p, sub, n = a.input, a.pattern, a.substitution, a.n
     print("Encrypting input / pattern / substitution / n...")

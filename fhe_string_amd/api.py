@@ -22,6 +22,13 @@ def default_params():
     return p
 
 
+def multibit_params(grouping_factor):
+    """PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_{2,3}_KS_PBS (BASELINE.json config 5)"""
+    p = Params()
+    check(_L().fhes_params_multibit(C.byref(p), grouping_factor))
+    return p
+
+
 def toy_params():
     p = Params()
     check(_L().fhes_params_toy(C.byref(p)))

@@ -1068,44 +1068,99 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   double2 *bufC = fbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
   const double2 *bufCo = fbuf + (size_t)(1 - r) * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
 
-  for (int j = 0; j < n_groups; ++j) {
-    // ---- bundle, column r: b0 = row 0, b1 = row 1.  Built two points at a time so that only the
-    // 2 * 2^G GGSW values and 2^G - 1 monomial factors of those points are in flight ----
-    double2 b0[8], b1[8];
-    {
-      const unsigned so = (unsigned)j * (unsigned)(NC * 4 * M * 16);
-      int deg[NC];
+  // ---- bundle pipeline.  The bundle of group j+1 (column r: b0 = row 0, b1 = row 1) is built while
+  // group j runs its inverse FFT: b0/b1 are dead after the external product, and the accumulator
+  // registers are dead between the digits and the rounding, so the loads of a batch (two points for
+  // G = 2, one point and half of c for G = 3) stay in flight across a whole FFT pass.  A batch is
+  // issued, and consumed at the next slot; the last batch is consumed right before the product. ----
+  constexpr int EB = G == 2 ? 2 : 1, CB = G == 2 ? NC - 1 : 4, NCB = (NC - 1 + CB - 1) / CB;
+  // measured: pipelining into the inverse FFT pays for G = 3 (72 -> 84 k PBS/s); for G = 2 the key
+  // stream is the limit either way and the plain order keeps the kernel spill-free (112 k PBS/s)
+  constexpr bool PIPE = G == 3;
+  constexpr int NBATCH = (8 / EB) * NCB, QB = NBATCH / 4;
+  double2 b0[8], b1[8];
+  double2 tg0[EB][CB], tg1[EB][CB], tww[EB][CB];
+  int deg[NC];
+  auto bundle_degrees = [&](int jn) __attribute__((always_inline)) {
 #pragma unroll
-      for (int c = 1; c < NC; ++c) deg[c] = __builtin_amdgcn_readfirstlane((int)degs[j * (NC - 1) + (c - 1)]);  // uniform -> SGPR
-      // batches keep at most ~22 loads (88 registers) in flight: G = 2: two points, all of c;
-      // G = 3: one point, c in two halves
-      constexpr int EB = G == 2 ? 2 : 1, CB = G == 2 ? NC - 1 : 4;
+    for (int c = 1; c < NC; ++c) deg[c] = __builtin_amdgcn_readfirstlane((int)degs[jn * (NC - 1) + (c - 1)]);  // uniform -> SGPR
+  };
+  auto bundle_issue = [&](int jn, int k) __attribute__((always_inline)) {
+    const int eb = (k / NCB) * EB, cb = 1 + (k % NCB) * CB;
+    const unsigned so = (unsigned)jn * (unsigned)(NC * 4 * M * 16);
 #pragma unroll
-      for (int eb = 0; eb < 8; eb += EB) {
+    for (int ee = 0; ee < EB; ++ee) {
+      const int e = eb + ee;
+      if (cb == 1) {
+        b0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
+        b1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
+      }
 #pragma unroll
-        for (int cb = 1; cb < NC; cb += CB) {
-#pragma unroll
-          for (int e = eb; e < eb + EB; ++e) {
-            if (cb == 1) {
-              b0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
-              b1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
-            }
-#pragma unroll
-            for (int c = cb; c < cb + CB && c < NC; ++c) {
-              const unsigned soc = so + (unsigned)c * (unsigned)(4 * M * 16);
-              const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);  // constant after unrolling
-              const double2 w = root[(sexp0 * deg[c] - br3 * (deg[c] << (LOGM - 1 - LO_C))) & (2 * N - 1)];
-              const double2 g0 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((0 * 16 + e) * TP * 16));
-              const double2 g1 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((1 * 16 + e) * TP * 16));
-              b0[e] = cfma(g0, w, b0[e]);
-              b1[e] = cfma(g1, w, b1[e]);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int cc = 0; cc < CB; ++cc) {
+        const int c = cb + cc;
+        if (c >= NC) continue;
+        const unsigned soc = so + (unsigned)c * (unsigned)(4 * M * 16);
+        const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);  // constant after unrolling
+        tww[ee][cc] = root[(sexp0 * deg[c] - br3 * (deg[c] << (LOGM - 1 - LO_C))) & (2 * N - 1)];
+        tg0[ee][cc] = buf_load_d2(rs_g, voff_g, soc + (unsigned)((0 * 16 + e) * TP * 16));
+        tg1[ee][cc] = buf_load_d2(rs_g, voff_g, soc + (unsigned)((1 * 16 + e) * TP * 16));
       }
     }
+  };
+  auto bundle_consume = [&](int k) __attribute__((always_inline)) {
+    const int eb = (k / NCB) * EB, cb = 1 + (k % NCB) * CB;
+#pragma unroll
+    for (int ee = 0; ee < EB; ++ee) {
+      const int e = eb + ee;
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc) {
+        if (cb + cc >= NC) continue;
+        b0[e] = cfma(tg0[ee][cc], tww[ee][cc], b0[e]);
+        b1[e] = cfma(tg1[ee][cc], tww[ee][cc], b1[e]);
+      }
+    }
+  };
+  // batches [first, first + count) of group jn; on entry batch first-1 is in flight (if first > 0),
+  // on exit batch first+count-1 is
+  auto bundle_advance = [&](int jn, int first, int count) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = first; k < first + count; ++k) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (k > 0) bundle_consume(k - 1);
+      bundle_issue(jn, k);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (PIPE) {
+    bundle_degrees(0);
+    bundle_advance(0, 0, NBATCH);
+  }
 
+  for (int j = 0; j < n_groups; ++j) {
+    const int jn = j + 1 < n_groups ? j + 1 : j;  // the last step rebuilds its own bundle (unused)
+    if (!PIPE) {  // plain order: two points at a time, loads and multiply-adds of a batch together
+      bundle_degrees(j);
+      const unsigned so = (unsigned)j * (unsigned)(NC * 4 * M * 16);
+#pragma unroll
+      for (int eb = 0; eb < 8; eb += 2) {
+#pragma unroll
+        for (int e = eb; e < eb + 2; ++e) {
+          b0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
+          b1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
+#pragma unroll
+          for (int c = 1; c < NC; ++c) {
+            const unsigned soc = so + (unsigned)c * (unsigned)(4 * M * 16);
+            const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);  // constant after unrolling
+            const double2 w = root[(sexp0 * deg[c] - br3 * (deg[c] << (LOGM - 1 - LO_C))) & (2 * N - 1)];
+            const double2 g0 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((0 * 16 + e) * TP * 16));
+            const double2 g1 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((1 * 16 + e) * TP * 16));
+            b0[e] = cfma(g0, w, b0[e]);
+            b1[e] = cfma(g1, w, b1[e]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     // ---- digits of the accumulator -> twist ----
     double2 x[8];
 #pragma unroll
@@ -1133,6 +1188,8 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     // ---- spectra exchanged in place, external product with the bundle ----
 #pragma unroll
     for (int e = 0; e < 8; ++e) bufC[e * SC] = x[e];
+    __builtin_amdgcn_sched_barrier(0);
+    if (PIPE) bundle_consume(NBATCH - 1);  // last batch of this group's bundle
     __syncthreads();
     if (r == 0) {
 #pragma unroll
@@ -1144,6 +1201,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     double2 twi[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) twi[e] = twist_inv_q[e * TP];
+    if (PIPE) {
+      bundle_degrees(jn);
+      bundle_advance(jn, 0, QB);
+    }
     __syncthreads();  // the other half has read my spectrum
 
     // ---- inverse FFT ----
@@ -1152,17 +1213,22 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       fft_butterflies_tab_all<LOGM, false, LO_C>(x, q, T);
 #pragma unroll
       for (int e = 0; e < 8; ++e) bufC[e * SC] = x[e];
+      if (PIPE) bundle_advance(jn, QB, QB);
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = bufB[e * SB];
+    } else {
+      if (PIPE) bundle_advance(jn, QB, QB);
     }
     fft_butterflies_tab_all<LOGM, false, LO_B>(x, q, T);
 #pragma unroll
     for (int e = 0; e < 8; ++e) bufB[e * SB] = x[e];
+    if (PIPE) bundle_advance(jn, 2 * QB, QB);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = bufA[e * SA];
     fft_butterflies_tab_all<LOGM, false, LO_A>(x, q, T);
+    if (PIPE) bundle_advance(jn, 3 * QB, NBATCH - 3 * QB);
 
     // ---- untwist, round to the torus: the new accumulator ----
 #pragma unroll

@@ -272,3 +272,26 @@ def test_slice_vector_methods_on_gpu(keys):
         assert v.decrypt(ck) == dec(rm.slices_truncate(raw, 2))
         v.reverse_with(sk)
         assert v.decrypt(ck) == dec(list(reversed(rm.slices_truncate(raw, 2))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g", [2, 3])
+def test_reference_tables_with_multibit_keys(g, libs):
+    """BASELINE.json config 5 parameter family: the same tables through the multi-bit kernel
+    (a spread of operations; the full tables run on the classic set above)"""
+    ck, sk = api.generate_keys_with_params(api.multibit_params(g), 255, seed=0xF4E50005)
+    try:
+        ops = ("find", "rfind", "contains", "eq", "lt", "ge", "len", "starts_with", "ends_with", "split", "rsplit",
+               "split_inclusive")
+        picked, seen = [], {}
+        for c in CASES:
+            if c["op"] in ops and seen.get(c["op"], 0) < 3:
+                seen[c["op"]] = seen.get(c["op"], 0) + 1
+                picked.append(c)
+        assert len(picked) >= 30
+        for c in picked:
+            assert run_api(ck, sk, c) == c["expect"], (g, c)
+        for c in [c for c in CASES_EXT if c["op"] in ("replace", "trim", "splitn", "insert", "add", "repeat", "char_at")][:10]:
+            assert run_api_ext(ck, sk, c) == c["expect"], (g, c)
+    finally:
+        sk.close()
