@@ -41,13 +41,13 @@ def north_star_inputs(rank=0):
     return s, s[37:41]
 
 
-def cpu_baseline(lib_params, text, pat, budget_s=30.0):
+def cpu_baseline(which, text, pat, budget_s=30.0):
     """Times the oracle on the same compiled `find` program, all host cores."""
     import numpy as np
     from tests.helpers import World
     from tests.progs import Prog, num_blocks_usize, string_blocks, decode_result
     cores = os.cpu_count() or 1
-    w = World("default", 255, 0xF4E50000)
+    w = World(which, 255, 0xF4E50000)
     p = Prog(w.p, "find", [65, 5], num_blocks_usize(255))
     cts = w.encrypt(np.concatenate([string_blocks(text), string_blocks(pat)]))
     t0 = time.time()
@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="blind-rotate kernel variant (0 = auto)")
+    ap.add_argument("--params", choices=["classic", "multibit2", "multibit3"], default="classic",
+                    help="parameter set: PARAM_MESSAGE_2_CARRY_2_KS_PBS (the headline, BASELINE config 2) or the "
+                         "multi-bit 2_2 sets of config 5")
     ap.add_argument("--batch", type=int, default=170, help="independent (input, pattern) pairs per step and rank (9 * 170 = 1530 bootstraps fill 3 x 512 workgroup slots)")
     args = ap.parse_args()
 
@@ -103,7 +106,15 @@ def main():
 
     lib = _lib.load()
     params = Params()
-    check(lib.fhes_params_default(C.byref(params)))
+    if args.params == "classic":
+        check(lib.fhes_params_default(C.byref(params)))
+    else:
+        check(lib.fhes_params_multibit(C.byref(params), int(args.params[-1])))
+    # algorithmic bytes of THIS parameter set ("for multi-bit sets recompute")
+    global KS_BYTES, BR_BYTES, PBS_BYTES
+    KS_BYTES = int(lib.fhes_ksk_words(C.byref(params))) * 8 + 16_392
+    BR_BYTES = int(lib.fhes_bsk_words(C.byref(params))) * 8 + 32_768 + 16_392
+    PBS_BYTES = KS_BYTES + BR_BYTES
     ck = check_ptr(lib.fhes_client_key_generate(C.byref(params), 255, 0xF4E50000))
     W = params.ct_words()
     bsk = np.zeros(lib.fhes_bsk_words(C.byref(params)), dtype=np.uint64)
@@ -225,7 +236,7 @@ def main():
         br_achieved = (BR_BYTES * units) / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.params == "classic":   # the committed PMC passes are of the classic kernel
             try:
                 traffic = json.load(open(tpath)).get("blind_rotate_hbm_bytes_per_launch")
             except Exception:
@@ -244,7 +255,8 @@ def main():
             "dtype": "u64 torus (f64 FFT inside the external product)",
             "data": "synthetic",
             "config": {"workload": "FheString::find, 64-char unpadded input, 4-char encrypted pattern, "
-                                   "PARAM_MESSAGE_2_CARRY_2_KS_PBS, l=255 (BASELINE config 2)",
+                                   + ("PARAM_MESSAGE_2_CARRY_2_KS_PBS, l=255 (BASELINE config 2)" if args.params == "classic" else
+                                      f"multi-bit 2_2 set, grouping factor {args.params[-1]}, l=255 (parameter family of BASELINE config 5)"),
                        "pbs_per_find": int(pbs_per_find), "levels": int(n_levels),
                        "strings_per_step_per_rank": B,
                        "parallelism": f"{world_size} rank(s) x {B} independent strings per step"},
@@ -268,7 +280,7 @@ def main():
         }
         line["roofline_pbs"]["frac"] = round(line["roofline_pbs"]["achieved"] / HBM_PEAK_GBS, 4)
         if world_size == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(params, text, pat)
+            line["cpu_baseline"] = cpu_baseline("default" if args.params == "classic" else args.params, text, pat)
         print(json.dumps(line), flush=True)
 
     lib.fhes_program_destroy(prog)
