@@ -97,6 +97,17 @@ __device__ __forceinline__ int fft_point(int q, int e) {
   return ((rest >> LO) << (LO + NB)) | (f << LO) | (rest & ((1 << LO) - 1));
 }
 
+// inverse (DIT) butterfly, fused form: s = u + v*conj(w) in 4 FMAs, d = 2u - s in 2
+__device__ __forceinline__ void inv_butterfly(double2 &a, double2 &b, double2 w) {
+  const double2 u = a, v = b;
+  double sre = __builtin_fma(v.x, w.x, u.x);
+  sre = __builtin_fma(v.y, w.y, sre);
+  double sim = __builtin_fma(v.y, w.x, u.y);
+  sim = __builtin_fma(-v.x, w.y, sim);
+  a = make_double2(sre, sim);
+  b = make_double2(__builtin_fma(2.0, u.x, -sre), __builtin_fma(2.0, u.y, -sim));
+}
+
 template <int LOGM, bool FWD, int LO, int NB>
 __device__ __forceinline__ void fft_butterflies(double2 (&x)[8], int q,
                                                 const double2 *__restrict__ tw) {
@@ -121,9 +132,7 @@ __device__ __forceinline__ void fft_butterflies(double2 (&x)[8], int q,
           x[e] = make_double2(u.x + v.x, u.y + v.y);
           x[e1] = cmul(d, w);
         } else {
-          const double2 vv = cmul_conj(v, w);
-          x[e] = make_double2(u.x + vv.x, u.y + vv.y);
-          x[e1] = make_double2(u.x - vv.x, u.y - vv.y);
+          inv_butterfly(x[e], x[e1], w);
         }
       }
     }
@@ -517,9 +526,7 @@ __device__ __forceinline__ void fft_butterflies_reg(double2 (&x)[8], const doubl
         x[e] = make_double2(u.x + v.x, u.y + v.y);
         x[e1] = cmul(d, tw);
       } else {
-        const double2 vv = cmul_conj(v, tw);
-        x[e] = make_double2(u.x + vv.x, u.y + vv.y);
-        x[e1] = make_double2(u.x - vv.x, u.y - vv.y);
+        inv_butterfly(x[e], x[e1], tw);
       }
     }
   }
@@ -730,9 +737,7 @@ __device__ __forceinline__ void fft_butterflies_tab(double2 (&x)[8], int q, cons
         x[e] = make_double2(u.x + v.x, u.y + v.y);
         x[e1] = cmul(dd, w);
       } else {
-        const double2 vv = cmul_conj(v, w);
-        x[e] = make_double2(u.x + vv.x, u.y + vv.y);
-        x[e1] = make_double2(u.x - vv.x, u.y - vv.y);
+        inv_butterfly(x[e], x[e1], w);
       }
     }
   }
@@ -983,9 +988,7 @@ __device__ __forceinline__ void fft_butterflies_tab_all(double2 (&x)[8], int q, 
         x[e] = make_double2(u.x + v.x, u.y + v.y);
         x[e1] = cmul(dd, w);
       } else {
-        const double2 vv = cmul_conj(v, w);
-        x[e] = make_double2(u.x + vv.x, u.y + vv.y);
-        x[e1] = make_double2(u.x - vv.x, u.y - vv.y);
+        inv_butterfly(x[e], x[e1], w);
       }
     }
   }

@@ -67,10 +67,20 @@ static void fft_inv(const oracle_ctx *c, cplx *x) {
   for (int half = 1, stride = M / 2; half <= M / 2; half <<= 1, stride >>= 1) {
     for (int b = 0; b < M; b += 2 * half) {
       for (int j = 0; j < half; j++) {
-        cplx u = x[b + j];
-        cplx v = cmul_conj(x[b + j + half], c->tw[j * stride]);
-        cplx s = {u.re + v.re, u.im + v.im};
-        cplx d = {u.re - v.re, u.im - v.im};
+        const cplx u = x[b + j], v = x[b + j + half];
+        cplx s, d;
+        if (half == 1) { /* first stage: the twiddle is exactly 1 */
+          s.re = u.re + v.re; s.im = u.im + v.im;
+          d.re = u.re - v.re; d.im = u.im - v.im;
+        } else { /* fused butterfly: s = u + v*conj(w) in 4 FMAs, d = 2u - s in 2 */
+          const cplx w = c->tw[j * stride];
+          s.re = fma(v.re, w.re, u.re);
+          s.re = fma(v.im, w.im, s.re);
+          s.im = fma(v.im, w.re, u.im);
+          s.im = fma(-v.re, w.im, s.im);
+          d.re = fma(2.0, u.re, -s.re);
+          d.im = fma(2.0, u.im, -s.im);
+        }
         x[b + j] = s;
         x[b + j + half] = d;
       }
