@@ -235,8 +235,8 @@ def main():
         units = st.pbs_count / launches
         br_achieved = (BR_BYTES * units) / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.params == "classic":   # the committed PMC passes are of the classic kernel
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.params == "classic" else f"pmc_traffic_{args.params}.json")
+        if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("blind_rotate_hbm_bytes_per_launch")
             except Exception:

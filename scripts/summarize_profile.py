@@ -27,7 +27,11 @@ def short(name):
     return n
 
 
-stats_csv = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+def newest(pattern):   # gpurun merges into an existing directory: older passes may still lie there
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats_csv = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 shutil.copy(stats_csv, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 kern = {}
 for r in csv.DictReader(open(stats_csv)):
@@ -36,7 +40,7 @@ for r in csv.DictReader(open(stats_csv)):
 
 
 def pmc(sub, counter):
-    f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(src, sub, "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -68,20 +72,25 @@ if bench_line and "roofline" in bench_line:
     steps = bench_line.get("steps", 1)
     warm = bench_line.get("warmup", 0)
     bench_total = rl["launches"] * rl["launch_ms"] * (steps + warm) / max(steps, 1)
-    prof_total = sum(v["total_ms"] for k, v in kern.items() if "blind_rotate_v3" in k)
+    dom = max((k for k in kern if "blind_rotate" in k), key=lambda k: kern[k]["total_ms"])
+    prof_total = kern[dom]["total_ms"]
     check = {"bench_hip_event_total_ms_scaled_to_all_batched_runs": round(bench_total, 1),
-             "rocprof_blind_rotate_v3_total_ms": round(prof_total, 1),
+             "rocprof_dominant_blind_rotate_kernel": dom,
+             "rocprof_total_ms": round(prof_total, 1),
              "ratio": round(prof_total / bench_total, 4) if bench_total else None}
-out = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (under rocprofv3)",
+extra = sys.argv[2] if len(sys.argv) > 2 else ""      # e.g. "--params multibit2"
+out = {"tag": tag, "command": f"python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline {extra}".strip() + " (under rocprofv3)",
        "duration_cross_check": check,
        "kernels": kern, "bench_line_under_profiler": bench_line}
 json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
-br = [k for k in kern if "blind_rotate" in k]
+br = sorted((k for k in kern if "blind_rotate" in k), key=lambda k: -kern[k]["total_ms"])
 if br:
     k = kern[br[0]]
     traffic = {"source": f"profiles/{tag}_summary.json", "kernel": br[0],
                "blind_rotate_hbm_bytes_per_launch": round(k.get("fetch_bytes_per_launch", 0) + k.get("write_bytes_per_launch", 0)),
                "note": "FETCH_SIZE x2 (gfx950) + WRITE_SIZE, KiB -> bytes, averaged over the launches of one bench run"}
-    json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    params = extra.split()[-1] if "--params" in extra else "classic"
+    name = "pmc_traffic.json" if params == "classic" else f"pmc_traffic_{params}.json"
+    json.dump(traffic, open(os.path.join(dst, name), "w"), indent=1)
 for k, v in kern.items():
     print(f"{k[:70]:70s} calls={v['calls']:5d} avg={v['avg_ms']:9.4f} ms  fetch/launch={v.get('fetch_bytes_per_launch', 0)/1e6:10.2f} MB")
