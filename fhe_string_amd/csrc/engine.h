@@ -57,6 +57,7 @@ struct fhes_ctx {
   std::vector<Timed> pending;         // launches whose events are not yet read
   std::vector<hipEvent_t> ev_free;    // recycled events
   int br_variant = 0;
+  int ks_min_cps = 8;   // smallest mask range per keyswitch split (developer knob FHES_KS_MIN_CPS)
 
   explicit fhes_ctx(const fhes_params &pp) : p(pp), dims(pp) {}
 };

@@ -148,7 +148,11 @@ static int launch_keyswitch(fhes_ctx *ctx, const dev::NodeDesc &d) {
   const Dims &dm = ctx->dims;
   FHES_HIP(hipMemsetAsync(ctx->ks_out, 0, (size_t)d.v_count * ctx->ks_stride * sizeof(uint64_t), ctx->stream));
   const int tiles = (d.v_count + dev::KS_TB - 1) / dev::KS_TB;
-  const int max_splits = dm.big / dev::KS_IC;
+  // wide launches: at most one split per KS_IC-coefficient chunk; small launches (the latency
+  // path, a handful of tiles) split down to FHES_KS_MIN_CPS coefficients so that the 61 MB key is
+  // streamed by all CUs
+  const int min_cps = ctx->ks_min_cps;
+  const int max_splits = dm.big / (tiles <= 8 ? min_cps : dev::KS_IC);
   int splits = 1;
   while (splits < max_splits && tiles * splits < 1024) splits *= 2;
   const int cps = dm.big / splits;
@@ -404,6 +408,10 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
     ctx->n_cus = prop.multiProcessorCount;
+  }
+  if (const char *e2 = getenv("FHES_KS_MIN_CPS")) {
+    const int v = atoi(e2);
+    if (v >= 1 && v <= dev::KS_IC && (v & (v - 1)) == 0) ctx->ks_min_cps = v;
   }
   ctx->ct_stride = d.big + 16;
   const char *env = getenv("FHES_ARENA_SLOTS");

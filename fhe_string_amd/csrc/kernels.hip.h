@@ -272,9 +272,11 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
     for (int q = 0; q < JPT; ++q) { acc_lo[b][q] = 0; acc_hi[b][q] = 0; }
 
   for (int chunk = i_begin; chunk < i_end; chunk += KS_IC) {
+    const int lim = min(KS_IC, i_end - chunk);  // small launches split finer than one chunk
     // stage the digits of KS_TB x KS_IC mask coefficients
     for (int idx = tid; idx < KS_TB * KS_IC; idx += 256) {
       const int b = idx / KS_IC, ii = idx % KS_IC;
+      if (ii >= lim) continue;
       uint64_t x = 0;
       if (b < nodes_here) {
         const int v = d.v0 + vbase + b;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
       }
     }
     __syncthreads();
-    for (int ii = 0; ii < KS_IC; ++ii) {
+    for (int ii = 0; ii < lim; ++ii) {
       const uint64_t *krow = ksk + ((size_t)(chunk + ii) * ks_level) * ks_stride;
       for (int l = 0; l < ks_level; ++l) {
         uint64_t kv[JPT];
