@@ -20,6 +20,13 @@
  * itself: decrypt(op(encrypt(x))) == std::str op(x) on the reference's test
  * tables (tests/golden/reference_tables.json).
  *
+ * Multi-bit parameter sets (grouping_factor 2 / 3, BASELINE.json config 5) are restated the
+ * same way from tfhe-rs's multi-bit PBS (key layout of generate_lwe_multi_bit_bootstrap_key,
+ * bundle + external product of multi_bit_blind_rotate_assign; sum-then-modswitch degrees), in
+ * the deterministic order documented in DESIGN.md 4.8.  The reference cannot select them
+ * (/root/reference/src/lib.rs:50), so there is no reference-side table for them at all:
+ * they are pinned by the same decrypted tables run under multi-bit keys.
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library.  The product library (fhe_string_amd/csrc) never links it.
  *
