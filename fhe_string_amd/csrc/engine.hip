@@ -226,14 +226,14 @@ static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d, unsigned long lon
   return FHES_OK;
 }
 
-template <int LOGN, int G>
+template <int LOGN, int G, bool PIPE>
 static int launch_br_mb(fhes_ctx *ctx, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const int n_deg = (ctx->dims.n / G) * ((1 << G) - 1);
   constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
   const size_t lds = (size_t)2 * SLOTS * 16 + (size_t)M * 16 + (size_t)((n_deg + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_mb_kernel<LOGN, 23, G>;
-  const unsigned bit = 8 + G;
+  auto kern = dev::blind_rotate_mb_kernel<LOGN, 23, G, PIPE>;
+  const unsigned bit = 8 + 2 * G + (PIPE ? 1 : 0);
   if (!(ctx->attr_done & (1u << bit))) {
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -249,9 +249,12 @@ static int launch_br_mb(fhes_ctx *ctx, const dev::NodeDesc &d) {
 // variant: 0 = auto (latency kernel for launches that fit one workgroup per CU, throughput
 // kernel otherwise), 1 / 2 / 3 = force
 static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
-  if (ctx->dims.g > 1) {  // multi-bit parameter sets have one kernel
-    if (ctx->dims.N == 2048) return ctx->dims.g == 2 ? launch_br_mb<11, 2>(ctx, d) : launch_br_mb<11, 3>(ctx, d);
-    return ctx->dims.g == 2 ? launch_br_mb<8, 2>(ctx, d) : launch_br_mb<8, 3>(ctx, d);
+  if (ctx->dims.g > 1) {  // multi-bit parameter sets: one kernel, with or without the bundle pipeline
+    if (ctx->dims.g == 3)
+      return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true>(ctx, d) : launch_br_mb<8, 3, true>(ctx, d);
+    const bool pipe = ctx->br_variant == 2 || (ctx->br_variant == 0 && d.v_count <= ctx->n_cus);
+    if (ctx->dims.N == 2048) return pipe ? launch_br_mb<11, 2, true>(ctx, d) : launch_br_mb<11, 2, false>(ctx, d);
+    return pipe ? launch_br_mb<8, 2, true>(ctx, d) : launch_br_mb<8, 2, false>(ctx, d);
   }
   int variant = ctx->br_variant;
   if (variant == 0) variant = d.v_count <= ctx->n_cus ? 2 : 3;  // v2: 3.4 ms alone; v3: 2 per CU in 6.3 ms

@@ -998,7 +998,7 @@ __device__ __forceinline__ void fft_butterflies_tab_all(double2 (&x)[8], int q, 
 
 __device__ __forceinline__ constexpr int fpad(int p) { return (p >> 7) * 142 + ((p >> 4) & 7) * 18 + (p & 15); }
 
-template <int LOGN, int BL, int G>
+template <int LOGN, int BL, int G, bool PIPE>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_mb_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
     int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
@@ -1079,9 +1079,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   // G = 2, one point and half of c for G = 3) stay in flight across a whole FFT pass.  A batch is
   // issued, and consumed at the next slot; the last batch is consumed right before the product. ----
   constexpr int EB = G == 2 ? 2 : 1, CB = G == 2 ? NC - 1 : 4, NCB = (NC - 1 + CB - 1) / CB;
-  // measured: pipelining into the inverse FFT pays for G = 3 (72 -> 84 k PBS/s); for G = 2 the key
-  // stream is the limit either way and the plain order keeps the kernel spill-free (112 k PBS/s)
-  constexpr bool PIPE = G == 3;
+  // PIPE (chosen by the launcher): build the next bundle inside the inverse FFT.  Measured: pays for
+  // G = 3 always (72 -> 84 k PBS/s) and for G = 2 when a launch leaves one workgroup per CU (2.83 vs
+  // 3.03 ms per PBS); in wide G = 2 launches the key stream is the limit either way and the plain
+  // order keeps the kernel spill-free (122 vs 105 k PBS/s)
   constexpr int NBATCH = (8 / EB) * NCB, QB = NBATCH / 4;
   double2 b0[8], b1[8];
   double2 tg0[EB][CB], tg1[EB][CB], tww[EB][CB];
