@@ -133,6 +133,15 @@ def main():
     check(lib.fhes_program_info(prog, info))
     n_in, n_out, n_levels, pbs_per_find = int(info[0]), int(info[1]), int(info[3]), int(info[7])
     pairs = [north_star_inputs(rank * 1000 + j) for j in range(B)]
+    # bootstraps per dependent level of one find (report depth and per-level batch sizes)
+    n_nodes, n_terms, n_luts = int(info[2]), int(info[4]), int(info[5])
+    lp = np.zeros(n_levels + 1, dtype=np.int32)
+    _tp, _ti, _tc = np.zeros(n_nodes + 1, np.int32), np.zeros(max(n_terms, 1), np.int32), np.zeros(max(n_terms, 1), np.int64)
+    _cs, _li, _oi = np.zeros(max(n_nodes, 1), np.uint64), np.zeros(max(n_nodes, 1), np.int32), np.zeros(max(n_nodes, 1), np.int32)
+    _lt, _os = np.zeros((max(n_luts, 1), 16), np.uint64), np.zeros(max(n_out, 1), np.int32)
+    check(lib.fhes_program_export(prog, lp.ctypes.data, _tp.ctypes.data, _ti.ctypes.data, _tc.ctypes.data, _cs.ctypes.data,
+                                  _li.ctypes.data, _oi.ctypes.data, _lt.ctypes.data, _os.ctypes.data, None))
+    level_sizes = [int(lp[i + 1] - lp[i]) for i in range(n_levels) if (_li[lp[i]:lp[i + 1]] >= 0).all()]
 
     def blocks(s):
         out = np.zeros((len(s) + 1) * 4, dtype=np.uint8)
@@ -270,6 +279,7 @@ def main():
                                    + ("PARAM_MESSAGE_2_CARRY_2_KS_PBS, l=255 (BASELINE config 2)" if args.params == "classic" else
                                       f"multi-bit 2_2 set, grouping factor {args.params[-1]}, l=255 (parameter family of BASELINE config 5)"),
                        "pbs_per_find": int(pbs_per_find), "levels": int(n_levels),
+                       "pbs_per_level_of_one_find": level_sizes,
                        "strings_per_step_per_rank": B,
                        "parallelism": f"{world_size} rank(s) x {B} independent strings per step"},
             "result_ok": bool(ok),
