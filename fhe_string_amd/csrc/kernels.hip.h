@@ -941,6 +941,200 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   if (tid == 0) out[N] = acc[N];
 }
 
+// padded exchange-buffer layout: slot(p) = (p>>7)*142 + ((p>>4)&7)*18 + (p&15).  Every 3-bit pass
+// layout is then base(q) + e * const (one address register per layout, immediate offsets) and b128
+// accesses stay conflict-free (16 consecutive lanes always cover 16 consecutive 16-byte groups).
+__device__ __forceinline__ constexpr int fpad(int p) { return (p >> 7) * 142 + ((p >> 4) & 7) * 18 + (p & 15); }
+
+typedef unsigned int fhes_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  const fhes_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
+
+// ------------------------------------------------------------------------------------------
+// K2+K3 (variant 4): variant 3 with one barrier fewer per iteration -- same arithmetic, same bits.
+// The thread's own accumulator coefficients stay in registers, so the accumulator image in LDS is
+// dead between the rotated reads and the write-back at the end of the iteration: it serves as a
+// SECOND exchange buffer.  The FFT exchanges alternate between the two buffers (X = fbuf, padded
+// layout; Y = the accumulator image, XOR-swizzled), so a buffer is never rewritten in the phase
+// that follows its reads and the barrier "the other half has read my spectrum" disappears:
+//   rot(Y) | A->X | B1 | B(X) ->Y | B2 | C(Y), spectrum ->X | B3 | other(X), MAC, inv C ->Y | B4 |
+//   B(Y) ->X | B5 | A(X), round, acc ->Y | B6
+// GGSW / twist factors through buffer loads with SGPR offsets.
+// LDS: Y = acc u64[2][N] | X = fbuf double2[2][SLOTS] | stage tables double2[M/2] | a_tilde u16
+// ------------------------------------------------------------------------------------------
+template <int LOGN, int BL>
+__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v4_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
+    int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
+    const double2 *__restrict__ twist, const double2 *__restrict__ twist_inv /* twist / M */,
+    const double2 *__restrict__ tw) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
+  constexpr int NP = (LOGM - 1) / 3;
+  static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
+  constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N]      } Y
+  double2 *ybuf = reinterpret_cast<double2 *>(smem_raw);                      // [2][M]      }
+  double2 *xbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][SLOTS]    X
+  double2 *T = xbuf + (size_t)2 * SLOTS;                                      // [M/2] stage tables
+  uint16_t *at = reinterpret_cast<uint16_t *>(T + M / 2);
+
+  const int tid = threadIdx.x;
+  const int r = tid / TP;
+  const int q = tid % TP;
+  const double sgn = (q & 1) ? -1.0 : 1.0;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  for (int j = tid; j <= n_small; j += blockDim.x)
+    at[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  for (int idx = 2 + tid; idx < M / 2; idx += blockDim.x) {
+    const int beta = 31 - __builtin_clz(idx);  // idx = 2^beta + j
+    T[idx] = tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
+  }
+  __syncthreads();
+
+  constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
+  constexpr int SA = fpad(1 << LO_A), SB = fpad(1 << LO_B), SC = fpad(1 << LO_C);
+  double2 wtop[4];  // stage LOGM-1 of pass A: tw[q + TP * e], e = 0..3
+#pragma unroll
+  for (int e = 0; e < 4; ++e) wtop[e] = tw[fft_point<LOGM, LO_A, 3>(q, e) & (M / 2 - 1)];
+  const __amdgpu_buffer_rsrc_t rs_g =
+      __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_small * 4 * M * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc((void *)twist, 0, M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ti = __builtin_amdgcn_make_buffer_rsrc((void *)twist_inv, 0, M * 16, 0x00020000);
+  const unsigned voff_q = (unsigned)q * 16u;                 // twist[q + e*TP]
+  const unsigned voff_g = (unsigned)(r * 8 * TP + q) * 16u;  // G[((row*2 + r)*8 + e)*TP + q]
+
+  uint64_t own_lo[8], own_hi[8];  // coefficients p and p + M of polynomial r
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      own_lo[e] = v0;
+      own_hi[e] = v1;
+      acc[(size_t)r * N + p] = v0;
+      acc[(size_t)r * N + p + M] = v1;
+    }
+  }
+  __syncthreads();
+
+  const uint64_t *acc_r = acc + (size_t)r * N;
+  uint64_t *acc_w = acc + (size_t)r * N + q;  // own coefficient p = q + e*TP lives at acc_w[e * TP]
+  double2 *xA = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_A, 3>(q, 0));
+  double2 *xB = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_B, 3>(q, 0));
+  double2 *xC = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
+  const double2 *xCo = xbuf + (size_t)(1 - r) * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
+  double2 *y_r = ybuf + (size_t)r * M;
+
+  for (int i = 0; i < n_small; ++i) {
+    const int a = (int)at[i];
+    if (a == 0) continue;
+
+    // twist factors first, GGSW prefetch after they have been consumed (vmcnt completes in order)
+    double2 twv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) twv[e] = buf_load_d2(rs_tw, voff_q, (unsigned)(e * TP * 16));
+    double2 x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      const uint64_t d0 = rot_read<N>(acc_r, a, p) - own_lo[e];
+      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - own_hi[e];
+      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twv[e]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double2 g0[8], g1[8];
+    {
+      const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        g0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
+        g1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
+      }
+    }
+    // ---- forward FFT: A -> X, B -> Y ----
+    fft_butterflies_tab<LOGM, true, LO_A>(x, q, T, wtop);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xA[e * SA] = x[e];
+    __syncthreads();  // B1 (also: every rotated read of Y is done)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = xB[e * SB];
+    fft_butterflies_tab<LOGM, true, LO_B>(x, q, T, wtop);
+    if (NP == 3) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+      __syncthreads();  // B2
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
+      fft_butterflies_tab<LOGM, true, LO_C>(x, q, T, wtop);
+    }
+    fft_stage_bit0_dpp(x, sgn);
+
+    // ---- spectra -> X (its B-layout reads ended before B2), external product ----
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xC[e * SC] = x[e];
+    __syncthreads();  // B3
+    if (r == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], xCo[e * SC], g0[e], g1[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(xCo[e * SC], x[e], g0[e], g1[e]);
+    }
+    double2 twi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) twi[e] = buf_load_d2(rs_ti, voff_q, (unsigned)(e * TP * 16));
+
+    // ---- inverse FFT: C -> Y (no barrier: Y was last read before B3), B -> X ----
+    fft_stage_bit0_dpp(x, sgn);
+    if (NP == 3) {
+      fft_butterflies_tab<LOGM, false, LO_C>(x, q, T, wtop);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+      __syncthreads();  // B4 (also: every read of the spectra in X is done)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+      fft_butterflies_tab<LOGM, false, LO_B>(x, q, T, wtop);
+    } else {
+      fft_butterflies_tab<LOGM, false, LO_B>(x, q, T, wtop);
+      __syncthreads();  // B4
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xB[e * SB] = x[e];
+    __syncthreads();  // B5
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = xA[e * SA];
+    fft_butterflies_tab<LOGM, false, LO_A>(x, q, T, wtop);
+
+    // ---- untwist, round, accumulate; the image goes back into Y (last read before B5) ----
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double2 v = cmul_conj(x[e], twi[e]);
+      own_lo[e] += torus_from_f64_fast(v.x);
+      own_hi[e] += torus_from_f64_fast(v.y);
+      acc_w[e * TP] = own_lo[e];
+      acc_w[e * TP + M] = own_hi[e];
+    }
+    __syncthreads();  // B6
+  }
+
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
+  if (tid == 0) out[N] = acc[N];
+}
+
 // ------------------------------------------------------------------------------------------
 // K4: multi-bit blind rotate (grouping factor G = 2 or 3) + sample extract.  Same transforms,
 // rounding and FMA chains as the classic kernels, different step:
@@ -956,13 +1150,6 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 // root[t] = exp(i*pi*t/N): slot p holds the evaluation at twist * exp(-2*pi*i*bitrev(p)/M).
 // LDS: fbuf double2[2][M] | stage twiddle tables double2[M/2] | degrees u16[(n/G) * (2^G - 1)]
 // ------------------------------------------------------------------------------------------
-typedef unsigned int fhes_u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-  const fhes_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-  return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
-}
-
 // acc += g * w with the operation order of cmul
 __device__ __forceinline__ double2 cfma(double2 g, double2 w, double2 acc) {
   double re = __builtin_fma(g.x, w.x, acc.x);
@@ -995,8 +1182,6 @@ __device__ __forceinline__ void fft_butterflies_tab_all(double2 (&x)[8], int q, 
     }
   }
 }
-
-__device__ __forceinline__ constexpr int fpad(int p) { return (p >> 7) * 142 + ((p >> 4) & 7) * 18 + (p & 15); }
 
 template <int LOGN, int BL, int G, bool PIPE>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_mb_kernel(
