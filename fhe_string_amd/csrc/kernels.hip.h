@@ -965,6 +965,21 @@ __device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t rs, unsign
 // GGSW / twist factors through buffer loads with SGPR offsets.
 // LDS: Y = acc u64[2][N] | X = fbuf double2[2][SLOTS] | stage tables double2[M/2] | a_tilde u16
 // ------------------------------------------------------------------------------------------
+// the 7 twiddles of a 3-bit pass from the LDS stage tables (same values and order as
+// load_pass_twiddles): issued BEFORE the barrier that precedes the pass, so that only the data
+// reads remain on the critical path after it
+template <int LOGM, int LO>
+__device__ __forceinline__ void load_pass_twiddles_tab(double2 (&w)[7], int q, const double2 *T, const double2 (&wtop)[4]) {
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int fb = k < 4 ? 2 : (k < 6 ? 1 : 0);
+    const int e = k < 4 ? k : (k < 6 ? (k - 4) : 0);
+    const int beta = LO + fb;
+    if (beta == LOGM - 1) w[k] = wtop[e & 3];
+    else w[k] = T[(1 << beta) + (fft_point<LOGM, LO, 3>(q, e) & ((1 << beta) - 1))];
+  }
+}
+
 template <int LOGN, int BL>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v4_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
@@ -1064,21 +1079,26 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
         g1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
       }
     }
-    // ---- forward FFT: A -> X, B -> Y ----
-    fft_butterflies_tab<LOGM, true, LO_A>(x, q, T, wtop);
+    // ---- forward FFT: A -> X, B -> Y.  The twiddles of the NEXT pass are requested before each
+    // barrier: after it only the data reads are on the critical path ----
+    double2 w[7];
+    load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
+    fft_butterflies_reg<true>(x, w);
 #pragma unroll
     for (int e = 0; e < 8; ++e) xA[e * SA] = x[e];
+    load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
     __syncthreads();  // B1 (also: every rotated read of Y is done)
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = xB[e * SB];
-    fft_butterflies_tab<LOGM, true, LO_B>(x, q, T, wtop);
+    fft_butterflies_reg<true>(x, w);
     if (NP == 3) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+      load_pass_twiddles_tab<LOGM, LO_C>(w, q, T, wtop);
       __syncthreads();  // B2
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
-      fft_butterflies_tab<LOGM, true, LO_C>(x, q, T, wtop);
+      fft_butterflies_reg<true>(x, w);
     }
     fft_stage_bit0_dpp(x, sgn);
 
@@ -1100,23 +1120,25 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     // ---- inverse FFT: C -> Y (no barrier: Y was last read before B3), B -> X ----
     fft_stage_bit0_dpp(x, sgn);
     if (NP == 3) {
-      fft_butterflies_tab<LOGM, false, LO_C>(x, q, T, wtop);
+      fft_butterflies_reg<false>(x, w);  // w still holds the pass-C twiddles
 #pragma unroll
       for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+      load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
       __syncthreads();  // B4 (also: every read of the spectra in X is done)
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
-      fft_butterflies_tab<LOGM, false, LO_B>(x, q, T, wtop);
+      fft_butterflies_reg<false>(x, w);
     } else {
-      fft_butterflies_tab<LOGM, false, LO_B>(x, q, T, wtop);
+      fft_butterflies_reg<false>(x, w);  // w holds the pass-B twiddles
       __syncthreads();  // B4
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) xB[e * SB] = x[e];
+    load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
     __syncthreads();  // B5
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = xA[e * SA];
-    fft_butterflies_tab<LOGM, false, LO_A>(x, q, T, wtop);
+    fft_butterflies_reg<false>(x, w);
 
     // ---- untwist, round, accumulate; the image goes back into Y (last read before B5) ----
 #pragma unroll
