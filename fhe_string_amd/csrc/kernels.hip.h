@@ -1053,8 +1053,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   const double2 *xCo = xbuf + (size_t)(1 - r) * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
   double2 *y_r = ybuf + (size_t)r * M;
 
+  int a_next = (int)at[0];
   for (int i = 0; i < n_small; ++i) {
-    const int a = (int)at[i];
+    const int a = a_next;
+    a_next = (int)at[i + 1];  // requested one iteration ahead: off the critical path (at has n+1 entries)
     if (a == 0) continue;
 
     // twist factors first, GGSW prefetch after they have been consumed (vmcnt completes in order)
