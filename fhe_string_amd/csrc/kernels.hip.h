@@ -612,8 +612,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
   const uint64_t *acc_r = acc + (size_t)r * N;
   double2 *buf_r = fbuf + (size_t)r * M;
 
+  int a_next = (int)at[0];
   for (int i = 0; i < n_small; ++i) {
-    const int a = (int)at[i];
+    const int a = a_next;
+    a_next = (int)at[i + 1];  // requested one iteration ahead: off the critical path (at has n+1 entries)
     if (a == 0) continue;
 
     // ---- prefetch this iteration's GGSW column r (consumed after the forward FFT) ----
