@@ -1092,6 +1092,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     for (int e = 0; e < 8; ++e) xA[e * SA] = x[e];
     load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
     __syncthreads();  // B1 (also: every rotated read of Y is done)
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = xB[e * SB];
     fft_butterflies_reg<true>(x, w);
@@ -1140,6 +1141,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     for (int e = 0; e < 8; ++e) xB[e * SB] = x[e];
     load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
     __syncthreads();  // B5
+    __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = xA[e * SA];
     fft_butterflies_reg<false>(x, w);
