@@ -1141,7 +1141,6 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     for (int e = 0; e < 8; ++e) xB[e * SB] = x[e];
     load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
     __syncthreads();  // B5
-    __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = xA[e * SA];
     fft_butterflies_reg<false>(x, w);
@@ -1156,6 +1155,9 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       acc_w[e * TP + M] = own_hi[e];
     }
     __syncthreads();  // B6
+    // the long head of the next iteration (rotated reads, digits, twist, first pass) runs at high
+    // priority, the short latency-bound passes at normal priority: measured +1.8 %
+    __builtin_amdgcn_s_setprio(3);
   }
 
   uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
