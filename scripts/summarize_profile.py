@@ -65,13 +65,15 @@ p = os.path.join(src, "bench_line.json")
 if os.path.exists(p) and os.path.getsize(p):
     bench_line = json.loads(open(p).read().strip().splitlines()[-1])
 # cross-check with bench.py's own HIP-event timing: the profiled command runs 1 warm-up + `steps`
-# batched steps (plus a few single-find launches), bench.py reports launches * launch_ms for `steps`
+# timed batched steps + 1 PCIe-inclusive step (plus a few single-find launches), bench.py reports
+# launches * launch_ms for the `steps` timed ones
 check = None
 if bench_line and "roofline" in bench_line:
     rl = bench_line["roofline"]
     steps = bench_line.get("steps", 1)
     warm = bench_line.get("warmup", 0)
-    bench_total = rl["launches"] * rl["launch_ms"] * (steps + warm) / max(steps, 1)
+    extra_passes = 1 if "pcie_inclusive" in bench_line else 0
+    bench_total = rl["launches"] * rl["launch_ms"] * (steps + warm + extra_passes) / max(steps, 1)
     dom = max((k for k in kern if "blind_rotate" in k), key=lambda k: kern[k]["total_ms"])
     prof_total = kern[dom]["total_ms"]
     check = {"bench_hip_event_total_ms_scaled_to_all_batched_runs": round(bench_total, 1),
