@@ -26,6 +26,10 @@ struct fhes_program {
   std::vector<uint64_t> consts;
   int32_t n_slots = 0, n_pbs_levels = 0;
   bool has_linear_level = false;
+  // device-side placement of node results: node j lives in scratch cell scratch_idx[j] of its
+  // instance (cells are re-used once every reader of the previous occupant ran in an earlier level)
+  std::vector<int32_t> scratch_idx;
+  int32_t n_scratch = 0;
   std::mutex mu;
   std::map<uint64_t, DeviceImage> images;  // keyed by fhes_ctx::uid
 };
@@ -49,6 +53,36 @@ static void flatten(fhes_program *fp) {
   const int nl = (int)p.level_ptr.size() - 1;
   fp->has_linear_level = nl > 0 && !p.nodes.empty() && p.nodes.back().lut < 0;
   fp->n_pbs_levels = fp->has_linear_level ? nl - 1 : nl;
+
+  // ---- liveness: last level that reads each node, then first-fit re-use of scratch cells ----
+  const int32_t n_nodes = (int32_t)p.nodes.size();
+  std::vector<int32_t> level_of(n_nodes, 0), last_use(n_nodes, -1);
+  for (int lv = 0; lv < nl; lv++)
+    for (int32_t j = p.level_ptr[lv]; j < p.level_ptr[lv + 1]; j++) level_of[j] = lv;
+  for (int32_t j = 0; j < n_nodes; j++)
+    for (const auto &t : p.nodes[j].terms)
+      if (t.slot >= p.n_inputs) last_use[t.slot - p.n_inputs] = std::max(last_use[t.slot - p.n_inputs], level_of[j]);
+  for (int32_t s : p.out_slots)
+    if (s >= p.n_inputs) last_use[s - p.n_inputs] = INT32_MAX;  // results stay
+  fp->scratch_idx.assign(n_nodes, 0);
+  std::vector<int32_t> free_cells;
+  std::vector<std::vector<int32_t>> expiring(nl + 1);  // expiring[lv]: cells whose occupant was last read in level lv
+  int32_t next_cell = 0;
+  for (int lv = 0; lv < nl; lv++) {
+    // a cell read for the last time in level lv-1 (or earlier) may be written in level lv: the
+    // reads of a level (keyswitch / linear kernel) are queued before the writes of the NEXT level
+    if (lv > 0)
+      for (int32_t c : expiring[lv - 1]) free_cells.push_back(c);
+    for (int32_t j = p.level_ptr[lv]; j < p.level_ptr[lv + 1]; j++) {
+      int32_t c;
+      if (!free_cells.empty()) { c = free_cells.back(); free_cells.pop_back(); }
+      else c = next_cell++;
+      fp->scratch_idx[j] = c;
+      const int32_t lu = std::max(last_use[j], lv);  // a node nobody reads expires with its own level
+      if (lu != INT32_MAX) expiring[std::min(lu, nl)].push_back(c);
+    }
+  }
+  fp->n_scratch = next_cell;
 }
 
 extern "C" {
@@ -92,6 +126,11 @@ int fhes_program_info(const fhes_program *fp, int64_t info[8]) {
   info[6] = fp->n_slots;
   info[7] = fp->prog.n_pbs;
   return FHES_OK;
+}
+
+int32_t fhes_program_scratch_cells(const fhes_program *fp) {
+  if (!fp) return fail(FHES_ERR_INVALID, "null argument");
+  return fp->n_scratch;
 }
 
 int32_t fhes_program_out_parts(const fhes_program *fp, int32_t *parts, int32_t max_parts) {
@@ -203,7 +242,7 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
   if (out_base < 0) return out_base;
   int32_t scratch = -1;
   if (n_nodes > 0) {
-    scratch = arena_alloc_locked(ctx, n_nodes * n_inst);
+    scratch = arena_alloc_locked(ctx, fp->n_scratch * n_inst);
     if (scratch < 0) {
       arena_free_locked(ctx, out_base, out_total);
       return scratch;
@@ -215,7 +254,7 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
   for (int32_t inst = 0; inst < n_inst; inst++) {
     int32_t *m = &map[(size_t)inst * n_slots];
     for (int32_t i = 0; i < n_in; i++) m[i] = in_handles[(size_t)inst * n_in + i];
-    for (int32_t j = 0; j < n_nodes; j++) m[n_in + j] = scratch + inst * n_nodes + j;
+    for (int32_t j = 0; j < n_nodes; j++) m[n_in + j] = scratch + inst * fp->n_scratch + fp->scratch_idx[j];
     std::fill(taken.begin(), taken.end(), 0);
     for (int32_t k = 0; k < n_out; k++) {
       const int32_t s = p.out_slots[k];
@@ -250,7 +289,7 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
     }
   }
   // scratch is released in stream order: later work on this ctx is queued behind the reads
-  if (scratch >= 0) arena_free_locked(ctx, scratch, n_nodes * n_inst);
+  if (scratch >= 0) arena_free_locked(ctx, scratch, fp->n_scratch * n_inst);
   if (rc != FHES_OK) arena_free_locked(ctx, out_base, out_total);
   return rc;
 }

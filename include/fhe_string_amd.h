@@ -188,6 +188,9 @@ int fhes_program_info(const fhes_program *prog, int64_t info[8]);
 /* Block counts of the result objects, in order (e.g. find -> {1, Bu}; split -> {n, n*Bu, n*Bu};
  * strip_prefix -> {1, slots*Bc}).  Returns the number of parts. */
 int32_t fhes_program_out_parts(const fhes_program *prog, int32_t *parts, int32_t max_parts);
+/* Arena cells one instance of the program occupies while it runs (results excluded): node
+ * results share cells once every reader of the previous occupant ran in an earlier level. */
+int32_t fhes_program_scratch_cells(const fhes_program *prog);
 /* Export for execution elsewhere (tests run programs on the oracle / a plaintext model).
  * Slot numbering: inputs are slots [0,n_inputs); node j writes slot out_idx[j]. */
 int fhes_program_export(const fhes_program *prog, int32_t *level_ptr, int32_t *term_ptr,

@@ -108,3 +108,20 @@ def test_serialisation_round_trips(libs):
         FheString.from_bytes(blob[:100])
     with pytest.raises(FheError):
         ClientKey.from_bytes(b"nope" + blob[4:])
+
+
+def test_scratch_cells_are_reused(libs):
+    """node results share arena cells once all readers of the previous occupant ran in an earlier
+    level (program.hip: flatten); results keep their own cells"""
+    lib, _ = libs
+    from tests.progs import Prog
+    p = Params()
+    lib.fhes_params_default(C.byref(p))
+    for op, shape, bu in (("find", [65, 5], 4), ("split", [33, 2], 4), ("replace", [9, 3, 2, 8], 4)):
+        pr = Prog(p, op, shape, bu)
+        cells = lib.fhes_program_scratch_cells(pr.h)
+        assert 0 < cells <= pr.n_nodes
+        # the widest level is a lower bound, the node count an upper bound
+        widest = max(int(pr.level_ptr[i + 1] - pr.level_ptr[i]) for i in range(pr.n_levels))
+        assert cells >= widest
+    assert lib.fhes_program_scratch_cells(Prog(p, "find", [65, 5], 4).h) < 1000   # 1665 nodes
