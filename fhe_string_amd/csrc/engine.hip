@@ -226,14 +226,14 @@ static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d, unsigned long lon
   return FHES_OK;
 }
 
-template <int LOGN, int G, bool PIPE>
+template <int LOGN, int G, bool PIPE, bool LAT = false>
 static int launch_br_mb(fhes_ctx *ctx, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const int n_deg = (ctx->dims.n / G) * ((1 << G) - 1);
   constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
   const size_t lds = (size_t)2 * SLOTS * 16 + (size_t)M * 16 + (size_t)((n_deg + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_mb_kernel<LOGN, 23, G, PIPE>;
-  const unsigned bit = 8 + 2 * G + (PIPE ? 1 : 0);
+  auto kern = dev::blind_rotate_mb_kernel<LOGN, 23, G, PIPE, LAT>;
+  const unsigned bit = 8 + 4 * (G - 2) + (PIPE ? 1 : 0) + (LAT ? 2 : 0);
   if (!(ctx->attr_done & (1u << bit))) {
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -267,12 +267,15 @@ static int launch_br_v4(fhes_ctx *ctx, const dev::NodeDesc &d) {
 // variant: 0 = auto (latency kernel for launches that fit one workgroup per CU, throughput
 // kernel -- variant 4 -- otherwise), 1 / 2 / 3 / 4 = force
 static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
-  if (ctx->dims.g > 1) {  // multi-bit parameter sets: one kernel, with or without the bundle pipeline
-    if (ctx->dims.g == 3)
+  if (ctx->dims.g > 1) {
+    // multi-bit parameter sets: one kernel in three builds -- latency (launches of at most one
+    // workgroup per CU: everything in registers, bundle pipeline), throughput with the pipeline
+    // (g = 3) and without (g = 2).  br_variant 2 forces the latency build, 3 the throughput build.
+    const bool lat = ctx->br_variant == 2 || (ctx->br_variant == 0 && d.v_count <= ctx->n_cus);
+    if (ctx->dims.g == 3)  // measured: the latency build gains nothing for g = 3 (3.21 vs 3.16 ms)
       return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true>(ctx, d) : launch_br_mb<8, 3, true>(ctx, d);
-    const bool pipe = ctx->br_variant == 2 || (ctx->br_variant == 0 && d.v_count <= ctx->n_cus);
-    if (ctx->dims.N == 2048) return pipe ? launch_br_mb<11, 2, true>(ctx, d) : launch_br_mb<11, 2, false>(ctx, d);
-    return pipe ? launch_br_mb<8, 2, true>(ctx, d) : launch_br_mb<8, 2, false>(ctx, d);
+    if (ctx->dims.N == 2048) return lat ? launch_br_mb<11, 2, true, true>(ctx, d) : launch_br_mb<11, 2, false>(ctx, d);
+    return lat ? launch_br_mb<8, 2, true, true>(ctx, d) : launch_br_mb<8, 2, false>(ctx, d);
   }
   int variant = ctx->br_variant;
   if (variant == 0) variant = d.v_count <= ctx->n_cus ? 2 : 4;  // v2: 3.3 ms alone; v4: 2 per CU

@@ -1213,8 +1213,10 @@ __device__ __forceinline__ void fft_butterflies_tab_all(double2 (&x)[8], int q, 
   }
 }
 
-template <int LOGN, int BL, int G, bool PIPE>
-__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_mb_kernel(
+// LAT = true: the latency build -- one workgroup per CU (512 registers per lane), pass twiddles and
+// twist factors in registers (as variant 2), always with the bundle pipeline.
+template <int LOGN, int BL, int G, bool PIPE, bool LAT>
+__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LAT ? 1 : 2) void blind_rotate_mb_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
     int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
     const double2 *__restrict__ twist, const double2 *__restrict__ twist_inv /* twist / M */,
@@ -1254,6 +1256,17 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
   const double2 *twist_q = twist + q;
   const double2 *twist_inv_q = twist_inv + q;
+  double2 wA[7], wB[7], wC[7], twr[8], twir[8];  // latency build only (dead otherwise)
+  if (LAT) {
+    load_pass_twiddles<LOGM, LO_A>(wA, q, tw);
+    load_pass_twiddles<LOGM, LO_B>(wB, q, tw);
+    if (NP == 3) load_pass_twiddles<LOGM, LO_C>(wC, q, tw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      twr[e] = twist_q[e * TP];
+      twir[e] = twist_inv_q[e * TP];
+    }
+  }
   const __amdgpu_buffer_rsrc_t rs_g =
       __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_groups * NC * 4 * M * 16), 0x00020000);
   const unsigned voff_g = (unsigned)(r * 8 * TP + q) * 16u;  // G[((row*2 + r)*8 + e)*TP + q]
@@ -1386,23 +1399,23 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     double2 x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      x[e] = cmul(make_double2(digit1_f64<BL>(own_lo[e]), digit1_f64<BL>(own_hi[e])), twist_q[e * TP]);
+      x[e] = cmul(make_double2(digit1_f64<BL>(own_lo[e]), digit1_f64<BL>(own_hi[e])), LAT ? twr[e] : twist_q[e * TP]);
 
     // ---- forward FFT ----
-    fft_butterflies_tab_all<LOGM, true, LO_A>(x, q, T);
+    if (LAT) fft_butterflies_reg<true>(x, wA); else fft_butterflies_tab_all<LOGM, true, LO_A>(x, q, T);
 #pragma unroll
     for (int e = 0; e < 8; ++e) bufA[e * SA] = x[e];
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = bufB[e * SB];
-    fft_butterflies_tab_all<LOGM, true, LO_B>(x, q, T);
+    if (LAT) fft_butterflies_reg<true>(x, wB); else fft_butterflies_tab_all<LOGM, true, LO_B>(x, q, T);
     if (NP == 3) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) bufB[e * SB] = x[e];
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = bufC[e * SC];
-      fft_butterflies_tab_all<LOGM, true, LO_C>(x, q, T);
+      if (LAT) fft_butterflies_reg<true>(x, wC); else fft_butterflies_tab_all<LOGM, true, LO_C>(x, q, T);
     }
     fft_stage_bit0_dpp(x, sgn);
 
@@ -1421,7 +1434,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     }
     double2 twi[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) twi[e] = twist_inv_q[e * TP];
+    for (int e = 0; e < 8; ++e) twi[e] = LAT ? twir[e] : twist_inv_q[e * TP];
     if (PIPE) {
       bundle_degrees(jn);
       bundle_advance(jn, 0, QB);
@@ -1431,7 +1444,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     // ---- inverse FFT ----
     fft_stage_bit0_dpp(x, sgn);
     if (NP == 3) {
-      fft_butterflies_tab_all<LOGM, false, LO_C>(x, q, T);
+      if (LAT) fft_butterflies_reg<false>(x, wC); else fft_butterflies_tab_all<LOGM, false, LO_C>(x, q, T);
 #pragma unroll
       for (int e = 0; e < 8; ++e) bufC[e * SC] = x[e];
       if (PIPE) bundle_advance(jn, QB, QB);
@@ -1441,14 +1454,14 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     } else {
       if (PIPE) bundle_advance(jn, QB, QB);
     }
-    fft_butterflies_tab_all<LOGM, false, LO_B>(x, q, T);
+    if (LAT) fft_butterflies_reg<false>(x, wB); else fft_butterflies_tab_all<LOGM, false, LO_B>(x, q, T);
 #pragma unroll
     for (int e = 0; e < 8; ++e) bufB[e * SB] = x[e];
     if (PIPE) bundle_advance(jn, 2 * QB, QB);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = bufA[e * SA];
-    fft_butterflies_tab_all<LOGM, false, LO_A>(x, q, T);
+    if (LAT) fft_butterflies_reg<false>(x, wA); else fft_butterflies_tab_all<LOGM, false, LO_A>(x, q, T);
     if (PIPE) bundle_advance(jn, 3 * QB, NBATCH - 3 * QB);
 
     // ---- untwist, round to the torus: the new accumulator ----
