@@ -6,7 +6,7 @@
 
 One "step" = one pass of `find` over one batch of B independent (input, pattern) pairs that are
 already resident in HBM (default B = 256: every one of the 68 dependent levels then fills the 256
-CUs several times over; measured 91.1 / 93.8 / 94.1 / 94.4 k PBS/s at B = 170 / 256 / 512 / 1024; `--batch 1` times a single find).  The single-find wall-clock is measured too (untimed region)
+CUs several times over; with the round's first throughput kernel 91.1 / 93.8 / 94.1 / 94.4 k PBS/s at B = 170 / 256 / 512 / 1024; `--batch 1` times a single find).  The single-find wall-clock is measured too (untimed region)
 and reported as `find_wall_ms_single`.  With N > 1 (launched by torch.distributed.run, one process
 per GPU) every rank runs the same workload on its own B strings: independent strings shard with no
 data-path collective, so scaling is "weak" and `value` is the PBS all ranks executed per second.
@@ -197,7 +197,7 @@ def main():
     single_ms = (time.perf_counter() - t0) * 1e3
     single_ok = decode(1)[0] == pairs[0][0].find(pairs[0][1])
     free_outputs(1)
-    # opt-in parallel-prefix scan (same decrypted result, 13 instead of 69 dependent levels)
+    # opt-in parallel-prefix scan (same decrypted result, 12 instead of 68 dependent levels)
     prog_log = check_ptr(lib.fhes_program_compile(C.byref(params), b"find_logdepth", shape.ctypes.data, 2, 4))
     check(lib.fhes_program_info(prog_log, info))
     log_levels, log_pbs = int(info[3]), int(info[7])
