@@ -1,4 +1,5 @@
-"""Developer tool: where do the cycles of one CMUX iteration go in the throughput kernel?"""
+"""Developer tool: where do the cycles of one CMUX iteration go?  Runs the instrumented build of
+blind-rotate variant 3 (variant 4, the default throughput kernel, has the same phases minus one barrier)."""
 import ctypes as C
 import sys
 
@@ -9,7 +10,7 @@ from fhe_string_amd import _lib
 from fhe_string_amd._lib import Params, check, check_ptr
 
 NAMES = ["prefetch+rotate+digits+twist", "fwd pass A + write", "BARRIER 1", "read + fwd pass B + write", "BARRIER 2",
-         "read + fwd pass C + DPP", "BARRIER 3", "spectrum write", "BARRIER 4", "read other + ext. product",
+         "read + fwd pass C + DPP", "(barrier removed: spectra are written in place)", "spectrum write", "BARRIER 4", "read other + ext. product",
          "BARRIER 5", "DPP + inv pass C + write", "BARRIER 6", "read + inv pass B + write", "BARRIER 7",
          "read + inv pass A + untwist + round + acc", "BARRIER 8"]
 
