@@ -79,6 +79,42 @@ class Prog:
         return arena[self.out_slots[:self.n_outputs]], arena
 
 
+def run_oracle_batch(prog, w, input_cts_list, threads=8):
+    """S independent inputs through one program on the oracle, level by level across all of them
+    (what fhes_program_run_batch does on the device): every level is one OpenMP loop over
+    S * (nodes of the level) bootstraps.  Returns the list of output ciphertext arrays."""
+    S = len(input_cts_list)
+    ns = prog.n_slots
+    arena = np.zeros((S * ns, w.W), dtype=np.uint64)
+    for i, cts in enumerate(input_cts_list):
+        arena[i * ns:i * ns + prog.n_inputs] = cts
+    polys = np.zeros((max(prog.n_luts, 1), w.N), dtype=np.uint64)
+    for i in range(prog.n_luts):
+        t = np.ascontiguousarray(prog.lut_tables[i])
+        w.orc.oracle_make_lut_poly(w.oc, ptr(t), ptr(polys[i]))
+    level_ptr = [0]
+    tp, ti, tc, cs, li, oi = [0], [], [], [], [], []
+    for lv in range(prog.n_levels):
+        lo, hi = int(prog.level_ptr[lv]), int(prog.level_ptr[lv + 1])
+        for inst in range(S):
+            for j in range(lo, hi):
+                a, b = int(prog.term_ptr[j]), int(prog.term_ptr[j + 1])
+                ti.extend((prog.term_idx[a:b] + inst * ns).tolist())
+                tc.extend(prog.term_coef[a:b].tolist())
+                tp.append(len(ti))
+                cs.append(int(prog.consts[j]))
+                li.append(int(prog.lut_ids[j]))
+                oi.append(int(prog.out_idx[j]) + inst * ns)
+        level_ptr.append(len(cs))
+    A = lambda v, dt: np.ascontiguousarray(np.array(v if len(v) else [0], dtype=dt))
+    level_ptr, tp, ti, tc = A(level_ptr, np.int32), A(tp, np.int32), A(ti, np.int32), A(tc, np.int64)
+    cs, li, oi = A(cs, np.uint64), A(li, np.int32), A(oi, np.int32)
+    rc = w.orc.oracle_exec_levels(w.oc, ptr(arena), w.W, prog.n_levels, ptr(level_ptr), ptr(tp), ptr(ti), ptr(tc),
+                                  ptr(cs), ptr(li), ptr(polys), ptr(oi), threads)
+    assert rc == 0
+    return [arena[prog.out_slots[:prog.n_outputs] + i * ns] for i in range(S)]
+
+
 # ---- shared string plumbing (block encodings as in mod.rs:58-92) ----
 def num_blocks_usize(l, msg_mod=4):
     n, v = 0, 1

@@ -145,3 +145,19 @@ def test_reference_tables_with_real_encryption(case, w):
     outs, _ = p.run_oracle(w, cts)
     got = decode_result(case["op"], w.decrypt(outs), bu, case["a"])
     assert got == case["expect"], case
+
+
+def test_batched_oracle_run_equals_single_runs(libs):
+    """bench.py's cpu_baseline runs S finds level by level across all of them: same bits as S single runs"""
+    from tests.progs import Prog, run_oracle_batch
+    ww = world("toy")
+    bu = num_blocks_usize(255)
+    p = Prog(ww.p, "find", [6, 3], bu)
+    pairs = [("abcab", "ca"), ("xxxxx", "yx"), ("abcab", "ab")]
+    ins = [ww.encrypt(np.concatenate([string_blocks(t), string_blocks(q)])) for t, q in pairs]
+    outs = run_oracle_batch(p, ww, ins, threads=4)
+    for cts, out, (t, q) in zip(ins, outs, pairs):
+        single, _ = p.run_oracle(ww, cts)
+        assert np.array_equal(single, out)
+        got = decode_result("find", ww.decrypt(out), bu)
+        assert (-1 if got is None else got) == t.find(q)
