@@ -91,6 +91,7 @@ class ServerKey:
         self._h = check_ptr(_L().fhes_server_key_create(client_key._h, device))
         self.num_blocks_usize = client_key.num_blocks_usize
         self.num_blocks_char = client_key.num_blocks_char
+        self.params = client_key.params
 
     @property
     def ctx(self):
@@ -181,9 +182,34 @@ class FheUsize(_Ct):
     def decrypt(self, ck):
         return ck.decrypt_usize(self)
 
+    @staticmethod
+    def new_from_bool(k, b):
+        """mod.rs:431-433"""
+        return FheUsize(_op(k, "usize_from_bool", b)[0])
+
+    @staticmethod
+    def max(k):
+        """mod.rs:435-437: largest value an FheUsize of this key holds"""
+        return (1 << (k.params.message_bits * k.num_blocks_usize)) - 1
+
 
 class FheAsciiChar(_Ct):
-    """mod.rs:30-38"""
+    """mod.rs:30-38; predicates convert.rs:14-49, trim.rs:15-25"""
+
+    def is_uppercase(self, k):
+        return BooleanBlock(_op(k, "is_uppercase", self)[0])
+
+    def is_lowercase(self, k):
+        return BooleanBlock(_op(k, "is_lowercase", self)[0])
+
+    def is_whitespace(self, k):
+        return BooleanBlock(_op(k, "is_whitespace", self)[0])
+
+    def to_lowercase(self, k):
+        return FheAsciiChar(_op(k, "char_to_lowercase", self)[0])
+
+    def to_uppercase(self, k):
+        return FheAsciiChar(_op(k, "char_to_uppercase", self)[0])
 
     def decrypt(self, ck):
         d = _decrypt_digits(ck, self)
@@ -289,6 +315,15 @@ class FheString(_Ct):
 
     def max_len(self, sk_or_ck):
         return self.num_blocks // sk_or_ck.num_blocks_char - 1
+
+    @staticmethod
+    def max_len_with_key(k):
+        """mod.rs:240-244"""
+        return FheUsize.max(k)
+
+    def substr_eq(self, k, i, s):
+        """compare.rs:119-151: whether self[i..i+s.len] == s (clear index i)"""
+        return BooleanBlock(_op(k, "substr_eq", self, s, ints=(i,))[0])
 
     # --- search.rs ---
     def contains(self, k, s):

@@ -553,7 +553,8 @@ void push_all(std::vector<Blk> &out, const Radix &r) {
 
 }  // namespace
 
-// Operand signature of every operation: S = FheString, U = FheUsize, I = clear integer, V =
+// Operand signature of every operation: S = FheString, U = FheUsize, I = clear integer, C =
+// FheAsciiChar (num_blocks_char blocks), B = BooleanBlock (one block), V =
 // FheStringSliceVector (three ciphertext operands: is_some[n], start[n][Bu], end[n][Bu]).
 // `shape` lists, in operand order, the slot count of each S operand, the element count of each V
 // operand and the value of each I operand (U operands contribute nothing: they are
@@ -572,6 +573,9 @@ static const OpSig kOps[] = {
     {"replace", "SSSI"}, {"replacen", "SSSUI"}, {"add", "SS"}, {"insert", "SUS"}, {"repeat", "SUI"},
     // FheStringSliceVector methods (split.rs:30-113): V = the vector (is_some[n], start[n], end[n])
     {"slices_len", "V"}, {"slices_get", "VSU"}, {"slices_truncate", "VU"}, {"slices_reverse", "V"},
+    // compare.rs:119 (clear index), FheAsciiChar predicates (convert.rs:14,22; trim.rs:15), FheUsize::new_from_bool
+    {"substr_eq", "SIS"}, {"is_uppercase", "C"}, {"is_lowercase", "C"}, {"is_whitespace", "C"},
+    {"char_to_lowercase", "C"}, {"char_to_uppercase", "C"}, {"usize_from_bool", "B"},
 };
 
 const char *op_signature(const std::string &op) {
@@ -647,6 +651,8 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
     for (char c : sg) {
       if (c == 'S') { if (shape[k] < 1) throw std::invalid_argument("a string has at least its terminator slot"); n_inputs += shape[k++] * Bc; }
       else if (c == 'U') n_inputs += Bu;
+      else if (c == 'C') n_inputs += Bc;
+      else if (c == 'B') n_inputs += 1;
       else if (c == 'V') { if (shape[k] < 0) throw std::invalid_argument("negative element count"); n_inputs += shape[k++] * (1 + 2 * Bu); }
       else { if (shape[k] < 0) throw std::invalid_argument("negative integer argument"); k++; }
     }
@@ -657,6 +663,8 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
   std::vector<Str> strs;
   std::vector<Radix> us;
   std::vector<int64_t> ints;
+  std::vector<Radix> chars;
+  std::vector<Blk> bools;
   std::vector<S::Slice> vec;
   {
     int32_t next = 0;
@@ -675,6 +683,12 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
         Radix r;
         for (int q = 0; q < Bu; q++) r.push_back(b.input(next++, msg_mod - 1));
         us.push_back(r);
+      } else if (c == 'C') {
+        Radix r;
+        for (int q = 0; q < Bc; q++) r.push_back(b.input(next++, msg_mod - 1));
+        chars.push_back(r);
+      } else if (c == 'B') {
+        bools.push_back(b.input(next++, 1));
       } else if (c == 'V') {
         const int n = shape[k++];
         vec.resize(n);
@@ -748,6 +762,20 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
     put_str(s.insert(strs[0], s.len(strs[0]), strs[1], max_len_key));
   } else if (op == "insert") {  // insert.rs:48
     put_str(s.insert(strs[0], us[0], strs[1], max_len_key));
+  } else if (op == "substr_eq") {  // compare.rs:119-151
+    put_bool(s.substr_eq(strs[0], (size_t)ints[0], strs[1]));
+  } else if (op == "is_uppercase") {  // convert.rs:14-19
+    put_bool(o.bitand_(o.scalar_cmp(chars[0], 65, Cmp::GE), o.scalar_cmp(chars[0], 90, Cmp::LE)));
+  } else if (op == "is_lowercase") {  // convert.rs:22-27
+    put_bool(o.bitand_(o.scalar_cmp(chars[0], 97, Cmp::GE), o.scalar_cmp(chars[0], 122, Cmp::LE)));
+  } else if (op == "is_whitespace") {  // trim.rs:15-25
+    put_bool(s.is_whitespace(chars[0]));
+  } else if (op == "char_to_lowercase") {  // convert.rs:30-38
+    put_radix(s.to_lowercase_char(chars[0]));
+  } else if (op == "char_to_uppercase") {  // convert.rs:41-49
+    put_radix(s.to_uppercase_char(chars[0]));
+  } else if (op == "usize_from_bool") {  // mod.rs:431-433
+    put_radix(s.usize_from_bool(bools[0]));
   } else if (op == "repeat") {  // insert.rs:20
     put_str(s.repeat(strs[0], us[0], (size_t)ints[0], max_len_key));
   } else if (op == "slices_len") put_radix(s.slices_len(vec));

@@ -301,6 +301,12 @@ int fhes_string_op(fhes_server_key *sk, const char *op, fhes_ct *const *args, in
       ai += 3;
       continue;
     }
+    if (*c == 'C' || *c == 'B') {
+      const int32_t want = *c == 'C' ? sk->nb_char : 1;
+      if (args[ai]->n_blocks != want) return fail(FHES_ERR_INVALID, "operand %d is not %s", ai, *c == 'C' ? "an FheAsciiChar" : "a BooleanBlock");
+      ai++;
+      continue;
+    }
     if (*c == 'S') {
       if (args[ai]->n_blocks % sk->nb_char) return fail(FHES_ERR_INVALID, "operand %d is not a string", ai);
       shape.push_back(args[ai]->n_blocks / sk->nb_char);

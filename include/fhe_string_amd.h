@@ -166,7 +166,10 @@ int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles
 typedef struct fhes_program fhes_program;
 
 /* Operand signature of an operation: one letter per operand in the order of the reference's
- * method arguments (self first): S = FheString, U = FheUsize, I = clear integer, V =
+ * method arguments (self first): S = FheString, U = FheUsize, I = clear integer, C = FheAsciiChar
+ * (num_blocks_char blocks: "is_uppercase" / "is_lowercase" / "is_whitespace" / "char_to_lowercase" /
+ * "char_to_uppercase" -> "C"; convert.rs:14-49, trim.rs:15), B = BooleanBlock ("usize_from_bool" ->
+ * "B"; mod.rs:431), "substr_eq" -> "SIS" (self, clear index, pattern; compare.rs:119), V =
  * FheStringSliceVector (split.rs:21-28), which is THREE ciphertext operands is_some[n],
  * start[n][Bu], end[n][Bu] as returned by the split family.  E.g. "find" -> "SS", "splitn" ->
  * "SUS" (self, n, pattern), "replacen" -> "SSSUI", "repeat" -> "SUI" (insert.rs:20),

@@ -164,6 +164,10 @@ def build_inputs(lib, op, args, bu):
             digits.append(blk)
         elif c == "U":
             digits.append(usize_blocks(a["u"], bu))
+        elif c == "C":      # {"c": character code}
+            digits.append(np.array([(a["c"] >> (2 * k)) & 3 for k in range(4)], dtype=np.uint8))
+        elif c == "B":      # {"b": 0/1}
+            digits.append(np.array([int(a["b"])], dtype=np.uint8))
         elif c == "V":      # {"v": [(is_some, start, end), ...]}
             v = a["v"]
             shape.append(len(v))
@@ -209,8 +213,10 @@ def decode_generic(op, outs, parts, bu, self_str=None):
         return blocks_to_str(chunks[1]) if chunks[0][0] & 1 else None
     if op in OPTION_PAIR:
         return [blocks_to_str(chunks[1]), blocks_to_str(chunks[2])] if chunks[0][0] & 1 else None
-    if op == "char_at":
+    if op in ("char_at", "char_to_lowercase", "char_to_uppercase"):
         return radix_value(chunks[0]) & 0xFF
+    if op == "usize_from_bool":
+        return radix_value(chunks[0])
     return decode_result(op, outs, bu, self_str)
 
 

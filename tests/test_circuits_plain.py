@@ -257,3 +257,22 @@ def test_slice_vector_methods_and_repeat(libs):
         n, l = rnd.randint(0, 4), rnd.randint(0, 12)
         want = (a * n)[:l]
         assert run_ext("repeat", [S(a, pad), {"u": n}, {"i": l}])[0] == want, (a, pad, n, l)
+
+
+def test_remaining_public_methods(libs):
+    """substr_eq (compare.rs:119), FheAsciiChar predicates / case (convert.rs:14-49, trim.rs:15-25),
+    FheUsize::new_from_bool (mod.rs:431)"""
+    rnd = random.Random(11)
+    for a, i, b in [("abcabc", 0, "abc"), ("abcabc", 3, "abc"), ("abcabc", 1, "abc"), ("abc", 2, "c"), ("abc", 3, ""),
+                    ("abc", 1, "bcd"), ("", 0, ""), ("ab", 5, "a")]:
+        want = a[i:i + len(b)] == b if i <= len(a) else (b == "")
+        assert run_ext("substr_eq", [S(a), {"i": i}, S(b)])[0] == want, (a, i, b)
+    assert run_ext("substr_eq", [S("abc", 6), {"i": 1}, S("bc", 4)])[0] is True
+    for ch in [0, 9, 13, 14, 32, 64, 65, 90, 91, 96, 97, 122, 123, 127] + [rnd.randrange(128) for _ in range(10)]:
+        c = chr(ch)
+        assert run_ext("is_uppercase", [{"c": ch}])[0] == ("A" <= c <= "Z"), ch
+        assert run_ext("is_lowercase", [{"c": ch}])[0] == ("a" <= c <= "z"), ch
+        assert run_ext("is_whitespace", [{"c": ch}])[0] == (9 <= ch <= 13 or ch == 32), ch
+        assert run_ext("char_to_lowercase", [{"c": ch}])[0] == ord(c.lower()), ch
+        assert run_ext("char_to_uppercase", [{"c": ch}])[0] == ord(c.upper()), ch
+    assert run_ext("usize_from_bool", [{"b": 1}])[0] == 1 and run_ext("usize_from_bool", [{"b": 0}])[0] == 0

@@ -295,3 +295,23 @@ def test_reference_tables_with_multibit_keys(g, libs):
             assert run_api_ext(ck, sk, c) == c["expect"], (g, c)
     finally:
         sk.close()
+
+
+@pytest.mark.gpu
+def test_remaining_public_methods_on_gpu(keys):
+    """substr_eq (compare.rs:119), FheAsciiChar predicates / case conversion (convert.rs:14-49,
+    trim.rs:15-25), FheUsize::new_from_bool / max, FheString::max_len_with_key"""
+    ck, sk = keys
+    A = api.FheString.new(ck, "aB c", 6)
+    assert ck.decrypt_bool(A.substr_eq(sk, 1, api.FheString.new(ck, "B "))) is True
+    assert ck.decrypt_bool(A.substr_eq(sk, 0, api.FheString.new(ck, "B "))) is False
+    for i, ch in enumerate("aB c"):
+        c = A.char_at(sk, api.FheUsize.new(ck, i))
+        assert ck.decrypt_bool(c.is_uppercase(sk)) == ch.isupper()
+        assert ck.decrypt_bool(c.is_lowercase(sk)) == ch.islower()
+        assert ck.decrypt_bool(c.is_whitespace(sk)) == (ch == " ")
+        assert c.to_uppercase(sk).decrypt(ck) == ord(ch.upper())
+        assert c.to_lowercase(sk).decrypt(ck) == ord(ch.lower())
+    t = A.contains(sk, api.FheString.new(ck, "B"))
+    assert api.FheUsize.new_from_bool(sk, t).decrypt(ck) == 1
+    assert api.FheUsize.max(sk) == 255 and api.FheString.max_len_with_key(sk) == 255
