@@ -650,7 +650,9 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
     if (NP == 3) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
-      __syncthreads();
+      // B -> C never leaves a wave (q >> 6 is index bit LOGM-1 in both layouts): LDS operations of
+      // one wave execute in order, no workgroup barrier
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
       fft_butterflies_reg<true>(x, wC);
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1)
       fft_butterflies_reg<false>(x, wC);
 #pragma unroll
       for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();  // C -> B stays inside the wave as well
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
     }
