@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
     if (NP == 3) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) bufB[e * SB] = x[e];
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();  // B -> C stays inside a wave (q >> 6 is index bit LOGM-1 in both layouts)
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = bufC[e * SC];
       if (LAT) fft_butterflies_reg<true>(x, wC); else fft_butterflies_tab_all<LOGM, true, LO_C>(x, q, T);
@@ -1450,7 +1450,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
 #pragma unroll
       for (int e = 0; e < 8; ++e) bufC[e * SC] = x[e];
       if (PIPE) bundle_advance(jn, QB, QB);
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();  // C -> B stays inside a wave
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = bufB[e * SB];
     } else {
