@@ -1102,7 +1102,9 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 #pragma unroll
       for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
       load_pass_twiddles_tab<LOGM, LO_C>(w, q, T, wtop);
-      __syncthreads();  // B2
+      // B -> C stays inside a wave (q >> 6 is index bit LOGM-1 in both layouts; the slots of X that
+      // the spectrum write below touches belong to the same wave as well): no workgroup barrier
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
       fft_butterflies_reg<true>(x, w);
@@ -1131,10 +1133,11 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 #pragma unroll
       for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
       load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
-      __syncthreads();  // B4 (also: every read of the spectra in X is done)
+      __builtin_amdgcn_wave_barrier();  // C -> B stays inside a wave
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
       fft_butterflies_reg<false>(x, w);
+      __syncthreads();  // B4: every read of the spectra in X is done (X is written next)
     } else {
       fft_butterflies_reg<false>(x, w);  // w holds the pass-B twiddles
       __syncthreads();  // B4
