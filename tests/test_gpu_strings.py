@@ -315,3 +315,23 @@ def test_remaining_public_methods_on_gpu(keys):
     t = A.contains(sk, api.FheString.new(ck, "B"))
     assert api.FheUsize.new_from_bool(sk, t).decrypt(ck) == 1
     assert api.FheUsize.max(sk) == 255 and api.FheString.max_len_with_key(sk) == 255
+
+
+@pytest.mark.gpu
+def test_config5_find_rfind_512_padded_multibit(libs):
+    """BASELINE.json config 5 shape (500 characters padded to 512, 3-character pattern, l = 1023 =>
+    5 usize blocks) under the multi-bit g = 2 parameters: find and rfind (the other three operations
+    of the suite take minutes: scripts/config5.py, profiles/r01_config5_*.jsonl)"""
+    rng = np.random.default_rng(0xF4E50005)
+    body = "".join(chr(c) for c in rng.integers(0x21, 0x7F, size=494))
+    text = "  " + body[:200] + " " + body[200:] + "   "
+    pat = text[301:304]
+    ck, sk = api.generate_keys_with_params(api.multibit_params(2), 1023, seed=0xF4E50005)
+    try:
+        assert sk.num_blocks_usize == 5
+        A, P = api.FheString.new(ck, text, 512), api.FheString.new(ck, pat)
+        assert A.find(sk, P).decrypt(ck) == text.find(pat)
+        assert A.rfind(sk, P).decrypt(ck) == text.rfind(pat)
+        assert ck.decrypt_bool(A.contains(sk, api.FheString.new(ck, "\x7f\x7f\x7f"))) is False
+    finally:
+        sk.close()
