@@ -15,7 +15,10 @@ Blk Builder::input(int32_t i, uint32_t deg) const {
   Blk b;
   b.terms.push_back({i, 1});
   b.deg = deg;
-  b.noise = 0.0;  // fresh big-key encryption noise is ~2^-36 of a PBS output's
+  // An operand is either a fresh encryption (noise ~2^-36 of a PBS output's) or the result of an
+  // earlier operation, which `finish` hands over as a clean block of at most ONE unit: the
+  // worst case is what every circuit is sized for (chained operations).
+  b.noise = 1.0;
   return b;
 }
 
@@ -179,9 +182,14 @@ Blk Builder::bivar(const Blk &x, const Blk &y, int shift,
 }
 
 Program Builder::finish(const std::vector<Blk> &outputs, const std::string &name) {
-  // 1. materialise outputs
+  // 1. materialise outputs.  Results cross the program boundary as CLEAN blocks, like the results
+  // of tfhe-rs's default operations: noise of one bootstrap, degree below the message modulus
+  // (booleans: <= 1).  A result that is still a lazy linear combination of bootstrapped blocks is
+  // re-bootstrapped here; combinations of INPUT blocks only (re-wiring, trivial constants) carry
+  // no new noise and are materialised by the linear kernel.
   std::vector<int32_t> out_slots;
-  for (const Blk &o : outputs) {
+  for (Blk o : outputs) {
+    if (!o.trivial() && (o.noise > 1.0 || o.deg >= (uint32_t)msg_mod())) o = clean(o);
     if (o.terms.size() == 1 && o.terms[0].coef == 1 && o.cst == 0) {
       out_slots.push_back(o.terms[0].slot);
     } else {

@@ -1,4 +1,5 @@
 // strings.cpp -- the reference's string circuits, restated function by function over the
+// Derived work: restates matthiasgeihs/fhe_string (c) 2024 Matthias Geihs, BSD 3-Clause -- see NOTICE.
 // symbolic builder.  Each function cites the reference code it follows; the structure
 // (which tfhe::integer op is applied to what, in which order) is the reference's.
 #include "strings.h"
