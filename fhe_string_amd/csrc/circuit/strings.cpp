@@ -1,7 +1,7 @@
 // strings.cpp -- the reference's string circuits, restated function by function over the
-// Derived work: restates matthiasgeihs/fhe_string (c) 2024 Matthias Geihs, BSD 3-Clause -- see NOTICE.
 // symbolic builder.  Each function cites the reference code it follows; the structure
 // (which tfhe::integer op is applied to what, in which order) is the reference's.
+// Derived work: restates matthiasgeihs/fhe_string (c) 2024 Matthias Geihs, BSD 3-Clause -- see NOTICE.
 #include "strings.h"
 
 #include <algorithm>
@@ -22,6 +22,11 @@ struct Option {  // FheOption<FheUsize> (mod.rs:358-363)
 struct S {
   Ops &o;
   int Bc, Bu;
+  // Opt-in ("<op>_logdepth"): the serial scans of the reference (mod.rs:341-349, search.rs:91-109,
+  // 136-149, compare.rs:89-96, split.rs:274-319, 118-143, 147-205) are replaced by parallel-prefix
+  // forms that compute the SAME booleans / integers (checked against the faithful circuits on every
+  // table case and on random inputs).  The faithful circuits stay the default.
+  bool fast = false;
 
   size_t max_len(const Str &s) const { return s.size() - 1; }         // mod.rs:159-162
   Radix term_char() const { return o.trivial_radix(0, Bc); }           // mod.rs:265-267
@@ -96,6 +101,7 @@ struct S {
     std::vector<Blk> a_lt_b, a_eq_b;
     for (size_t i = 0; i < x.size(); i++) a_lt_b.push_back(o.cmp(x[i], y[i], Cmp::LT));
     for (size_t i = 0; i < x.size(); i++) a_eq_b.push_back(o.eq(x[i], y[i]));
+    if (fast) return lt_fold_logdepth(a_lt_b, a_eq_b);
     Blk is_lt = o.trivial_bool(false), is_eq = o.trivial_bool(true);
     for (size_t i = 0; i < x.size(); i++) {
       Blk t = o.bitand_(a_lt_b[i], is_eq);
@@ -103,6 +109,25 @@ struct S {
       is_eq = o.bitand_(is_eq, a_eq_b[i]);
     }
     return is_lt;
+  }
+  // inclusive prefix AND / OR (Sklansky: ceil(log2 n) levels, (n/2) log2 n lookups)
+  std::vector<Blk> prefix_scan(std::vector<Blk> v, bool is_and) {
+    const size_t n = v.size();
+    for (size_t span = 1; span < n; span <<= 1)
+      for (size_t i = 0; i < n; i++)
+        if ((i / span) & 1) {
+          const Blk &left = v[(i / span) * span - 1];
+          v[i] = is_and ? o.bitand_(v[i], left) : o.bitor_(v[i], left);
+        }
+    return v;
+  }
+  // compare.rs:89-96 without the carried state: is_eq before char i is the AND of eq_0..eq_{i-1};
+  // the terms lt_i & is_eq_i are mutually exclusive (only the first differing char can set one)
+  Blk lt_fold_logdepth(const std::vector<Blk> &a_lt_b, const std::vector<Blk> &a_eq_b) {
+    std::vector<Blk> pe = prefix_scan(a_eq_b, true);
+    std::vector<Blk> t;
+    for (size_t i = 0; i < a_lt_b.size(); i++) t.push_back(i == 0 ? a_lt_b[0] : o.bitand_(a_lt_b[i], pe[i - 1]));
+    return any(t);
   }
   Blk le(const Str &a, const Str &s) { return o.bitnot_(lt(s, a)); }  // compare.rs:56-59
   Blk ge(const Str &a, const Str &s) { return le(s, a); }             // compare.rs:102-104
@@ -130,6 +155,7 @@ struct S {
 
   // mod.rs:315-355
   Option index_of(const std::vector<Blk> &v, bool reverse) {
+    if (fast) return index_of_logdepth(v, reverse);
     Blk bfound = o.trivial_bool(false);
     Radix index = usize(0);
     std::vector<size_t> order;
@@ -154,10 +180,7 @@ struct S {
     const size_t n = v.size();
     if (reverse) std::reverse(v.begin(), v.end());
     if (n == 0) return {o.trivial_bool(false), usize(0)};
-    std::vector<Blk> pre = v;  // inclusive prefix OR
-    for (size_t span = 1; span < n; span <<= 1)
-      for (size_t i = 0; i < n; i++)
-        if ((i / span) & 1) pre[i] = o.bitor_(pre[i], pre[(i / span) * span - 1]);
+    std::vector<Blk> pre = prefix_scan(v, false);  // inclusive prefix OR
     std::vector<Radix> terms;
     for (size_t i = 0; i < n; i++) {
       Blk first = i == 0 ? v[0] : o.bitand_(v[i], o.bitnot_(pre[i - 1]));
@@ -183,7 +206,6 @@ struct S {
   // search.rs:17-28, 155-174, 216-244
   Blk contains(const Str &a, const Str &s) { return any(find_all(a, s)); }
   Option find(const Str &a, const Str &s) { return index_of(find_all(a, s), false); }
-  Option find_logdepth(const Str &a, const Str &s) { return index_of_logdepth(find_all(a, s), false); }
   Option rfind(const Str &a, const Str &s) {
     Option last = index_of(find_all(a, s), true);
     Blk empty = is_empty(s);
@@ -222,6 +244,8 @@ struct S {
   std::vector<Blk> find_all_non_overlapping(const Str &a, const Str &s) {
     std::vector<Blk> matches = find_all(a, s);
     Radix s_len = len(s);
+    if (fast && max_len(s) >= 1 && max_len(s) - 1 <= 7) return suppress_overlaps_logdepth(matches, s_len, max_len(s) - 1);
+    if (fast && max_len(s) == 0) return matches;  // the empty pattern suppresses nothing (j < 0 never holds)
     Blk in_match = o.trivial_bool(false);
     Radix j = usize(0);
     std::vector<Blk> out;
@@ -237,10 +261,121 @@ struct S {
     return out;
   }
 
+  // search.rs:91-109 as a finite automaton.  The loop's state between two positions is the number c
+  // of positions still covered by the last accepted match, 0 <= c <= W = max_len(s) - 1:
+  //     c > 0 : out_i = false, c' = c - 1         c == 0 : out_i = m_i, c' = m_i ? max(len(s) - 1, 0) : 0
+  // Position i is a function F_i on {0..W} (a table of W+1 blocks); the state before position i is
+  // (F_{i-1} o ... o F_0)(0), a prefix under composition: Sklansky scan, ceil(log2 n) levels.  Blocks
+  // of the scan that start at position 0 carry VALUES (function applied to the initial state), the
+  // others whole tables.  W <= 3: a table entry is two bits, one bivariate lookup selects per (s, t);
+  // W <= 7: an equality lookup and a boolean-gated lookup.
+  std::vector<Blk> suppress_overlaps_logdepth(const std::vector<Blk> &m, const Radix &s_len, size_t W) {
+    Builder &b = o.b;
+    const size_t n = m.size();
+    if (n == 0) return {};
+    if (W == 0) return m;  // len(s) <= 1: nothing is ever covered
+    const int K = (int)W + 1;  // number of states
+    // lm1 = max(len(s) - 1, 0) as ONE block (len(s) <= W + 1 <= 8 lives in the two low blocks)
+    Blk lo2 = s_len.size() > 1 ? b.add(b.tame(s_len[0], 1), b.scale(b.tame(s_len[1], o.M), o.M)) : b.tame(s_len[0], 1);
+    Blk lm1 = b.pbs(lo2, [](uint64_t v) { return v > 0 ? v - 1 : 0; });
+    lm1.deg = (uint32_t)W;
+    const int vbits = W <= 3 ? 2 : 3;  // bits of a state value
+    // gate(c, x) = c ? x : 0 for a boolean c and a state value x
+    auto gate = [&](const Blk &c, const Blk &x) -> Blk {
+      if (x.trivial()) return b.scale(c, x.cst);
+      if (c.trivial()) return c.cst ? x : b.trivial(0);
+      Blk r = b.bivar(c, x, vbits, [](uint64_t cb, uint64_t xv) { return cb ? xv : 0; });
+      return r;
+    };
+    using Fn = std::vector<Blk>;  // table: state -> state
+    auto sum_excl = [&](const std::vector<Blk> &terms) -> Blk {
+      Blk acc = b.trivial(0);
+      uint32_t deg = 0;
+      for (const Blk &t : terms) {
+        if (t.trivial() && t.cst == 0) continue;
+        deg = std::max(deg, std::max(acc.deg, t.deg));
+        acc = b.add(acc, t);
+        acc.deg = deg;
+      }
+      return acc;
+    };
+    // apply table f to state value g: f[g] = sum_t [g == t] * f[t]
+    auto apply = [&](const Fn &f, const Blk &g) -> Blk {
+      if (g.trivial()) return f[(size_t)g.cst];
+      std::vector<Blk> terms;
+      for (int t = 0; t < K; t++) {
+        if (f[t].trivial() && f[t].cst == 0) continue;
+        if (f[t].trivial()) {
+          const uint64_t tv = (uint64_t)t, fv = (uint64_t)f[t].cst;
+          Blk r = b.pbs(b.tame(g, 1), [tv, fv](uint64_t x) { return x == tv ? fv : 0; });
+          terms.push_back(r);
+        } else if (W <= 3) {
+          const uint64_t tv = (uint64_t)t;
+          terms.push_back(b.bivar(g, f[t], 2, [tv](uint64_t x, uint64_t y) { return x == tv ? y : 0; }));
+        } else {
+          const uint64_t tv = (uint64_t)t;
+          Blk is_t = b.pbs(b.tame(g, 1), [tv](uint64_t x) { return x == tv ? 1 : 0; });
+          terms.push_back(gate(is_t, f[t]));
+        }
+      }
+      Blk r = sum_excl(terms);
+      r.deg = std::min<uint32_t>(r.deg, (uint32_t)W);
+      return r;
+    };
+    // leaves
+    std::vector<Fn> fn(n);
+    for (size_t i = 0; i < n; i++) {
+      fn[i].resize(K);
+      fn[i][0] = gate(m[i], lm1);
+      fn[i][0].deg = std::min<uint32_t>(fn[i][0].deg, (uint32_t)W);
+      for (int c = 1; c < K; c++) fn[i][c] = b.trivial((uint64_t)(c - 1));
+    }
+    // Sklansky scan: after the scan, fn[i] is the composition F_i o ... o F_{start of its block}; blocks
+    // that start at 0 keep only the value at state 0 (val[i] = state AFTER position i)
+    std::vector<Blk> val(n);
+    std::vector<char> is_val(n, 0);
+    val[0] = fn[0][0];
+    is_val[0] = 1;
+    for (size_t span = 1; span < n; span <<= 1)
+      for (size_t i = 0; i < n; i++)
+        if ((i / span) & 1) {
+          const size_t left = (i / span) * span - 1;
+          if (is_val[left]) {
+            val[i] = apply(fn[i], val[left]);
+            is_val[i] = 1;
+          } else {
+            Fn comp(K);
+            for (int c = 0; c < K; c++) comp[c] = apply(fn[i], fn[left][c]);
+            fn[i] = comp;
+          }
+        }
+    std::vector<Blk> out(n);
+    out[0] = m[0];
+    for (size_t i = 1; i < n; i++) {
+      // out_i = m_i & [state before i == 0]
+      const Blk &c = val[i - 1];
+      if (c.trivial()) { out[i] = c.cst == 0 ? m[i] : b.trivial(0); continue; }
+      if (m[i].trivial()) {
+        out[i] = m[i].cst ? b.pbs(b.tame(c, 1), [](uint64_t x) { return x == 0 ? 1 : 0; }) : b.trivial(0);
+        continue;
+      }
+      out[i] = b.bivar(c, m[i], 1, [](uint64_t x, uint64_t y) { return (x == 0 && y) ? 1 : 0; });
+    }
+    return out;
+  }
+
   // search.rs:114-152 (iterates `matches` front to back, exactly as the code does)
   std::vector<Blk> rfind_all_non_overlapping(const Str &a, const Str &s) {
     std::vector<Blk> matches = find_all(a, s);
     Radix s_len = len(s);
+    if (fast) {
+      // In the loop `c = j_lt & mi` is always false (mi is forced to false whenever j_lt holds), so j
+      // is the public counter k + 1 and the loop computes  mi_k = m_k & !(k + 1 < len(s)).
+      std::vector<Blk> out;
+      for (size_t k = 0; k < matches.size(); k++)
+        out.push_back(o.bitand_(matches[k], o.bitnot_(o.scalar_cmp(s_len, k + 1, Cmp::GT))));
+      return out;
+    }
     Radix zero = usize(0), j = usize(1);
     std::vector<Blk> out;
     for (const Blk &m0 : matches) {
@@ -423,7 +558,30 @@ struct S {
   struct Slice { Blk is_some; Radix start, end; };  // FheOption<FheStringSlice> split.rs:10-28
 
   // split.rs:116-144
+  // exclusive AND of !is_some over the entries before k (forward) or after k (backward)
+  std::vector<Blk> none_before(const std::vector<Slice> &v, bool backward) {
+    const size_t n = v.size();
+    std::vector<Blk> ns(n);
+    for (size_t k = 0; k < n; k++) ns[k] = o.bitnot_(v[backward ? n - 1 - k : k].is_some);
+    std::vector<Blk> incl = prefix_scan(ns, true), out(n);
+    for (size_t k = 0; k < n; k++) {
+      const Blk e = k == 0 ? o.trivial_bool(true) : incl[k - 1];
+      out[backward ? n - 1 - k : k] = e;
+    }
+    return out;
+  }
+
   void truncate_last_if_empty(std::vector<Slice> &v) {
+    if (fast) {  // bb before entry k (walking backwards) = no later entry is Some
+      std::vector<Blk> bb = none_before(v, true);
+      for (size_t k = 0; k < v.size(); k++) {
+        Slice &vi = v[k];
+        Blk is_empty = o.cmp(vi.start, vi.end, Cmp::GE);
+        Blk b_s_e = all({bb[k], vi.is_some, is_empty});
+        vi.is_some = o.bitand_(o.bitnot_(b_s_e), vi.is_some);
+      }
+      return;
+    }
     Blk bb = o.trivial_bool(true);
     for (size_t k = v.size(); k-- > 0;) {
       Slice &vi = v[k];
@@ -472,8 +630,13 @@ struct S {
   }
   // split.rs:147-173
   void expand_first(std::vector<Slice> &v) {
-    Blk not_found = o.trivial_bool(true);
     Radix zero = usize(0);
+    if (fast) {
+      std::vector<Blk> nf = none_before(v, false);
+      for (size_t k = 0; k < v.size(); k++) v[k].start = o.if_then_else(o.bitand_(nf[k], v[k].is_some), zero, v[k].start);
+      return;
+    }
+    Blk not_found = o.trivial_bool(true);
     for (Slice &vi : v) {
       Blk nf_and_some = o.bitand_(not_found, vi.is_some);
       vi.start = o.if_then_else(nf_and_some, zero, vi.start);
@@ -482,8 +645,13 @@ struct S {
   }
   // split.rs:176-205
   void expand_last(std::vector<Slice> &v, const Str &a) {
-    Blk not_found = o.trivial_bool(true);
     Radix self_len = len(a);
+    if (fast) {
+      std::vector<Blk> nf = none_before(v, true);
+      for (size_t k = 0; k < v.size(); k++) v[k].end = o.if_then_else(o.bitand_(nf[k], v[k].is_some), self_len, v[k].end);
+      return;
+    }
+    Blk not_found = o.trivial_bool(true);
     for (size_t k = v.size(); k-- > 0;) {
       Slice &vi = v[k];
       Blk nf_and_some = o.bitand_(not_found, vi.is_some);
@@ -527,6 +695,31 @@ struct S {
     Radix n_hidden = o.scalar_add(self_len, 2);
     Radix next_match = self_len;
     std::vector<Slice> elems(n);
+    std::vector<Radix> next_fast;
+    if (fast) {
+      // split.rs:301 carries `next_match` from the back: next_match_i = target_j of the first j >= i
+      // with matches_j, else len(self).  That is a suffix scan under (f1, v1) . (f2, v2) = (f1 | f2,
+      // f1 ? v1 : v2) with a sentinel (true, len(self)) behind the last position: Sklansky over the
+      // reversed positions, ceil(log2 (n+1)) levels.
+      std::vector<Blk> F(n + 1);
+      std::vector<Radix> V(n + 1);
+      F[0] = o.trivial_bool(true);
+      V[0] = self_len;
+      for (size_t k = 1; k <= n; k++) {
+        const size_t i = n - k;
+        F[k] = i < matches.size() ? matches[i] : o.trivial_bool(false);
+        V[k] = inclusive ? o.scalar_add(p_len, i) : usize(i);
+      }
+      for (size_t span = 1; span < n + 1; span <<= 1)
+        for (size_t k = 0; k < n + 1; k++)
+          if ((k / span) & 1) {
+            const size_t left = (k / span) * span - 1;
+            V[k] = o.if_then_else(F[k], V[k], V[left]);  // the nearer range (smaller i) wins
+            F[k] = o.bitor_(F[k], F[left]);
+          }
+      next_fast.resize(n);
+      for (size_t i = 0; i < n; i++) next_fast[i] = V[n - i];
+    }
     for (size_t i = n; i-- > 0;) {
       Blk is_some;
       if (i == 0) {
@@ -539,7 +732,7 @@ struct S {
       }
       Radix target = inclusive ? o.scalar_add(p_len, i) : usize(i);
       Blk matches_i = i < matches.size() ? matches[i] : o.trivial_bool(false);
-      next_match = o.if_then_else(matches_i, target, next_match);
+      next_match = fast ? next_fast[i] : o.if_then_else(matches_i, target, next_match);
       Radix start = i > 0 ? o.sub(usize(i), usize_from_bool(pattern_empty)) : usize(0);
       elems[i] = {is_some, start, next_match};
     }
@@ -562,7 +755,7 @@ void push_all(std::vector<Blk> &out, const Radix &r) {
 // num_blocks_usize blocks).
 struct OpSig { const char *name; const char *sig; };
 static const OpSig kOps[] = {
-    {"find", "SS"}, {"find_logdepth", "SS"}, {"rfind", "SS"}, {"contains", "SS"}, {"starts_with", "SS"}, {"ends_with", "SS"},
+    {"find", "SS"}, {"rfind", "SS"}, {"contains", "SS"}, {"starts_with", "SS"}, {"ends_with", "SS"},
     {"eq", "SS"}, {"ne", "SS"}, {"lt", "SS"}, {"le", "SS"}, {"gt", "SS"}, {"ge", "SS"},
     {"eq_ignore_ascii_case", "SS"}, {"is_empty", "S"}, {"len", "S"},
     {"split", "SS"}, {"rsplit", "SS"}, {"split_inclusive", "SS"}, {"split_terminator", "SS"},
@@ -579,7 +772,16 @@ static const OpSig kOps[] = {
     {"char_to_lowercase", "C"}, {"char_to_uppercase", "C"}, {"usize_from_bool", "B"},
 };
 
-const char *op_signature(const std::string &op) {
+// "<op>_logdepth" selects the parallel-prefix forms of the serial scans (S::fast)
+static std::string base_op(const std::string &op, bool *fast = nullptr) {
+  static const std::string suffix = "_logdepth";
+  const bool f = op.size() > suffix.size() && op.compare(op.size() - suffix.size(), suffix.size(), suffix) == 0;
+  if (fast) *fast = f;
+  return f ? op.substr(0, op.size() - suffix.size()) : op;
+}
+
+const char *op_signature(const std::string &op_full) {
+  const std::string op = base_op(op_full);
   for (const auto &e : kOps)
     if (op == e.name) return e.sig;
   if (op == "find_all_range") return "SSII";
@@ -587,8 +789,10 @@ const char *op_signature(const std::string &op) {
   return nullptr;
 }
 
-Program compile_op(const fhes_params &p, const std::string &op, const std::vector<int32_t> &shape,
+Program compile_op(const fhes_params &p, const std::string &op_full, const std::vector<int32_t> &shape,
                    int32_t num_blocks_usize) {
+  bool fast = false;
+  const std::string op = base_op(op_full, &fast);
   const int msg_mod = 1 << p.message_bits;
   int Bc = 0;
   for (int v = 1; v < 128; v *= msg_mod) Bc++;  // lib.rs:60-61
@@ -604,14 +808,14 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
       throw std::invalid_argument("find_all_range needs {slots_a, slots_b, lo, hi} with 0 <= lo <= hi <= slots_a - 1");
     Builder b(p, (shape[0] + shape[1]) * Bc);
     Ops o(b);
-    S s{o, Bc, Bu};
+    S s{o, Bc, Bu, fast};
     Str sa, sb;
     int32_t next = 0;
     for (int c = 0; c < shape[0]; c++) { Radix ch; for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1)); sa.push_back(ch); }
     for (int c = 0; c < shape[1]; c++) { Radix ch; for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1)); sb.push_back(ch); }
     std::vector<Blk> out;
     for (int i = shape[2]; i < shape[3]; i++) out.push_back(s.substr_eq(sa, (size_t)i, sb));  // search.rs:33-41
-    Program prog = b.finish(out, op);
+    Program prog = b.finish(out, op_full);
     prog.out_parts = {(int32_t)out.size()};
     return prog;
   }
@@ -620,7 +824,7 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
     if (shape.size() != 1 || shape[0] < 0) throw std::invalid_argument(op + " needs {n}");
     Builder b(p, shape[0]);
     Ops o(b);
-    S s{o, Bc, Bu};
+    S s{o, Bc, Bu, fast};
     std::vector<Blk> v;
     for (int i = 0; i < shape[0]; i++) v.push_back(b.input(i, 1));
     std::vector<Blk> out;
@@ -660,7 +864,7 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
   }
   Builder b(p, n_inputs);
   Ops o(b);
-  S s{o, Bc, Bu};
+  S s{o, Bc, Bu, fast};
   std::vector<Str> strs;
   std::vector<Radix> us;
   std::vector<int64_t> ints;
@@ -714,8 +918,8 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
     parts.push_back((int32_t)v.size() * Bu);
   };
 
-  if (op == "find" || op == "rfind" || op == "find_logdepth") {
-    Option r = op == "find" ? s.find(strs[0], strs[1]) : op == "rfind" ? s.rfind(strs[0], strs[1]) : s.find_logdepth(strs[0], strs[1]);
+  if (op == "find" || op == "rfind") {
+    Option r = op == "find" ? s.find(strs[0], strs[1]) : s.rfind(strs[0], strs[1]);
     put_bool(r.is_some);
     put_radix(r.val);
   } else if (op == "contains") put_bool(s.contains(strs[0], strs[1]));
@@ -817,7 +1021,7 @@ Program compile_op(const fhes_params &p, const std::string &op, const std::vecto
     } else throw std::invalid_argument("unhandled operation '" + op + "'");
     put_slices(v);
   }
-  Program prog = b.finish(out, op);
+  Program prog = b.finish(out, op_full);
   prog.out_parts = parts;
   return prog;
 }

@@ -1171,6 +1171,246 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 }
 
 // ------------------------------------------------------------------------------------------
+// K2+K3 (variant 5): variant 4 with the INTEGER side of an iteration rewritten -- same transforms,
+// same roundings, same bits.  Measured on gfx950 (scripts/micro/f64_rate.hip): every VALU slot
+// costs ~4.4 cycles next to f64 work, a VALU write of VCC followed by a VALU read of it costs two
+// extra wait states (the compiler pads `v_sub_co / v_subb` and `v_cmp / v_cndmask` with s_nop), and
+// variant 4 spends 16 issue slots per coefficient on the rotated read -> signed digit path and 8 on
+// the accumulator update.  Here:
+//   * registers and the LDS image hold the NEGATED accumulator  nacc = -acc  (mod 2^64), so the
+//     decomposed difference  (+-)acc[s] - acc[p]  is  nacc[p] + ((-+)nacc[s])  -- additions only;
+//   * the conditional negation of the rotated operand is  (v ^ M) + c  with the wrap mask M taken
+//     from one bit of the rotated index (v_bfe_i32), no compare / select;
+//   * 64-bit additions are single v_lshl_add_u64 instructions (no carry chain through VCC); the
+//     rounding bit 2^40 of the closest-representable digit rides in the high word of the constant
+//     pair that carries c;
+//   * the accumulator update adds rint(-y) = -rint(y) (round-half-even is symmetric; the untwist
+//     factors enter negated through the free f64 source modifiers), the two dwords of the rounded
+//     value are assembled in place and added with one v_lshl_add_u64.
+// LDS layout, barriers, FFT passes: exactly variant 4.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b) {  // one instruction, no VCC
+  uint64_t r;
+  asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// rint(y) mod 2^64 as in torus_from_f64_fast, returned so that ONE 64-bit add consumes it
+__device__ __forceinline__ uint64_t torus_from_f64_pair(double y) {
+  const double C0 = 0x1.8p116, C1 = 0x1.8p84, C2 = 0x1.8p52;
+  const double h0 = (y + C0) - C0;
+  const double z = y - h0;
+  const double t1 = z + C1;
+  const double rem = z - (t1 - C1);
+  const double t2 = rem + C2;
+  // high dword: low mantissa dword of t1 + (0 or -1 from the sign of rem); low dword: that of t2
+  uint32_t hi = (uint32_t)__double2loint(t1) + (((uint32_t)__double2hiint(t2) & 0xFFFFFu) - 0x80000u);
+  asm("" : "+v"(hi));  // opaque: keeps the compiler from spreading (a + b) << 32 over several 64-bit adds
+  return ((uint64_t)hi << 32) | (uint64_t)(uint32_t)__double2loint(t2);
+}
+
+template <int LOGN, int BL>
+__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v5_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
+    int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
+    const double2 *__restrict__ twist, const double2 *__restrict__ twist_inv /* twist / M */,
+    const double2 *__restrict__ tw) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
+  constexpr int NP = (LOGM - 1) / 3;
+  static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
+  static_assert(BL >= 1 && BL <= 31, "single-level digit must fit the high dword");
+  constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N] image of -acc  } Y
+  double2 *ybuf = reinterpret_cast<double2 *>(smem_raw);                      // [2][M]                }
+  double2 *xbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][SLOTS]    X
+  double2 *T = xbuf + (size_t)2 * SLOTS;                                      // [M/2] stage tables
+  uint16_t *at = reinterpret_cast<uint16_t *>(T + M / 2);
+
+  const int tid = threadIdx.x;
+  const int r = tid / TP;
+  const int q = tid % TP;
+  const double sgn = (q & 1) ? -1.0 : 1.0;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  for (int j = tid; j <= n_small; j += blockDim.x)
+    at[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  for (int idx = 2 + tid; idx < M / 2; idx += blockDim.x) {
+    const int beta = 31 - __builtin_clz(idx);  // idx = 2^beta + j
+    T[idx] = tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
+  }
+  __syncthreads();
+
+  constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
+  constexpr int SA = fpad(1 << LO_A), SB = fpad(1 << LO_B), SC = fpad(1 << LO_C);
+  double2 wtop[4];  // stage LOGM-1 of pass A: tw[q + TP * e], e = 0..3
+#pragma unroll
+  for (int e = 0; e < 4; ++e) wtop[e] = tw[fft_point<LOGM, LO_A, 3>(q, e) & (M / 2 - 1)];
+  const __amdgpu_buffer_rsrc_t rs_g =
+      __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_small * 4 * M * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc((void *)twist, 0, M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ti = __builtin_amdgcn_make_buffer_rsrc((void *)twist_inv, 0, M * 16, 0x00020000);
+  const unsigned voff_q = (unsigned)q * 16u;                 // twist[q + e*TP]
+  const unsigned voff_g = (unsigned)(r * 8 * TP + q) * 16u;  // G[((row*2 + r)*8 + e)*TP + q]
+
+  // nacc: NEGATED coefficients p = q + e*TP (lo) and p + M (hi) of polynomial r
+  uint64_t nlo[8], nhi[8];
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      nlo[e] = (uint64_t)0 - v0;
+      nhi[e] = (uint64_t)0 - v1;
+      acc[(size_t)r * N + p] = nlo[e];
+      acc[(size_t)r * N + p + M] = nhi[e];
+    }
+  }
+  __syncthreads();
+
+  const unsigned ybase = (unsigned)(r * N * 8);              // byte offset of polynomial r inside Y (bits >= LOGN+3)
+  uint64_t *acc_w = acc + (size_t)r * N + q;  // own coefficient p = q + e*TP lives at acc_w[e * TP]
+  double2 *xA = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_A, 3>(q, 0));
+  double2 *xB = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_B, 3>(q, 0));
+  double2 *xC = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
+  const double2 *xCo = xbuf + (size_t)(1 - r) * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
+  double2 *y_r = ybuf + (size_t)r * M;
+  const unsigned char *ybytes = smem_raw;
+
+  // closest-representable digit of x with the rounding bit already added to x:
+  // (int)hi >> (32 - BL)
+  constexpr uint64_t ROUND = (uint64_t)1 << (63 - BL);
+
+  int a_next = (int)at[0];
+  for (int i = 0; i < n_small; ++i) {
+    const int a = a_next;
+    a_next = (int)at[i + 1];  // requested one iteration ahead: off the critical path (at has n+1 entries)
+    if (a == 0) continue;
+
+    // twist factors first, GGSW prefetch after they have been consumed (vmcnt completes in order)
+    double2 twv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) twv[e] = buf_load_d2(rs_tw, voff_q, (unsigned)(e * TP * 16));
+    double2 x[8];
+    {
+      // byte offset of the rotated coefficient (q - a) mod 2N, with the wrap bit (bit LOGN+3 of the byte
+      // offset) INVERTED: the image holds -acc, the operand wanted is +acc[s] when the rotation wrapped
+      // (X^N = -1) and -acc[s] = image[s] when it did not.
+      const unsigned t0 = ((unsigned)(q - a) << 3) ^ (1u << (LOGN + 3));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        uint64_t dd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned se = t0 + (unsigned)((e * TP + h * M) * 8);
+          const unsigned off = (se & (unsigned)((N - 1) * 8)) | ybase;
+          const uint64_t v = *reinterpret_cast<const uint64_t *>(ybytes + off);
+          const int m32 = __builtin_amdgcn_sbfe(se, LOGN + 3, 1);       // 0: take image (= -acc[s]); -1: take -image
+          const uint64_t mm = ((uint64_t)(uint32_t)m32 << 32) | (uint64_t)(uint32_t)m32;  // both dwords: m32 is 0 or -1
+          const uint64_t k = ROUND | (uint64_t)(uint32_t)(m32 & 1);     // carry of the negation + rounding bit of the digit
+          dd[h] = add64(add64(v ^ mm, h == 0 ? nlo[e] : nhi[e]), k);
+        }
+        const double d0 = (double)((int)(uint32_t)(dd[0] >> 32) >> (32 - BL));
+        const double d1 = (double)((int)(uint32_t)(dd[1] >> 32) >> (32 - BL));
+        x[e] = cmul(make_double2(d0, d1), twv[e]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double2 g0[8], g1[8];
+    {
+      const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        g0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
+        g1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
+      }
+    }
+    double2 w[7];
+    load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
+    fft_butterflies_reg<true>(x, w);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xA[e * SA] = x[e];
+    load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
+    __syncthreads();  // B1 (also: every rotated read of Y is done)
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = xB[e * SB];
+    fft_butterflies_reg<true>(x, w);
+    if (NP == 3) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+      load_pass_twiddles_tab<LOGM, LO_C>(w, q, T, wtop);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
+      fft_butterflies_reg<true>(x, w);
+    }
+    fft_stage_bit0_dpp(x, sgn);
+
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xC[e * SC] = x[e];
+    __syncthreads();  // B3
+    if (r == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], xCo[e * SC], g0[e], g1[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(xCo[e * SC], x[e], g0[e], g1[e]);
+    }
+    double2 twi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) twi[e] = buf_load_d2(rs_ti, voff_q, (unsigned)(e * TP * 16));
+
+    fft_stage_bit0_dpp(x, sgn);
+    if (NP == 3) {
+      fft_butterflies_reg<false>(x, w);  // w still holds the pass-C twiddles
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+      load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
+      __builtin_amdgcn_wave_barrier();  // C -> B stays inside a wave
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+      fft_butterflies_reg<false>(x, w);
+      __syncthreads();  // B4
+    } else {
+      fft_butterflies_reg<false>(x, w);
+      __syncthreads();  // B4
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xB[e * SB] = x[e];
+    load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
+    __syncthreads();  // B5
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = xA[e * SA];
+    fft_butterflies_reg<false>(x, w);
+
+    // ---- untwist (negated factors: -y), round, nacc += rint(-y); the image goes back into Y ----
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double2 v = cmul_conj(x[e], make_double2(-twi[e].x, -twi[e].y));
+      nlo[e] = add64(torus_from_f64_pair(v.x), nlo[e]);
+      nhi[e] = add64(torus_from_f64_pair(v.y), nhi[e]);
+      acc_w[e * TP] = nlo[e];
+      acc_w[e * TP + M] = nhi[e];
+    }
+    __syncthreads();  // B6
+    __builtin_amdgcn_s_setprio(3);
+  }
+
+  // ---- sample extract from the image of -acc: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? (uint64_t)0 - acc[0] : acc[N - j];
+  if (tid == 0) out[N] = (uint64_t)0 - acc[N];
+}
+
+// ------------------------------------------------------------------------------------------
 // K4: multi-bit blind rotate (grouping factor G = 2 or 3) + sample extract.  Same transforms,
 // rounding and FMA chains as the classic kernels, different step:
 //     bundle = G_0 + sum_{c=1}^{2^G-1} G_c * X^{deg_c}      (Fourier domain, c ascending)

@@ -12,16 +12,19 @@
 #define REP8(S) S S S S S S S S
 #define REP64(S) REP8(REP8(S))
 
-enum { K_FMA64, K_ADD64, K_MUL64, K_FMA32, K_DPP, K_CVT, K_LSHLADD64, K_SUB64, K_CNDMASK, K_PERMSWAP, K_AND, K_MIX, K_COUNT };
+enum { K_FMA64, K_ADD64, K_MUL64, K_FMA32, K_DPP, K_CVT, K_LSHLADD64, K_SUB64, K_CNDMASK, K_PERMSWAP, K_AND, K_MIX, K_CND_INDEP, K_CND_SGPR, K_XOR, K_ADDC, K_COUNT };
 static const char *kNames[K_COUNT] = {"v_fma_f64", "v_add_f64", "v_mul_f64", "v_fma_f32", "v_mov_b32_dpp", "v_cvt_f64_i32",
                                       "v_lshl_add_u64", "v_sub_co+v_subb (pair)", "v_cndmask_b32", "v_permlane32_swap",
-                                      "v_and_b32", "mix 5 fma_f64 : 3 int"};
+                                      "v_and_b32", "mix 5 fma_f64 : 3 int",
+                                      "v_cndmask_b32 vcc (independent)", "v_cndmask_b32 e64 sgpr cond", "v_xor_b32", "v_add_co+v_addc (pair)"};
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void k(unsigned long long *stamps, double *sink, int iters, double a, double b) {
   double x0 = threadIdx.x + 1.0, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
   int i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3;
   unsigned long long u0 = threadIdx.x, u1 = u0 * 3;
+  const int j0 = threadIdx.x * 7 + 1, j1 = threadIdx.x * 5 + 2;
+  const unsigned long long smask = 0x5555555555555555ull ^ (unsigned long long)iters;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
   for (int i = 0; i < iters; i++) {
@@ -36,7 +39,11 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *stamps, double *si
     if (KIND == K_CNDMASK) { REP8(asm volatile("v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n v_cndmask_b32 %2, %3, %0, vcc\n v_cndmask_b32 %3, %0, %1, vcc\n v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n v_cndmask_b32 %2, %3, %0, vcc\n v_cndmask_b32 %3, %0, %1, vcc" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "vcc");) }
     if (KIND == K_PERMSWAP) { REP8(asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %0, %2\n v_permlane32_swap_b32 %1, %3\n v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %0, %2\n v_permlane32_swap_b32 %1, %3" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
     if (KIND == K_AND) { REP8(asm volatile("v_and_b32 %0, %1, %2\n v_and_b32 %1, %2, %3\n v_and_b32 %2, %3, %0\n v_and_b32 %3, %0, %1\n v_and_b32 %0, %1, %2\n v_and_b32 %1, %2, %3\n v_and_b32 %2, %3, %0\n v_and_b32 %3, %0, %1" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
-    if (KIND == K_MIX) { REP8(asm volatile("v_fma_f64 %0, %0, %8, %9\n v_and_b32 %10, %11, %12\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_and_b32 %11, %12, %13\n v_fma_f64 %3, %3, %8, %9\n v_fma_f64 %4, %4, %8, %9\n v_and_b32 %12, %13, %10" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b), "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
+    if (KIND == K_CND_INDEP) { REP8(asm volatile("v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %5, %4, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n v_cndmask_b32 %3, %5, %4, vcc\n v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %5, %4, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n v_cndmask_b32 %3, %5, %4, vcc" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(j0), "v"(j1) : "vcc");) }
+    if (KIND == K_CND_SGPR) { REP8(asm volatile("v_cndmask_b32 %0, %4, %5, %6\n v_cndmask_b32 %1, %5, %4, %6\n v_cndmask_b32 %2, %4, %5, %6\n v_cndmask_b32 %3, %5, %4, %6\n v_cndmask_b32 %0, %4, %5, %6\n v_cndmask_b32 %1, %5, %4, %6\n v_cndmask_b32 %2, %4, %5, %6\n v_cndmask_b32 %3, %5, %4, %6" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(j0), "v"(j1), "s"(smask));) }
+    if (KIND == K_XOR) { REP8(asm volatile("v_xor_b32 %0, %1, %2\n v_xor_b32 %1, %2, %3\n v_xor_b32 %2, %3, %0\n v_xor_b32 %3, %0, %1\n v_xor_b32 %0, %1, %2\n v_xor_b32 %1, %2, %3\n v_xor_b32 %2, %3, %0\n v_xor_b32 %3, %0, %1" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+    if (KIND == K_ADDC) { REP8(asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %3, vcc\n v_add_co_u32 %2, vcc, %2, %0\n v_addc_co_u32 %3, vcc, %3, %1, vcc\n v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %3, vcc\n v_add_co_u32 %2, vcc, %2, %0\n v_addc_co_u32 %3, vcc, %3, %1, vcc" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "vcc");) }
+    if (KIND == K_MIX) { REP8(asm volatile("v_fma_f64 %0, %0, %12, %13\n v_and_b32 %8, %9, %10\n v_fma_f64 %1, %1, %12, %13\n v_fma_f64 %2, %2, %12, %13\n v_and_b32 %9, %10, %11\n v_fma_f64 %3, %3, %12, %13\n v_fma_f64 %4, %4, %12, %13\n v_and_b32 %10, %11, %8" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(i0), "+v"(i1), "+v"(i2) : "v"(i3), "v"(a), "v"(b));) }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *stamps, double *si
 
 template <int KIND>
 static void run(unsigned long long *d_st, double *d_sink, int wps, int n_cu) {
-  const int iters = KIND == K_FMA32 || KIND == K_AND || KIND == K_CNDMASK ? 40000 : 20000;
+  const int iters = KIND == K_FMA32 || KIND == K_AND || KIND == K_XOR ? 40000 : 20000;
   dim3 grid(n_cu), block(64 * 4 * wps);  // one block per CU
   const int n_waves = n_cu * 4 * wps;
   std::vector<unsigned long long> st(2 * (size_t)n_waves);
@@ -89,8 +96,8 @@ int main() {
   if (hipGetDeviceProperties(&prop, 0) == hipSuccess) n_cu = prop.multiProcessorCount;
   unsigned long long *d_st;
   double *d_sink;
-  hipMalloc(&d_st, (size_t)n_cu * 16 * 2 * 8);
-  hipMalloc(&d_sink, (size_t)n_cu * 1024 * 8);
+  hipMalloc(&d_st, (size_t)(n_cu + 1) * 16 * 2 * 8);
+  hipMalloc(&d_sink, (size_t)(n_cu + 1) * 1024 * 8);
   for (int wps : {1, 2, 4}) {
     run<K_FMA64>(d_st, d_sink, wps, n_cu);
     run<K_ADD64>(d_st, d_sink, wps, n_cu);
@@ -104,6 +111,10 @@ int main() {
     run<K_PERMSWAP>(d_st, d_sink, wps, n_cu);
     run<K_AND>(d_st, d_sink, wps, n_cu);
     run<K_MIX>(d_st, d_sink, wps, n_cu);
+    run<K_CND_INDEP>(d_st, d_sink, wps, n_cu);
+    run<K_CND_SGPR>(d_st, d_sink, wps, n_cu);
+    run<K_XOR>(d_st, d_sink, wps, n_cu);
+    run<K_ADDC>(d_st, d_sink, wps, n_cu);
   }
   return 0;
 }

@@ -195,7 +195,13 @@ OPTION_STRING = {"strip_prefix", "strip_suffix"}
 OPTION_PAIR = {"split_once", "rsplit_once"}
 
 
+def base_op(op):
+    """"<op>_logdepth" (opt-in parallel-prefix circuits) decodes like <op>"""
+    return op[:-len("_logdepth")] if op.endswith("_logdepth") else op
+
+
 def decode_generic(op, outs, parts, bu, self_str=None):
+    op = base_op(op)
     outs = [int(v) for v in outs]
     chunks, off = [], 0
     for n in parts:
@@ -224,8 +230,9 @@ def decode_result(op, outs, bu, s=None):
     """decoded message values of the program outputs -> Python value as the reference's
     decrypt would give (FheOption::decrypt mod.rs:378-386, FheStringSliceVector::decrypt
     split.rs:208-226)."""
+    op = base_op(op)
     outs = [int(v) for v in outs]
-    if op in ("find", "rfind", "find_logdepth"):
+    if op in ("find", "rfind"):
         return radix_value(outs[1:1 + bu]) if outs[0] & 1 else None
     if op == "len":
         return radix_value(outs[:bu])

@@ -276,3 +276,65 @@ def test_remaining_public_methods(libs):
         assert run_ext("char_to_lowercase", [{"c": ch}])[0] == ord(c.lower()), ch
         assert run_ext("char_to_uppercase", [{"c": ch}])[0] == ord(c.upper()), ch
     assert run_ext("usize_from_bool", [{"b": 1}])[0] == 1 and run_ext("usize_from_bool", [{"b": 0}])[0] == 0
+
+
+# ---- opt-in log-depth circuits ("<op>_logdepth"): same results as the faithful circuits --------
+LOGDEPTH_OPS = {"find", "rfind", "lt", "le", "gt", "ge", "split", "rsplit", "split_inclusive", "split_terminator",
+                "rsplit_terminator", "splitn", "rsplitn", "split_once", "rsplit_once", "trim", "trim_start", "trim_end",
+                "strip_suffix", "split_ascii_whitespace"}
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["op"] in LOGDEPTH_OPS],
+                         ids=lambda c: f"{c['op']}-{c['a']!r}-{c['b']!r}-{c['a_pad']}")
+def test_logdepth_reference_tables(case, libs):
+    got, _ = run_plain(case["op"] + "_logdepth", case["a"], case["a_pad"], case["b"], case["b_pad"])
+    assert got == case["expect"], case
+
+
+@pytest.mark.parametrize("case", [c for c in CASES_EXT if c["op"] in LOGDEPTH_OPS],
+                         ids=lambda c: f"{c['op']}-{c['args'][0].get('s')!r}-{len(c['args'])}")
+def test_logdepth_reference_tables_ext(case, libs):
+    got, _ = run_ext(case["op"] + "_logdepth", case["args"])
+    assert got == case["expect"], case
+
+
+def test_logdepth_equals_faithful_on_random_inputs(libs):
+    """every block of every output, not only the decoded value: the log-depth circuits must compute the
+    same booleans and integers as the faithful ones (overlapping patterns, padded patterns up to the
+    automaton's window of 7, empty pattern, matches at the ends)"""
+    import numpy as np
+    rnd = random.Random(0x10D)
+    for trial in range(70):
+        la = rnd.randint(0, 9)
+        a = "".join(rnd.choice("xa") for _ in range(la))
+        p = "".join(rnd.choice("xa") for _ in range(rnd.randint(0, 3)))
+        a_pad = rnd.choice([None, la + rnd.randint(0, 3)])
+        p_pad = rnd.choice([None, len(p) + rnd.randint(0, 5)])
+        for op in ("find", "rfind", "lt", "ge", "split", "rsplit", "split_inclusive", "split_terminator", "rsplit_terminator"):
+            if p == "" and "split" in op:
+                continue    # undefined in the reference (split.rs:337-338): covered by the table cases only
+            bu = num_blocks_usize(255)
+            ins = [string_blocks(a, a_pad), string_blocks(p, p_pad)]
+            shape = [len(x) // 4 for x in ins]
+            digits = np.concatenate(ins).astype("int64")
+            ref = prog(op, shape, bu).run_plain(digits)
+            fast = prog(op + "_logdepth", shape, bu).run_plain(digits)
+            # message digits (mod 4; booleans mod 2 are covered by it) of every output block
+            assert [int(v) % 4 for v in ref] == [int(v) % 4 for v in fast], (op, a, a_pad, p, p_pad)
+    for trial in range(12):
+        a = "".join(rnd.choice("xa") for _ in range(rnd.randint(1, 7)))
+        p = "".join(rnd.choice("xa") for _ in range(rnd.randint(1, 2)))
+        n = rnd.randint(0, 3)
+        for op in ("splitn", "rsplitn"):
+            assert run_ext(op + "_logdepth", [S(a), {"u": n}, S(p)])[0] == run_ext(op, [S(a), {"u": n}, S(p)])[0], (op, a, p, n)
+        w = "".join(rnd.choice("a b\t") for _ in range(rnd.randint(0, 7)))
+        for op in ("trim", "trim_start", "trim_end", "split_ascii_whitespace"):
+            assert run_ext(op + "_logdepth", [S(w)])[0] == run_ext(op, [S(w)])[0], (op, w)
+
+
+def test_logdepth_depth_and_size(libs):
+    """what the opt-in circuits buy at BASELINE config 3 / 5 sizes (levels = dependent launch pairs)"""
+    bu = num_blocks_usize(512)
+    for op, shape in (("split", [129, 4]), ("lt", [65, 65]), ("rfind", [129, 4])):
+        ref, fast = prog(op, shape, bu), prog(op + "_logdepth", shape, bu)
+        assert fast.n_levels * 4 < ref.n_levels, (op, fast.n_levels, ref.n_levels)
