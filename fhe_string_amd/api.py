@@ -97,6 +97,12 @@ class ServerKey:
     def ctx(self):
         return _L().fhes_server_key_ctx(self._h)
 
+    def set_logdepth(self, enabled=True):
+        """Opt-in: run the parallel-prefix ("<op>_logdepth") form of every circuit that has a serial scan
+        (find / rfind / lt.. / split family / trim): identical results, tens instead of thousands of
+        dependent levels.  Default off: the reference's own circuits."""
+        check(_L().fhes_server_key_set_logdepth(self._h, 1 if enabled else 0))
+
     def stats(self):
         st = _lib.Stats()
         check(_L().fhes_get_stats(self.ctx, C.byref(st)))

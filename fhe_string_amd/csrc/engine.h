@@ -24,6 +24,7 @@ struct fhes_ctx {
   // ciphertext arena: u64 [capacity][ct_stride]
   uint64_t *arena = nullptr;
   int64_t capacity = 0;
+  bool arena_fixed = false;  // FHES_ARENA_SLOTS given: no growth
   int ct_stride = 0;
   std::map<int32_t, int32_t> free_ranges;  // first -> count (coalesced)
   int64_t in_use = 0;

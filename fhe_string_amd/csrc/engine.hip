@@ -60,8 +60,42 @@ static bool kernels_support(const fhes_params &p, std::string *why) {
 }
 
 // ---- arena (first-fit free list of handle ranges) -----------------------------------------
-int32_t arena_alloc_locked(fhes_ctx *ctx, int32_t count) {
-  if (count <= 0) return fail(FHES_ERR_INVALID, "arena_alloc: count must be positive");
+// Grows the arena to at least `min_capacity` slots (handles are slot numbers, so they stay valid):
+// new allocation, device-to-device copy, old one released.  Called with the stream idle.
+static int arena_grow_locked(fhes_ctx *ctx, int64_t min_capacity) {
+  if (min_capacity <= ctx->capacity) return FHES_OK;
+  if (ctx->arena_fixed) return fail(FHES_ERR_OOM, "ciphertext arena exhausted (%lld slots, fixed by FHES_ARENA_SLOTS)", (long long)ctx->capacity);
+  int64_t cap = std::max<int64_t>(min_capacity + min_capacity / 8, ctx->capacity * 2);
+  cap = std::min<int64_t>(cap, (int64_t)INT32_MAX - 1);
+  const size_t row = (size_t)ctx->ct_stride * 8;
+  size_t free_b = 0, total_b = 0;
+  FHES_HIP(hipSetDevice(ctx->device));
+  FHES_HIP(hipStreamSynchronize(ctx->stream));
+  FHES_HIP(hipMemGetInfo(&free_b, &total_b));
+  const int64_t fit = (int64_t)((free_b - std::min<size_t>(free_b, (size_t)1 << 30)) / row);  // keep 1 GiB for keys / staging
+  if (cap > fit) cap = fit;
+  if (cap < min_capacity)
+    return fail(FHES_ERR_OOM, "ciphertext arena cannot grow to %lld slots (%.1f GB): %.1f GB of device memory free",
+                (long long)min_capacity, (double)min_capacity * row / 1e9, (double)free_b / 1e9);
+  uint64_t *bigger = nullptr;
+  FHES_HIP(hipMalloc(&bigger, (size_t)cap * row));
+  hipError_t e = hipMemcpy(bigger, ctx->arena, (size_t)ctx->capacity * row, hipMemcpyDeviceToDevice);
+  if (e != hipSuccess) { (void)hipFree(bigger); return hip_fail(e, "arena copy"); }
+  FHES_HIP(hipFree(ctx->arena));
+  ctx->arena = bigger;
+  const int32_t old_cap = (int32_t)ctx->capacity;
+  ctx->capacity = cap;
+  // append [old_cap, cap) to the free list (merging with a free range that ends at old_cap)
+  int32_t first = old_cap, count = (int32_t)(cap - old_cap);
+  if (!ctx->free_ranges.empty()) {
+    auto last = std::prev(ctx->free_ranges.end());
+    if (last->first + last->second == old_cap) { first = last->first; count += last->second; ctx->free_ranges.erase(last); }
+  }
+  ctx->free_ranges[first] = count;
+  return FHES_OK;
+}
+
+static int32_t arena_take(fhes_ctx *ctx, int32_t count) {
   for (auto it = ctx->free_ranges.begin(); it != ctx->free_ranges.end(); ++it) {
     if (it->second >= count) {
       const int32_t first = it->first, left = it->second - count;
@@ -71,8 +105,27 @@ int32_t arena_alloc_locked(fhes_ctx *ctx, int32_t count) {
       return first;
     }
   }
-  return fail(FHES_ERR_OOM, "ciphertext arena exhausted (%lld slots; set FHES_ARENA_SLOTS)",
-              (long long)ctx->capacity);
+  return -1;
+}
+
+// The arena starts at 2^16 slots (1.1 GB) and grows on demand (a program run asks for
+// n_inst * fhes_program_scratch_cells at once): sized by what runs, not by an environment variable.
+// FHES_ARENA_SLOTS, when set, pins the size instead (no growth).
+int32_t arena_alloc_locked(fhes_ctx *ctx, int32_t count) {
+  if (count <= 0) return fail(FHES_ERR_INVALID, "arena_alloc: count must be positive");
+  int32_t h = arena_take(ctx, count);
+  if (h >= 0) return h;
+  // the request must fit behind the last used slot at worst
+  int64_t tail_free = 0;
+  if (!ctx->free_ranges.empty()) {
+    auto last = std::prev(ctx->free_ranges.end());
+    if (last->first + last->second == ctx->capacity) tail_free = last->second;
+  }
+  const int rc = arena_grow_locked(ctx, ctx->capacity + (int64_t)count - tail_free);
+  if (rc) return rc;
+  h = arena_take(ctx, count);
+  if (h < 0) return fail(FHES_ERR_OOM, "ciphertext arena exhausted (%lld slots)", (long long)ctx->capacity);
+  return h;
 }
 
 int arena_free_locked(fhes_ctx *ctx, int32_t first, int32_t count) {
@@ -267,7 +320,7 @@ static int launch_br_v4(fhes_ctx *ctx, const dev::NodeDesc &d) {
 template <int LOGN>
 static int launch_br_v5(fhes_ctx *ctx, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
-  constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
+  constexpr int SLOTS = M;
   const size_t lds = (size_t)2 * N * 8 + (size_t)2 * SLOTS * 16 + (size_t)(M / 2) * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
   auto kern = dev::blind_rotate_v5_kernel<LOGN, 23>;
   if (!(ctx->attr_done & (1u << 6))) {
@@ -459,7 +512,8 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   }
   ctx->ct_stride = d.big + 16;
   const char *env = getenv("FHES_ARENA_SLOTS");
-  ctx->capacity = env ? atoll(env) : (int64_t)1 << 19;  // 2^19 slots * 16.5 KB = 8.7 GB of the 288 GB
+  ctx->arena_fixed = env != nullptr;
+  ctx->capacity = env ? atoll(env) : (int64_t)1 << 16;  // 2^16 slots * 16.5 KB = 1.1 GB; grows on demand
   if (ctx->capacity < 64) ctx->capacity = 64;
   if ((e = hipMalloc(&ctx->arena, (size_t)ctx->capacity * ctx->ct_stride * 8)) != hipSuccess) return bail(e, "hipMalloc(arena)");
   ctx->free_ranges[0] = (int32_t)ctx->capacity;
@@ -578,6 +632,7 @@ int32_t fhes_lut_register(fhes_ctx *ctx, const uint64_t *table, int32_t n) {
 int32_t fhes_arena_alloc(fhes_ctx *ctx, int32_t count) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
   std::lock_guard<std::mutex> lk(ctx->mu);
+  FHES_HIP(hipSetDevice(ctx->device));
   return arena_alloc_locked(ctx, count);
 }
 

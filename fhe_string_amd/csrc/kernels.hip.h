@@ -1218,7 +1218,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   constexpr int NP = (LOGM - 1) / 3;
   static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
   static_assert(BL >= 1 && BL <= 31, "single-level digit must fit the high dword");
-  constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
+  constexpr int SLOTS = M;  // X is XOR-swizzled like Y (fswz): the padded layout of variant 4 costs one
+                            // extra LDS cycle per lane group on every ds_read_b128 (the groups are
+                            // {0-3,12-15,20-27}.., not 16 consecutive lanes) -- measured 96 conflict cycles per
+                            // wave and iteration (SQ_LDS_BANK_CONFLICT), predicted exactly by the bank model
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N] image of -acc  } Y
   double2 *ybuf = reinterpret_cast<double2 *>(smem_raw);                      // [2][M]                }
@@ -1243,7 +1246,6 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   __syncthreads();
 
   constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
-  constexpr int SA = fpad(1 << LO_A), SB = fpad(1 << LO_B), SC = fpad(1 << LO_C);
   double2 wtop[4];  // stage LOGM-1 of pass A: tw[q + TP * e], e = 0..3
 #pragma unroll
   for (int e = 0; e < 4; ++e) wtop[e] = tw[fft_point<LOGM, LO_A, 3>(q, e) & (M / 2 - 1)];
@@ -1277,10 +1279,8 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 
   const unsigned ybase = (unsigned)(r * N * 8);              // byte offset of polynomial r inside Y (bits >= LOGN+3)
   uint64_t *acc_w = acc + (size_t)r * N + q;  // own coefficient p = q + e*TP lives at acc_w[e * TP]
-  double2 *xA = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_A, 3>(q, 0));
-  double2 *xB = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_B, 3>(q, 0));
-  double2 *xC = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
-  const double2 *xCo = xbuf + (size_t)(1 - r) * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
+  double2 *x_r = xbuf + (size_t)r * SLOTS;
+  const double2 *x_o = xbuf + (size_t)(1 - r) * SLOTS;
   double2 *y_r = ybuf + (size_t)r * M;
   const unsigned char *ybytes = smem_raw;
 
@@ -1336,12 +1336,12 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
     fft_butterflies_reg<true>(x, w);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) xA[e * SA] = x[e];
+    for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
     load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
     __syncthreads();  // B1 (also: every rotated read of Y is done)
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = xB[e * SB];
+    for (int e = 0; e < 8; ++e) x[e] = x_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
     fft_butterflies_reg<true>(x, w);
     if (NP == 3) {
 #pragma unroll
@@ -1355,14 +1355,14 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     fft_stage_bit0_dpp(x, sgn);
 
 #pragma unroll
-    for (int e = 0; e < 8; ++e) xC[e * SC] = x[e];
+    for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
     __syncthreads();  // B3
     if (r == 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], xCo[e * SC], g0[e], g1[e]);
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], x_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], g0[e], g1[e]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(xCo[e * SC], x[e], g0[e], g1[e]);
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], x[e], g0[e], g1[e]);
     }
     double2 twi[8];
 #pragma unroll
@@ -1384,11 +1384,11 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       __syncthreads();  // B4
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) xB[e * SB] = x[e];
+    for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
     load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
     __syncthreads();  // B5
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = xA[e * SA];
+    for (int e = 0; e < 8; ++e) x[e] = x_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
     fft_butterflies_reg<false>(x, w);
 
     // ---- untwist (negated factors: -y), round, nacc += rint(-y); the image goes back into Y ----

@@ -16,6 +16,7 @@ struct fhes_server_key {  // server_key.rs:11-17
   fhes_params p;
   fhes_ctx *ctx = nullptr;
   int32_t msg_mod = 0, nb_char = 0, nb_usize = 0;
+  bool logdepth = false;  // opt-in: every operation compiles its "<op>_logdepth" form
   std::mutex mu;
   std::map<std::string, fhes_program *> cache;
 };
@@ -87,6 +88,13 @@ void fhes_server_key_destroy(fhes_server_key *sk) {
 }
 
 fhes_ctx *fhes_server_key_ctx(fhes_server_key *sk) { return sk ? sk->ctx : nullptr; }
+
+int fhes_server_key_set_logdepth(fhes_server_key *sk, int32_t enabled) {
+  if (!sk) return fail(FHES_ERR_INVALID, "null server key");
+  std::lock_guard<std::mutex> lk(sk->mu);
+  sk->logdepth = enabled != 0;
+  return FHES_OK;
+}
 
 // mod.rs:58-92
 fhes_ct *fhes_string_encrypt(fhes_client_key *ck, const char *s, int64_t pad, int32_t *status) {
@@ -272,13 +280,20 @@ int fhes_ct_decrypt_blocks(const fhes_client_key *ck, fhes_ct *c, uint8_t *value
   return FHES_OK;
 }
 
-int fhes_string_op(fhes_server_key *sk, const char *op, fhes_ct *const *args, int32_t n_args,
+int fhes_string_op(fhes_server_key *sk, const char *op_in, fhes_ct *const *args, int32_t n_args,
                    const int64_t *iargs, int32_t n_iargs, fhes_ct **outs, int32_t max_outs,
                    int32_t *n_outs) {
-  if (!sk || !op || !args || n_args < 1 || !outs || !n_outs) return fail(FHES_ERR_INVALID, "bad argument");
-  const char *sig = fhes_op_signature(op);
-  if (!sig) return fail(FHES_ERR_INVALID, "unknown operation '%s'", op);
+  if (!sk || !op_in || !args || n_args < 1 || !outs || !n_outs) return fail(FHES_ERR_INVALID, "bad argument");
+  const char *sig = fhes_op_signature(op_in);
+  if (!sig) return fail(FHES_ERR_INVALID, "unknown operation '%s'", op_in);
   std::lock_guard<std::mutex> lk(sk->mu);
+  std::string op_name = op_in;
+  {
+    static const std::string suffix = "_logdepth";
+    const bool has = op_name.size() > suffix.size() && op_name.compare(op_name.size() - suffix.size(), suffix.size(), suffix) == 0;
+    if (sk->logdepth && !has) op_name += suffix;
+  }
+  const char *op = op_name.c_str();
   std::vector<int32_t> shape;
   std::string key = op;
   int ai = 0, ii = 0;

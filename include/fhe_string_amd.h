@@ -220,6 +220,11 @@ typedef struct fhes_ct fhes_ct;                 /* radix ciphertext: FheString /
 fhes_server_key *fhes_server_key_create(const fhes_client_key *ck, int32_t device);
 void fhes_server_key_destroy(fhes_server_key *sk);
 fhes_ctx *fhes_server_key_ctx(fhes_server_key *sk);
+/* Opt-in: every later fhes_string_op on this key runs the "<op>_logdepth" form of its circuit -- the
+ * serial scans of the reference (mod.rs:341-349, search.rs:91-109, compare.rs:89-96, split.rs:274-319)
+ * replaced by parallel-prefix forms with identical results (tests/test_circuits_plain.py).  Default
+ * off: the faithful circuits.  An operation name may also carry the suffix itself. */
+int fhes_server_key_set_logdepth(fhes_server_key *sk, int32_t enabled);
 
 /* FheString::new (mod.rs:58-92).  pad < 0 means None.  Returns NULL and sets
  * *status to one of FHES_ERR_NOT_ASCII.. on validation failure. */
