@@ -317,16 +317,16 @@ static int launch_br_v4(fhes_ctx *ctx, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
-template <int LOGN>
+template <int LOGN, int PRIO = 0>
 static int launch_br_v5(fhes_ctx *ctx, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   constexpr int SLOTS = M;
   const size_t lds = (size_t)2 * N * 8 + (size_t)2 * SLOTS * 16 + (size_t)(M / 2) * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_v5_kernel<LOGN, 23>;
-  if (!(ctx->attr_done & (1u << 6))) {
+  auto kern = dev::blind_rotate_v5_kernel<LOGN, 23, PRIO>;
+  if (!(ctx->attr_done & (1u << (20 + PRIO)))) {
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ctx->attr_done |= 1u << 6;
+    ctx->attr_done |= 1u << (20 + PRIO);
   }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
@@ -335,8 +335,8 @@ static int launch_br_v5(fhes_ctx *ctx, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
-// variant: 0 = auto (latency kernel for launches that fit one workgroup per CU, throughput
-// kernel -- variant 4 -- otherwise), 1 / 2 / 3 / 4 = force
+// variant: 0 = auto (variant 5), 1..7 = force (1 simple, 2 register-resident latency build, 3 / 4 earlier
+// throughput builds, 5 current, 6 / 7 = 5 with other wave-priority policies); all produce the same bits
 static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
   if (ctx->dims.g > 1) {
     // multi-bit parameter sets: one kernel in three builds -- latency (launches of at most one
@@ -349,12 +349,14 @@ static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
     return lat ? launch_br_mb<8, 2, true, true>(ctx, d) : launch_br_mb<8, 2, false>(ctx, d);
   }
   int variant = ctx->br_variant;
-  if (variant == 0) variant = d.v_count <= ctx->n_cus ? 2 : 4;  // v2: 3.3 ms alone; v4: 2 per CU
+  // auto: variant 5 for every launch size (measured round 2: 3.26 ms for <= 256 ciphertexts against
+  // 3.39 ms of the register-resident latency build, 120 k against 114.6 k PBS/s of variant 4 in wide launches)
+  if (variant == 0) variant = 5;
   if (ctx->dims.N == 2048)
     return variant == 1 ? launch_br_v1<11>(ctx, d) : variant == 2 ? launch_br_v2<11>(ctx, d)
-         : variant == 4 ? launch_br_v4<11>(ctx, d) : variant == 5 ? launch_br_v5<11>(ctx, d) : launch_br_v3<11, false>(ctx, d);
+         : variant == 4 ? launch_br_v4<11>(ctx, d) : variant == 5 ? launch_br_v5<11>(ctx, d) : variant == 6 ? launch_br_v5<11, 1>(ctx, d) : variant == 7 ? launch_br_v5<11, 2>(ctx, d) : launch_br_v3<11, false>(ctx, d);
   return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 2 ? launch_br_v2<8>(ctx, d)
-       : variant == 4 ? launch_br_v4<8>(ctx, d) : variant == 5 ? launch_br_v5<8>(ctx, d) : launch_br_v3<8, false>(ctx, d);
+       : variant == 4 ? launch_br_v4<8>(ctx, d) : variant == 5 ? launch_br_v5<8>(ctx, d) : variant == 6 ? launch_br_v5<8, 1>(ctx, d) : variant == 7 ? launch_br_v5<8, 2>(ctx, d) : launch_br_v3<8, false>(ctx, d);
 }
 
 static int take_event(fhes_ctx *ctx, hipEvent_t *e) {
@@ -730,7 +732,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  if (v < 0 || v > 5) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
+  if (v < 0 || v > 7) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
   ctx->br_variant = v;
   return FHES_OK;
 }

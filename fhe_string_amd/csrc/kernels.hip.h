@@ -1208,7 +1208,10 @@ __device__ __forceinline__ uint64_t torus_from_f64_pair(double y) {
   return ((uint64_t)hi << 32) | (uint64_t)(uint32_t)__double2loint(t2);
 }
 
-template <int LOGN, int BL>
+// PRIO: 0 = head of an iteration at high wave priority (as variant 4), 1 = static priority by the
+// wave slot the workgroup occupies (one of the two workgroups of a CU always wins arbitration and runs
+// at its solo speed, the other fills its gaps), 2 = no priority hints
+template <int LOGN, int BL, int PRIO>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v5_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
     int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
@@ -1288,6 +1291,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   // (int)hi >> (32 - BL)
   constexpr uint64_t ROUND = (uint64_t)1 << (63 - BL);
 
+  if (PRIO == 1) {
+    const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_REG_HW_ID.WAVE_ID: slot inside the SIMD
+    if (slot & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+  }
   int a_next = (int)at[0];
   for (int i = 0; i < n_small; ++i) {
     const int a = a_next;
@@ -1339,7 +1346,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
     load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
     __syncthreads();  // B1 (also: every rotated read of Y is done)
-    __builtin_amdgcn_s_setprio(0);
+    if (PRIO == 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = x_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
     fft_butterflies_reg<true>(x, w);
@@ -1401,7 +1408,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       acc_w[e * TP + M] = nhi[e];
     }
     __syncthreads();  // B6
-    __builtin_amdgcn_s_setprio(3);
+    if (PRIO == 0) __builtin_amdgcn_s_setprio(3);
   }
 
   // ---- sample extract from the image of -acc: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----

@@ -148,8 +148,8 @@ int fhes_get_stats(fhes_ctx *ctx, fhes_stats *out);
 int fhes_reset_stats(fhes_ctx *ctx);
 /* enable per-launch HIP-event timing (used by bench.py for the roofline object) */
 int fhes_set_timing(fhes_ctx *ctx, int32_t enabled);
-/* blind-rotate kernel selection for A/B benchmarking: 0 = auto (variant 2 for launches of at most
- * one ciphertext per CU, variant 4 beyond), 1..4 = force (all produce the same bits) */
+/* blind-rotate kernel selection for A/B benchmarking: 0 = auto (variant 5), 1..7 = force (all produce
+ * the same bits; multi-bit sets: 2 = latency build, 3 = throughput build) */
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t br_variant);
 /* test hooks: Fourier BSK in the oracle's canonical order [n][L][k+1][k+1][N/2][2];
  * FFT tables twist[N/2][2], twiddle[N/4][2]. */
