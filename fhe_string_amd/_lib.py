@@ -99,8 +99,29 @@ SIGNATURES = {
     "fhes_client_key_deserialize": (_P, [_P, C.c_int64]),
     "fhes_ct_serialize": (C.c_int64, [_P, _P, C.c_int64]),
     "fhes_ct_deserialize": (_P, [_P, C.c_int64]),
+    "fhes_ct_block_meta": (C.c_int, [_P, _P, _P]),
+    "fhes_server_key_serialize": (C.c_int64, [_P, _P, C.c_int64]),
+    "fhes_server_key_deserialize": (_P, [_P, C.c_int64, C.c_int32]),
     "fhes_string_op": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _i32p]),
+    # multi-GPU (one process per GPU)
+    "fhes_comm_unique_id": (C.c_int, [_P]),
+    "fhes_comm_create_rccl": (_P, [_P, C.c_int32, C.c_int32, _P]),
+    "fhes_comm_create_host": (_P, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "fhes_comm_destroy": (None, [_P]),
+    "fhes_comm_rank": (C.c_int32, [_P]),
+    "fhes_comm_world": (C.c_int32, [_P]),
+    "fhes_comm_is_rccl": (C.c_int32, [_P]),
+    "fhes_shard_range": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "fhes_comm_all_gather_host": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "fhes_comm_all_gather_cts": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "fhes_comm_broadcast_cts": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    "fhes_comm_broadcast_keys": (C.c_int, [_P, C.c_int32]),
+    "fhes_sharded_search": (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, C.c_int32, _i32p]),
+    "fhes_server_key_set_comm": (C.c_int, [_P, _P]),
 }
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
 
 _lib = None
 

@@ -7,7 +7,10 @@
 // parameter set PARAM_MESSAGE_2_CARRY_2_KS_PBS.
 #include <cmath>
 #include <cstring>
-#include <random>
+#include <cerrno>
+#include <cstdio>
+#include <sys/random.h>
+#include <sys/types.h>
 #include <thread>
 #include <vector>
 
@@ -47,8 +50,41 @@ bool params_valid(const fhes_params &p, std::string *why) {
 }
 
 // ---- ChaCha20-based CSPRNG ---------------------------------------------------------------
+struct Key256 { uint32_t w[8]; };
+
+// 256 bits from the operating system (getrandom, /dev/urandom as fallback)
+static bool os_random(void *buf, size_t n) {
+  unsigned char *p = static_cast<unsigned char *>(buf);
+  size_t got = 0;
+  while (got < n) {
+    const ssize_t r = getrandom(p + got, n - got, 0);
+    if (r > 0) { got += (size_t)r; continue; }
+    if (r < 0 && errno == EINTR) continue;
+    break;
+  }
+  if (got == n) return true;
+  FILE *f = fopen("/dev/urandom", "rb");
+  if (!f) return false;
+  const size_t rd = fread(p, 1, n, f);
+  fclose(f);
+  return rd == n;
+}
+
 class ChaCha {
  public:
+  // production: full 256-bit key
+  ChaCha(const Key256 &key, uint64_t stream) {
+    static const uint32_t sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int i = 0; i < 4; i++) st_[i] = sigma[i];
+    for (int i = 0; i < 8; i++) st_[4 + i] = key.w[i];
+    st_[12] = 0;
+    st_[13] = 0;
+    st_[14] = (uint32_t)stream;
+    st_[15] = (uint32_t)(stream >> 32);
+    pos_ = 16;
+  }
+  // TEST-ONLY deterministic mode: a 64-bit seed expanded with splitmix64 (reproducible keys and
+  // ciphertexts for the bit-exact parity tests; 64 bits of entropy -- never for real keys)
   ChaCha(uint64_t seed, uint64_t stream) {
     static const uint32_t sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
     for (int i = 0; i < 4; i++) st_[i] = sigma[i];
@@ -130,8 +166,16 @@ struct fhes_client_key {
   uint64_t l;             // maximum string length
   int32_t nb_char;        // lib.rs:60-61
   int32_t nb_usize;       // lib.rs:62
-  uint64_t seed;
-  uint64_t enc_counter;   // stream counter for encryption randomness
+  // randomness: seed != 0 selects the deterministic TEST mode -- everything derives from
+  // the 64-bit seed and a serialised counter, so that parity tests see reproducible bits.  seed == 0
+  // is the production mode: secret keys from a 256-bit OS key that is not kept, server-key masks and
+  // noise from a second 256-bit key (`gen_key`, part of the secret client key), and every encryption
+  // call draws a fresh 256-bit key from the OS -- nothing about encryption randomness is serialised.
+  bool deterministic = false;
+  uint64_t seed = 0;
+  uint64_t enc_counter = 0;   // deterministic mode only: stream counter of the encryption randomness
+  Key256 gen_key{};           // production mode only
+  ChaCha stream(uint64_t id) const { return deterministic ? ChaCha(seed, id) : ChaCha(gen_key, id); }
   std::vector<uint64_t> big_sk, small_sk;  // 0/1 words
 };
 
@@ -233,11 +277,14 @@ fhes_client_key *fhes_client_key_generate(const fhes_params *p, uint64_t l, uint
     fail(FHES_ERR_INVALID, "invalid parameters: %s", why.c_str());
     return nullptr;
   }
-  if (seed == 0) {
-    std::random_device rd;
-    seed = ((uint64_t)rd() << 32) ^ rd() ^ 0x5bd1e995u;
-  }
   auto *ck = new fhes_client_key;
+  ck->deterministic = seed != 0;
+  Key256 sk_key{};
+  if (!ck->deterministic && (!os_random(&sk_key, sizeof sk_key) || !os_random(&ck->gen_key, sizeof ck->gen_key))) {
+    delete ck;
+    fail(FHES_ERR_STATE, "no entropy source (getrandom and /dev/urandom failed)");
+    return nullptr;
+  }
   ck->p = *p;
   ck->l = l;
   const uint64_t msg_mod = 1ull << p->message_bits;
@@ -246,7 +293,7 @@ fhes_client_key *fhes_client_key_generate(const fhes_params *p, uint64_t l, uint
   ck->seed = seed;
   ck->enc_counter = 0;
   Dims d(*p);
-  ChaCha g(seed, /*stream=*/1);
+  ChaCha g = ck->deterministic ? ChaCha(seed, /*stream=*/1) : ChaCha(sk_key, 1);
   ck->big_sk.resize(d.big);
   ck->small_sk.resize(d.n);
   for (auto &b : ck->big_sk) b = g.next32() & 1u;
@@ -297,7 +344,7 @@ int fhes_client_key_make_server_keys(const fhes_client_key *ck, uint64_t *bsk, u
       const int l = (int)((row_id / kp1) % L);
       const int row = (int)(row_id % kp1);
       uint64_t *glwe = bsk + (size_t)row_id * kp1 * N;  // [kp1][N]
-      ChaCha g(ck->seed, 0x100000000ull + (uint64_t)row_id);
+      ChaCha g = ck->stream(0x100000000ull + (uint64_t)row_id);
       uint64_t *body = glwe + (size_t)k * N;
       for (int j = 0; j < N; j++) body[j] = g.noise(ck->p.glwe_noise_std);
       for (int c = 0; c < k; c++) {
@@ -327,7 +374,7 @@ int fhes_client_key_make_server_keys(const fhes_client_key *ck, uint64_t *bsk, u
     for (long r = tid; r < krows; r += nthreads) {
       const int i = (int)(r / d.ks_level), l = (int)(r % d.ks_level);
       uint64_t *ct = ksk + (size_t)r * (n + 1);
-      ChaCha g(ck->seed, 0x200000000ull + (uint64_t)r);
+      ChaCha g = ck->stream(0x200000000ull + (uint64_t)r);
       uint64_t b = g.noise(ck->p.lwe_noise_std);
       for (int j = 0; j < n; j++) {
         ct[j] = g.next64();
@@ -347,20 +394,25 @@ int fhes_client_key_make_server_keys(const fhes_client_key *ck, uint64_t *bsk, u
 
 // ---- serialisation of the client key ---------------------------------------------------------
 static const char kMagic[4] = {'F', 'H', 'E', 'S'};
-static const uint32_t kVersion = 1;
+static const uint32_t kVersion = 2;
 
 int64_t fhes_client_key_serialize(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len) {
   if (!ck) return fail(FHES_ERR_INVALID, "null argument");
   const Dims d(ck->p);
   const int64_t bits = (int64_t)d.big + d.n;
-  const int64_t total = 4 + 4 + 4 + (int64_t)sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8 + (bits + 7) / 8;
+  // "FHES" | version | kind 1 | fhes_params | l | nb_char | nb_usize | mode | (seed, enc_counter) or gen_key | key bits
+  const int64_t total = 4 + 4 + 4 + (int64_t)sizeof(fhes_params) + 8 + 4 + 4 + 4 + (ck->deterministic ? 16 : 32) + (bits + 7) / 8;
   if (!buf) return total;
   if (buf_len < total) return fail(FHES_ERR_INVALID, "buffer too small (%lld needed)", (long long)total);
   uint8_t *w = buf;
   auto put = [&](const void *src, size_t n) { memcpy(w, src, n); w += n; };
   const uint32_t kind = 1;
   put(kMagic, 4); put(&kVersion, 4); put(&kind, 4); put(&ck->p, sizeof(fhes_params));
-  put(&ck->l, 8); put(&ck->nb_char, 4); put(&ck->nb_usize, 4); put(&ck->seed, 8); put(&ck->enc_counter, 8);
+  put(&ck->l, 8); put(&ck->nb_char, 4); put(&ck->nb_usize, 4);
+  const uint32_t mode = ck->deterministic ? 1 : 0;
+  put(&mode, 4);
+  if (ck->deterministic) { put(&ck->seed, 8); put(&ck->enc_counter, 8); }
+  else put(&ck->gen_key, 32);
   memset(w, 0, (size_t)((bits + 7) / 8));
   for (int64_t i = 0; i < bits; i++) {
     const uint64_t bit = i < d.big ? ck->big_sk[i] : ck->small_sk[i - d.big];
@@ -370,7 +422,7 @@ int64_t fhes_client_key_serialize(const fhes_client_key *ck, uint8_t *buf, int64
 }
 
 fhes_client_key *fhes_client_key_deserialize(const uint8_t *buf, int64_t len) {
-  const int64_t head = 4 + 4 + 4 + (int64_t)sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8;
+  int64_t head = 4 + 4 + 4 + (int64_t)sizeof(fhes_params) + 8 + 4 + 4 + 4 + 16;
   if (!buf || len < head || memcmp(buf, kMagic, 4) != 0) { fail(FHES_ERR_INVALID, "not an FHES blob"); return nullptr; }
   const uint8_t *r = buf + 4;
   auto get = [&](void *dst, size_t n) { memcpy(dst, r, n); r += n; };
@@ -381,7 +433,16 @@ fhes_client_key *fhes_client_key_deserialize(const uint8_t *buf, int64_t len) {
   get(&ck->p, sizeof(fhes_params));
   std::string why;
   if (!params_valid(ck->p, &why)) { delete ck; fail(FHES_ERR_INVALID, "invalid parameters: %s", why.c_str()); return nullptr; }
-  get(&ck->l, 8); get(&ck->nb_char, 4); get(&ck->nb_usize, 4); get(&ck->seed, 8); get(&ck->enc_counter, 8);
+  get(&ck->l, 8); get(&ck->nb_char, 4); get(&ck->nb_usize, 4);
+  uint32_t mode;
+  get(&mode, 4);
+  ck->deterministic = mode == 1;
+  if (ck->deterministic) { get(&ck->seed, 8); get(&ck->enc_counter, 8); }
+  else {
+    head += 16;
+    if (len < head) { delete ck; fail(FHES_ERR_INVALID, "truncated blob"); return nullptr; }
+    get(&ck->gen_key, 32);
+  }
   const Dims d(ck->p);
   const int64_t bits = (int64_t)d.big + d.n;
   if (len < head + (bits + 7) / 8) { delete ck; fail(FHES_ERR_INVALID, "truncated blob"); return nullptr; }
@@ -399,9 +460,12 @@ int fhes_client_encrypt_blocks(fhes_client_key *ck, const uint8_t *values, int64
   if (!ck || !values || !out || count < 0) return fail(FHES_ERR_INVALID, "bad argument");
   const Dims d(ck->p);
   const int W = d.ct_words();
+  Key256 call_key{};  // production mode: fresh OS randomness per call, one ChaCha stream per block
+  if (!ck->deterministic && !os_random(&call_key, sizeof call_key))
+    return fail(FHES_ERR_STATE, "no entropy source (getrandom and /dev/urandom failed)");
   for (int64_t q = 0; q < count; q++) {
     if (values[q] >= 2 * d.space()) return fail(FHES_ERR_INVALID, "block value %d out of range", values[q]);
-    ChaCha g(ck->seed, 0x300000000ull + ck->enc_counter++);
+    ChaCha g = ck->deterministic ? ChaCha(ck->seed, 0x300000000ull + ck->enc_counter++) : ChaCha(call_key, (uint64_t)q);
     uint64_t *ct = out + (size_t)q * W;
     uint64_t b = g.noise(ck->p.glwe_noise_std) + (uint64_t)values[q] * d.delta;
     for (int j = 0; j < d.big; j++) {

@@ -54,6 +54,8 @@ static bool kernels_support(const fhes_params &p, std::string *why) {
   if (p.pbs_base_log != 23) { *why = "HIP kernels are instantiated for pbs_base_log == 23"; return false; }
   if (p.poly_size != 2048 && p.poly_size != 256) { *why = "HIP kernels are instantiated for poly_size 2048 (and 256 for tests)"; return false; }
   if (p.ks_level > dev::KS_MAXLV || p.ks_base_log > 7) { *why = "keyswitch decomposition too large"; return false; }
+  // keyswitch_kernel keeps the rounded prefix of a mask coefficient in 32 bits
+  if (p.ks_level * p.ks_base_log > 31) { *why = "keyswitch decomposition wider than 31 bits (ks_level * ks_base_log)"; return false; }
   if (p.lwe_dim + 1 > 1024) { *why = "lwe_dim too large"; return false; }
   if (p.grouping_factor > 3) { *why = "HIP kernels support grouping factors 2 and 3"; return false; }
   return true;

@@ -17,6 +17,7 @@ struct fhes_server_key {  // server_key.rs:11-17
   fhes_ctx *ctx = nullptr;
   int32_t msg_mod = 0, nb_char = 0, nb_usize = 0;
   bool logdepth = false;  // opt-in: every operation compiles its "<op>_logdepth" form
+  fhes_comm *comm = nullptr;  // attached communicator: contains / find run position-sharded over its ranks
   std::mutex mu;
   std::map<std::string, fhes_program *> cache;
 };
@@ -24,6 +25,9 @@ struct fhes_server_key {  // server_key.rs:11-17
 struct fhes_ct {
   int32_t n_blocks = 0;
   int64_t ct_words = 0;
+  // per-block metadata (tfhe-rs keeps Degree / NoiseLevel per block): upper bound of the value, noise in
+  // units of one bootstrap output.  Fresh / trivial encryptions: noise 0; results of operations: <= 1.
+  std::vector<uint8_t> degree, noise;
   std::vector<uint64_t> host;  // [n_blocks][ct_words] when present
   fhes_ctx *ctx = nullptr;     // device residency
   int32_t handle = -1;
@@ -89,6 +93,13 @@ void fhes_server_key_destroy(fhes_server_key *sk) {
 
 fhes_ctx *fhes_server_key_ctx(fhes_server_key *sk) { return sk ? sk->ctx : nullptr; }
 
+int fhes_server_key_set_comm(fhes_server_key *sk, fhes_comm *comm) {
+  if (!sk) return fail(FHES_ERR_INVALID, "null server key");
+  std::lock_guard<std::mutex> lk(sk->mu);
+  sk->comm = comm;
+  return FHES_OK;
+}
+
 int fhes_server_key_set_logdepth(fhes_server_key *sk, int32_t enabled) {
   if (!sk) return fail(FHES_ERR_INVALID, "null server key");
   std::lock_guard<std::mutex> lk(sk->mu);
@@ -126,6 +137,8 @@ fhes_ct *fhes_string_encrypt(fhes_client_key *ck, const char *s, int64_t pad, in
   ct->host.resize(blocks.size() * ct->ct_words);
   int rc = fhes_client_encrypt_blocks(ck, blocks.data(), (int64_t)blocks.size(), ct->host.data());
   if (rc) { delete ct; *status = rc; return nullptr; }
+  ct->degree.assign(blocks.size(), (uint8_t)(M - 1));
+  ct->noise.assign(blocks.size(), 0);
   *status = FHES_OK;
   return ct;
 }
@@ -151,6 +164,8 @@ fhes_ct *fhes_string_trivial(const fhes_server_key *sk, const char *s, int32_t *
     for (int k = 0; k < sk->nb_char; k++, c /= M)
       ct->host[(i * sk->nb_char + k) * ct->ct_words + d.big] = (c % M) * d.delta;
   }
+  ct->degree.assign((size_t)ct->n_blocks, (uint8_t)(M - 1));
+  ct->noise.assign((size_t)ct->n_blocks, 0);
   *status = FHES_OK;
   return ct;
 }
@@ -172,6 +187,8 @@ fhes_ct *fhes_usize_encrypt(fhes_client_key *ck, uint64_t v) {
   const int enc = std::min(Bc, Bu);
   int rc = fhes_client_encrypt_blocks(ck, blocks.data(), enc, ct->host.data());
   if (rc) { delete ct; return nullptr; }
+  ct->degree.assign((size_t)Bu, (uint8_t)(M - 1));
+  ct->noise.assign((size_t)Bu, 0);
   return ct;
 }
 
@@ -236,17 +253,33 @@ int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out) {
   return FHES_OK;
 }
 
+static void default_meta(fhes_ct *ct) {  // objects built before metadata existed / results: clean blocks
+  if ((int32_t)ct->degree.size() != ct->n_blocks) ct->degree.assign((size_t)ct->n_blocks, 3);
+  if ((int32_t)ct->noise.size() != ct->n_blocks) ct->noise.assign((size_t)ct->n_blocks, 1);
+}
+
+int fhes_ct_block_meta(const fhes_ct *ct, uint8_t *degree, uint8_t *noise) {
+  if (!ct || !degree || !noise) return fail(FHES_ERR_INVALID, "null argument");
+  for (int32_t i = 0; i < ct->n_blocks; i++) {
+    degree[i] = (size_t)i < ct->degree.size() ? ct->degree[i] : 3;
+    noise[i] = (size_t)i < ct->noise.size() ? ct->noise[i] : 1;
+  }
+  return FHES_OK;
+}
+
 int64_t fhes_ct_serialize(fhes_ct *ct, uint8_t *buf, int64_t buf_len) {
   if (!ct) return fail(FHES_ERR_INVALID, "null argument");
-  const int64_t total = 4 + 4 + 4 + 4 + 8 + (int64_t)ct->n_blocks * ct->ct_words * 8;
+  const int64_t total = 4 + 4 + 4 + 4 + 8 + 2 * (int64_t)ct->n_blocks + (int64_t)ct->n_blocks * ct->ct_words * 8;
   if (!buf) return total;
   if (buf_len < total) return fail(FHES_ERR_INVALID, "buffer too small (%lld needed)", (long long)total);
   int rc = ensure_host(ct);
   if (rc) return rc;
-  const uint32_t version = 1, kind = 2;
+  default_meta(ct);
+  const uint32_t version = 2, kind = 2;
   uint8_t *w = buf;
   auto put = [&](const void *src, size_t n) { memcpy(w, src, n); w += n; };
   put("FHES", 4); put(&version, 4); put(&kind, 4); put(&ct->n_blocks, 4); put(&ct->ct_words, 8);
+  for (int32_t i = 0; i < ct->n_blocks; i++) { put(&ct->degree[i], 1); put(&ct->noise[i], 1); }
   put(ct->host.data(), ct->host.size() * 8);
   return total;
 }
@@ -256,19 +289,77 @@ fhes_ct *fhes_ct_deserialize(const uint8_t *buf, int64_t len) {
   uint32_t version, kind;
   memcpy(&version, buf + 4, 4);
   memcpy(&kind, buf + 8, 4);
-  if (version != 1 || kind != 2) { fail(FHES_ERR_INVALID, "unsupported version / kind"); return nullptr; }
+  if (version != 2 || kind != 2) { fail(FHES_ERR_INVALID, "unsupported version / kind"); return nullptr; }
   auto *ct = new fhes_ct;
   memcpy(&ct->n_blocks, buf + 12, 4);
   memcpy(&ct->ct_words, buf + 16, 8);
   if (ct->n_blocks < 0 || ct->ct_words < 2 || ct->ct_words > (1 << 20) ||
-      len < 24 + (int64_t)ct->n_blocks * ct->ct_words * 8) {
+      len < 24 + 2 * (int64_t)ct->n_blocks + (int64_t)ct->n_blocks * ct->ct_words * 8) {
     delete ct;
     fail(FHES_ERR_INVALID, "truncated or corrupt blob");
     return nullptr;
   }
+  const uint8_t *r = buf + 24;
+  ct->degree.resize((size_t)ct->n_blocks);
+  ct->noise.resize((size_t)ct->n_blocks);
+  for (int32_t i = 0; i < ct->n_blocks; i++) { ct->degree[i] = *r++; ct->noise[i] = *r++; }
   ct->host.resize((size_t)ct->n_blocks * ct->ct_words);
-  memcpy(ct->host.data(), buf + 24, ct->host.size() * 8);
+  memcpy(ct->host.data(), r, ct->host.size() * 8);
   return ct;
+}
+
+// ---- ServerKey blob (server_key.rs:11) -----------------------------------------------------------
+int64_t fhes_server_key_serialize(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len) {
+  if (!ck) return fail(FHES_ERR_INVALID, "null argument");
+  fhes_params p;
+  fhes_client_key_params(ck, &p);
+  const int64_t bw = fhes_bsk_words(&p), kw = fhes_ksk_words(&p);
+  const int64_t head = 4 + 4 + 4 + (int64_t)sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8;
+  const int64_t total = head + (bw + kw) * 8;
+  if (!buf) return total;
+  if (buf_len < total) return fail(FHES_ERR_INVALID, "buffer too small (%lld needed)", (long long)total);
+  const uint32_t version = 2, kind = 3;
+  const uint64_t l = ipow((uint64_t)1 << p.message_bits, fhes_client_key_num_blocks_usize(ck)) - 1;  // max_len of the key (mod.rs:435)
+  const int32_t nbc = fhes_client_key_num_blocks_char(ck), nbu = fhes_client_key_num_blocks_usize(ck);
+  uint8_t *w = buf;
+  auto put = [&](const void *src, size_t n) { memcpy(w, src, n); w += n; };
+  put("FHES", 4); put(&version, 4); put(&kind, 4); put(&p, sizeof p); put(&l, 8); put(&nbc, 4); put(&nbu, 4); put(&bw, 8); put(&kw, 8);
+  // the key material is generated straight into the blob (8-byte alignment of the payload: head is a multiple of 8)
+  static_assert((4 + 4 + 4 + sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8) % 4 == 0, "header layout");
+  std::vector<uint64_t> bsk((size_t)bw), ksk((size_t)kw);
+  int rc = fhes_client_key_make_server_keys(ck, bsk.data(), ksk.data());
+  if (rc) return rc;
+  put(bsk.data(), (size_t)bw * 8);
+  put(ksk.data(), (size_t)kw * 8);
+  return total;
+}
+
+fhes_server_key *fhes_server_key_deserialize(const uint8_t *buf, int64_t len, int32_t device) {
+  const int64_t head = 4 + 4 + 4 + (int64_t)sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8;
+  if (!buf || len < head || memcmp(buf, "FHES", 4) != 0) { fail(FHES_ERR_INVALID, "not an FHES blob"); return nullptr; }
+  const uint8_t *r = buf + 4;
+  auto get = [&](void *dst, size_t n) { memcpy(dst, r, n); r += n; };
+  uint32_t version, kind;
+  get(&version, 4); get(&kind, 4);
+  if (version != 2 || kind != 3) { fail(FHES_ERR_INVALID, "unsupported version / kind"); return nullptr; }
+  auto *sk = new fhes_server_key;
+  uint64_t l;
+  int64_t bw, kw;
+  get(&sk->p, sizeof sk->p); get(&l, 8); get(&sk->nb_char, 4); get(&sk->nb_usize, 4); get(&bw, 8); get(&kw, 8);
+  std::string why;
+  if (!params_valid(sk->p, &why) || bw != fhes_bsk_words(&sk->p) || kw != fhes_ksk_words(&sk->p) || len < head + (bw + kw) * 8) {
+    delete sk;
+    fail(FHES_ERR_INVALID, "corrupt or truncated server-key blob %s", why.c_str());
+    return nullptr;
+  }
+  sk->msg_mod = 1 << sk->p.message_bits;
+  sk->ctx = fhes_ctx_create(&sk->p, device);  // fails loudly without a HIP device
+  if (!sk->ctx) { delete sk; return nullptr; }
+  std::vector<uint64_t> bsk((size_t)bw), ksk((size_t)kw);  // aligned copies of the payload
+  memcpy(bsk.data(), r, (size_t)bw * 8);
+  memcpy(ksk.data(), r + (size_t)bw * 8, (size_t)kw * 8);
+  if (fhes_upload_keys(sk->ctx, bsk.data(), ksk.data()) != FHES_OK) { fhes_server_key_destroy(sk); return nullptr; }
+  return sk;
 }
 
 int fhes_ct_decrypt_blocks(const fhes_client_key *ck, fhes_ct *c, uint8_t *values) {
@@ -294,6 +385,37 @@ int fhes_string_op(fhes_server_key *sk, const char *op_in, fhes_ct *const *args,
     if (sk->logdepth && !has) op_name += suffix;
   }
   const char *op = op_name.c_str();
+  // position-sharded path: every rank of the attached communicator makes this call
+  if (sk->comm && fhes_comm_world(sk->comm) > 1 && n_args == 2 && args[0] && args[1] &&
+      (std::string(op_in) == "contains" || std::string(op_in) == "find")) {
+    for (int i = 0; i < 2; i++) {
+      if (args[i]->n_blocks % sk->nb_char) return fail(FHES_ERR_INVALID, "operand %d is not a string", i);
+      int rc = ensure_device(sk, args[i]);
+      if (rc) return rc;
+    }
+    int32_t h[32], n = 0;
+    int rc = fhes_sharded_search(sk->comm, op_in, args[0]->handle, args[0]->n_blocks / sk->nb_char, args[1]->handle,
+                                 args[1]->n_blocks / sk->nb_char, sk->nb_usize, h, 32, &n);
+    if (rc) return rc;
+    const int32_t n_parts = n == 1 ? 1 : 2;
+    if (n_parts > max_outs) return fail(FHES_ERR_INVALID, "need room for %d results", n_parts);
+    const Dims d(sk->p);
+    const int32_t part_blocks[2] = {1, n - 1};
+    int32_t off = 0;
+    for (int32_t k = 0; k < n_parts; k++) {
+      auto *c = new fhes_ct;
+      c->n_blocks = part_blocks[k];
+      c->ct_words = d.ct_words();
+      c->ctx = sk->ctx;
+      c->handle = h[0] + off;
+      c->degree.assign((size_t)c->n_blocks, c->n_blocks == 1 ? 1 : (uint8_t)(sk->msg_mod - 1));
+      c->noise.assign((size_t)c->n_blocks, 1);
+      off += part_blocks[k];
+      outs[k] = c;
+    }
+    *n_outs = n_parts;
+    return FHES_OK;
+  }
   std::vector<int32_t> shape;
   std::string key = op;
   int ai = 0, ii = 0;
@@ -364,6 +486,10 @@ int fhes_string_op(fhes_server_key *sk, const char *op_in, fhes_ct *const *args,
     c->ct_words = d.ct_words();
     c->ctx = sk->ctx;
     c->handle = out[0] + off;  // program outputs are one contiguous handle range
+    // results cross the program boundary clean (Builder::finish): degree below the message modulus, one
+    // bootstrap's noise at most
+    c->degree.assign((size_t)c->n_blocks, (uint8_t)(sk->msg_mod - 1));
+    c->noise.assign((size_t)c->n_blocks, 1);
     off += parts[k];
     outs[k] = c;
   }

@@ -237,16 +237,31 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
   img.arrays.slot_map = img.slot_map;
 
   // ---- slot maps for this run ----
-  const int32_t out_total = std::max(n_out * n_inst, 1);
-  const int32_t out_base = arena_alloc_locked(ctx, out_total);
-  if (out_base < 0) return out_base;
-  int32_t scratch = -1;
-  if (n_nodes > 0) {
-    scratch = arena_alloc_locked(ctx, fp->n_scratch * n_inst);
-    if (scratch < 0) {
-      arena_free_locked(ctx, out_base, out_total);
-      return scratch;
+  // Everything this call takes from the arena is handed back on EVERY failing exit (the outputs too:
+  // the caller only owns them when the call succeeds); a program without outputs allocates none.
+  struct ArenaGuard {
+    fhes_ctx *ctx;
+    int32_t out_base = -1, out_total = 0, scratch = -1, scratch_total = 0;
+    bool keep_outputs = false;
+    ~ArenaGuard() {
+      if (scratch >= 0) arena_free_locked(ctx, scratch, scratch_total);  // stream-ordered: later work queues behind the reads
+      if (out_base >= 0 && !keep_outputs) arena_free_locked(ctx, out_base, out_total);
     }
+  } guard{ctx};
+  const int32_t out_total = n_out * n_inst;
+  int32_t out_base = 0;
+  if (out_total > 0) {
+    out_base = arena_alloc_locked(ctx, out_total);
+    if (out_base < 0) return out_base;
+    guard.out_base = out_base;
+    guard.out_total = out_total;
+  }
+  int32_t scratch = -1;
+  if (n_nodes > 0 && fp->n_scratch > 0) {
+    scratch = arena_alloc_locked(ctx, fp->n_scratch * n_inst);
+    if (scratch < 0) return scratch;
+    guard.scratch = scratch;
+    guard.scratch_total = fp->n_scratch * n_inst;
   }
   std::vector<int32_t> map((size_t)n_inst * n_slots);
   std::vector<std::pair<int32_t, int32_t>> copies;  // (dst handle, src handle index into map)
@@ -288,9 +303,7 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
       if (e != hipSuccess) { rc = hip_fail(e, "output copy"); break; }
     }
   }
-  // scratch is released in stream order: later work on this ctx is queued behind the reads
-  if (scratch >= 0) arena_free_locked(ctx, scratch, fp->n_scratch * n_inst);
-  if (rc != FHES_OK) arena_free_locked(ctx, out_base, out_total);
+  guard.keep_outputs = rc == FHES_OK;
   return rc;
 }
 

@@ -1,14 +1,19 @@
-"""Multi-GPU sharding of the search path.
+"""Multi-GPU sharding of the search path -- Python face of the C entry points
+`fhes_comm_*` / `fhes_shard_range` / `fhes_sharded_search` (include/fhe_string_amd.h).
 
 `find_all` positions are independent (/root/reference/src/ciphertext/search.rs:33-41), so the
 position axis is split contiguously over the ranks of one node: rank g evaluates
 `substr_eq(i, pattern)` for its positions, the per-position BooleanBlocks are exchanged with ONE
-all-gather (RCCL when the process group is `nccl`), and the reduction that follows (`any` for
-contains, the first-match scan for find) runs replicated on every rank -- it is deterministic, so
-all ranks hold identical ciphertexts and no broadcast is needed.  Keys are replicated per GPU.
+all-gather, and the reduction that follows (`any` for contains, the first-match scan for find) runs
+replicated on every rank -- it is deterministic, so all ranks hold identical ciphertexts and no
+broadcast is needed.  One process per GPU.
 
-One process per GPU; ciphertext batches cross this module as numpy uint64 arrays
-[count][k*N+1] (the ABI's host format)."""
+Transports of a communicator:
+  * RCCL: `Comm.rccl(ctx, rank, world, id)` -- ncclAllGather / ncclBroadcast on arena rows (device
+    pointers, no host staging); the 128-byte id comes from `Comm.unique_id()` on rank 0 and travels over
+    whatever the host runtime has (here: a torch.distributed object broadcast);
+  * host: `Comm.host(ctx, dist)` -- the same C calls staged through host buffers and carried by
+    torch.distributed collectives (gloo on CPU-only boxes: tests/test_parallel_gloo.py)."""
 import ctypes as C
 
 import numpy as np
@@ -18,84 +23,120 @@ from ._lib import check, check_ptr
 
 
 def shard_range(n, world_size, rank):
-    """contiguous block partition of range(n)"""
-    base, rem = divmod(n, world_size)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """fhes_shard_range: rank r owns [min(r*c, n), min((r+1)*c, n)), c = ceil(n / world)"""
+    lo, hi = C.c_int64(), C.c_int64()
+    check(_lib.load().fhes_shard_range(n, world_size, rank, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
 
 
-class DeviceExecutor:
-    """Runs compiled programs on this rank's GPU through the C ABI."""
+class Comm:
+    """fhes_comm handle (keeps the ctypes callbacks of the host transport alive)"""
 
-    def __init__(self, ctx, params):
-        self.lib = _lib.load()
-        self.ctx, self.params = ctx, params
-        self.W = params.ct_words()
-        self._progs = {}
+    def __init__(self, h, keep=()):
+        self._h, self._keep = h, keep
+        lib = _lib.load()
+        self.rank, self.world = lib.fhes_comm_rank(h), lib.fhes_comm_world(h)
 
-    def program(self, op, shape, bu):
-        key = (op, tuple(shape), bu)
-        if key not in self._progs:
-            sh = np.array(shape, dtype=np.int32)
-            h = check_ptr(self.lib.fhes_program_compile(C.byref(self.params), op.encode(), sh.ctypes.data, len(shape), bu))
-            info = (C.c_int64 * 8)()
-            check(self.lib.fhes_program_info(h, info))
-            self._progs[key] = (h, int(info[0]), int(info[1]))
-        return self._progs[key]
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(_lib.load().fhes_comm_unique_id(buf))
+        return bytes(buf)
 
-    def run(self, op, shape, bu, input_cts):
-        h, n_in, n_out = self.program(op, shape, bu)
-        input_cts = np.ascontiguousarray(input_cts, dtype=np.uint64).reshape(-1, self.W)
-        assert len(input_cts) == n_in
-        if n_out == 0:
-            return np.zeros((0, self.W), dtype=np.uint64)
-        hin = check(self.lib.fhes_arena_alloc(self.ctx, max(n_in, 1)))
-        if n_in:
-            check(self.lib.fhes_arena_upload(self.ctx, hin, n_in, input_cts.ctypes.data))
-        ins = np.arange(hin, hin + n_in, dtype=np.int32)
-        outs = np.zeros(n_out, dtype=np.int32)
-        check(self.lib.fhes_program_run(self.ctx, h, ins.ctypes.data, outs.ctypes.data))
-        res = np.zeros((n_out, self.W), dtype=np.uint64)
-        check(self.lib.fhes_arena_download(self.ctx, int(outs[0]), n_out, res.ctypes.data))
-        check(self.lib.fhes_arena_free(self.ctx, hin, max(n_in, 1)))
-        check(self.lib.fhes_arena_free(self.ctx, int(outs[0]), n_out))
-        return res
+    @staticmethod
+    def rccl(ctx, rank, world, uid):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        return Comm(check_ptr(_lib.load().fhes_comm_create_rccl(ctx, rank, world, buf)))
 
+    @staticmethod
+    def rccl_from_torch(ctx, dist):
+        """the id travels through torch.distributed (any backend); the data path is this library's own RCCL"""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return Comm.rccl(ctx, rank, world, box[0])
 
-def all_gather_cts(local, counts, dist, device=None):
-    """all-gather of ciphertext rows with per-rank row counts `counts` (padded to the max)."""
-    import torch
-    W = local.shape[1]
-    mx = max(counts)
-    pad = np.zeros((mx, W), dtype=np.uint64)
-    pad[:len(local)] = local
-    t = torch.from_numpy(pad.view(np.int64))
-    if device is not None:
-        t = t.to(device)
-    bufs = [torch.empty_like(t) for _ in counts]
-    dist.all_gather(bufs, t)
-    parts = [b.cpu().numpy().view(np.uint64)[:c] for b, c in zip(bufs, counts)]
-    return np.concatenate(parts, axis=0) if parts else np.zeros((0, W), dtype=np.uint64)
+    @staticmethod
+    def host(ctx, dist=None, rank=None, world=None):
+        """host transport over a torch.distributed module (None: a single rank)"""
+        import torch
+        rank = dist.get_rank() if dist else (rank or 0)
+        world = dist.get_world_size() if dist else (world or 1)
+
+        def all_gather(_user, send, recv, nbytes):
+            try:
+                src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+                t = torch.from_numpy(src.copy())
+                bufs = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(bufs, t)
+                for r, b in enumerate(bufs):
+                    dst[r * nbytes:(r + 1) * nbytes] = b.numpy()
+                return 0
+            except Exception:      # never let an exception cross the C boundary
+                return -1
+
+        def bcast(_user, buf, nbytes, root):
+            try:
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                t = torch.from_numpy(a.copy())
+                dist.broadcast(t, src=root)
+                a[:] = t.numpy()
+                return 0
+            except Exception:
+                return -1
+
+        ag, bc = _lib.ALLGATHER_FN(all_gather), _lib.BCAST_FN(bcast)
+        h = check_ptr(_lib.load().fhes_comm_create_host(ctx, rank, world, ag if dist else None, bc if dist else None, None))
+        return Comm(h, keep=(ag, bc))
+
+    def all_gather_host(self, rows):
+        """host rows [count][W] of every rank, concatenated in rank order (equal counts)"""
+        rows = np.ascontiguousarray(rows)
+        out = np.zeros((self.world,) + rows.shape, dtype=rows.dtype)
+        check(_lib.load().fhes_comm_all_gather_host(self._h, rows.ctypes.data, out.ctypes.data, rows.nbytes))
+        return out.reshape((-1,) + rows.shape[1:])
+
+    def broadcast_keys(self, root=0):
+        check(_lib.load().fhes_comm_broadcast_keys(self._h, root))
+
+    def broadcast_cts(self, first, count, root=0):
+        check(_lib.load().fhes_comm_broadcast_cts(self._h, first, count, root))
+
+    def sharded_search(self, op, a_first, a_slots, p_first, p_slots, bu):
+        """fhes_sharded_search -> list of output handles (one contiguous range)"""
+        out = (C.c_int32 * 32)()
+        n = C.c_int32()
+        check(_lib.load().fhes_sharded_search(self._h, op.encode(), a_first, a_slots, p_first, p_slots, bu, out, 32, C.byref(n)))
+        return [int(out[i]) for i in range(n.value)]
+
+    def close(self):
+        if self._h:
+            _lib.load().fhes_comm_destroy(self._h)
+            self._h = None
 
 
 class ShardedSearch:
-    """contains / find / rfind over the ranks of `dist` (a torch.distributed module or None)."""
+    """contains / find / rfind_last with a pluggable executor (`run(op, shape, bu, input_cts) -> cts`):
+    planning (`fhes_shard_range`) and the exchange (`fhes_comm_all_gather_host`) go through the C entry
+    points; on a GPU use `Comm.sharded_search`, which keeps everything on the device."""
 
-    def __init__(self, executor, bu, dist=None, device=None, bc=4):
-        self.ex, self.bu, self.dist, self.device, self.bc = executor, bu, dist, device, bc
-        self.rank = dist.get_rank() if dist else 0
-        self.world = dist.get_world_size() if dist else 1
+    def __init__(self, executor, bu, comm, bc=4):
+        self.ex, self.bu, self.comm, self.bc = executor, bu, comm, bc
+        self.rank, self.world = comm.rank, comm.world
 
     def find_all(self, a_cts, b_cts):
         """found[i] for every start position i (search.rs:33-41), gathered on all ranks"""
         sa, sb = len(a_cts) // self.bc, len(b_cts) // self.bc
         n_pos = sa - 1
-        counts = [shard_range(n_pos, self.world, r)[1] - shard_range(n_pos, self.world, r)[0] for r in range(self.world)]
         lo, hi = shard_range(n_pos, self.world, self.rank)
-        local = self.ex.run("find_all_range", [sa, sb, lo, hi], self.bu, np.concatenate([a_cts, b_cts]))
-        if self.world == 1:
-            return local
-        return all_gather_cts(local, counts, self.dist, self.device)
+        chunk = -(-n_pos // self.world)
+        W = a_cts.shape[1]
+        local = self.ex.run("find_all_range", [sa, sb, lo, hi], self.bu, np.concatenate([a_cts, b_cts])) if hi > lo \
+            else np.zeros((0, W), dtype=np.uint64)
+        seg = np.zeros((chunk, W), dtype=np.uint64)
+        seg[:hi - lo] = local
+        return self.comm.all_gather_host(seg)[:n_pos]
 
     def contains(self, a_cts, b_cts):
         found = self.find_all(a_cts, b_cts)

@@ -88,7 +88,11 @@ const char *fhes_last_error(void);
  * reference too and are not part of the accelerated path. */
 typedef struct fhes_client_key fhes_client_key;
 
-/* `l` = maximum string length (lib.rs:50); seed == 0 -> OS entropy. */
+/* `l` = maximum string length (lib.rs:50).
+ * seed == 0: production -- secret keys, server-key masks / noise and every encryption call use
+ * independent 256-bit keys from the OS (getrandom); encryption randomness is never serialised.
+ * seed != 0: TEST-ONLY deterministic mode (64 bits of entropy): keys and ciphertexts are reproducible
+ * from the seed and a serialised counter, which is what the bit-exact parity tests need. */
 fhes_client_key *fhes_client_key_generate(const fhes_params *p, uint64_t l, uint64_t seed);
 void fhes_client_key_destroy(fhes_client_key *ck);
 int fhes_client_key_params(const fhes_client_key *ck, fhes_params *out);
@@ -242,14 +246,29 @@ int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out);
 /* raw decoded value (message + carry + padding bit) of every block; values[num_blocks] */
 int fhes_ct_decrypt_blocks(const fhes_client_key *ck, fhes_ct *c, uint8_t *values);
 
-/* ---- serialisation (the reference derives serde on ClientKey / FheString / FheUsize:
- * client_key.rs:15, ciphertext/mod.rs:30,42,401).  Versioned little-endian format:
- *   "FHES" | u32 version | u32 kind (1 client key, 2 ciphertext) | fhes_params (52 bytes) | payload
+/* ---- serialisation (the reference derives serde on ClientKey / ServerKey / FheAsciiChar / FheString /
+ * FheUsize: client_key.rs:15, server_key.rs:11, ciphertext/mod.rs:30,42,401).  Versioned little-endian:
+ *   client key   "FHES" | u32 version | u32 kind = 1 | fhes_params (sizeof = 56) | l | block counts | mode |
+ *                randomness state of the mode | secret key bits
+ *   ciphertext   "FHES" | u32 version | u32 kind = 2 | u32 n_blocks | u64 ct_words | per block {u8 degree,
+ *                u8 noise level in bootstrap units} | u64 words [n_blocks][ct_words]
+ *   server key   "FHES" | u32 version | u32 kind = 3 | fhes_params | u64 l | block counts |
+ *                u64 bsk_words | u64 ksk_words | standard-domain BSK | KSK   (170 MB for the default set)
+ * An FheOption<T> is {BooleanBlock, T} and an FheStringSliceVector {is_some[n], start[n][Bu], end[n][Bu]}
+ * plus its string: each part is a ciphertext blob of its own.
  * fhes_*_serialize returns the byte size; call with buf == NULL to query it. */
 int64_t fhes_client_key_serialize(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len);
 fhes_client_key *fhes_client_key_deserialize(const uint8_t *buf, int64_t len);
 int64_t fhes_ct_serialize(fhes_ct *ct, uint8_t *buf, int64_t buf_len);
 fhes_ct *fhes_ct_deserialize(const uint8_t *buf, int64_t len);
+/* per-block metadata of a ciphertext object: degree (upper bound of the block's value) and noise level in
+ * units of one bootstrap output (0 = fresh or trivial encryption); results of fhes_string_op are clean:
+ * degree < message modulus (booleans: 1), noise <= 1.  Arrays of fhes_ct_num_blocks entries. */
+int fhes_ct_block_meta(const fhes_ct *ct, uint8_t *degree, uint8_t *noise);
+/* ServerKey blob (server_key.rs:11 derives serde): the standard-domain key material plus the block counts;
+ * deserialising uploads it to `device` (Fourier transform on the device) and needs no client key. */
+int64_t fhes_server_key_serialize(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len);
+fhes_server_key *fhes_server_key_deserialize(const uint8_t *buf, int64_t len, int32_t device);
 
 /* Generic operation dispatch: op names and operand order as in fhes_op_signature.  `args` are
  * the ciphertext operands (S, U and the three parts of each V, in signature order), `iargs` the
@@ -260,6 +279,61 @@ fhes_ct *fhes_ct_deserialize(const uint8_t *buf, int64_t len);
 int fhes_string_op(fhes_server_key *sk, const char *op, fhes_ct *const *args, int32_t n_args,
                    const int64_t *iargs, int32_t n_iargs, fhes_ct **outs, int32_t max_outs,
                    int32_t *n_outs);
+
+/* ============================ multi-GPU: one process per GPU ===============================
+ * SURVEY.md 8(e) / 2.4 C1-C2.  The reference has no distributed code (rayon only); what shards is the
+ * position axis of `find_all` (/root/reference/src/ciphertext/search.rs:33-41): rank g evaluates
+ * substr_eq for its contiguous block of start positions, ONE all-gather of the per-position
+ * BooleanBlocks follows, and the reduction (`any` / first-match scan) runs replicated -- it is
+ * deterministic, so all ranks end with identical ciphertexts.  Keys and inputs are replicated with a
+ * broadcast.  Transports:
+ *   RCCL  ncclAllGather / ncclBroadcast directly on arena rows and key buffers (device pointers, the
+ *         context's stream; librccl.so.1 is resolved at run time, so hosts without it still load this
+ *         library); xGMI between the GPUs of a node;
+ *   host  the same calls staged through host buffers and carried by two caller-supplied callbacks
+ *         (MPI, gloo, a socket...): the CPU-only tests run it over gloo. */
+typedef struct fhes_comm fhes_comm;
+#define FHES_COMM_ID_BYTES 128
+/* rank 0 creates the id (ncclGetUniqueId); the host runtime hands the 128 bytes to every rank */
+int fhes_comm_unique_id(uint8_t id[FHES_COMM_ID_BYTES]);
+/* collective over all ranks: ncclCommInitRank on the device of `ctx` */
+fhes_comm *fhes_comm_create_rccl(fhes_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[FHES_COMM_ID_BYTES]);
+/* all-gather: every rank contributes `bytes_per_rank` bytes, recv gets world * bytes_per_rank in rank
+ * order; broadcast: `bytes` bytes from `root`.  Return 0 on success. */
+typedef int (*fhes_allgather_fn)(void *user, const void *send, void *recv, int64_t bytes_per_rank);
+typedef int (*fhes_bcast_fn)(void *user, void *buf, int64_t bytes, int32_t root);
+/* `ctx` may be NULL for a communicator that only moves host buffers (fhes_comm_all_gather_host) */
+fhes_comm *fhes_comm_create_host(fhes_ctx *ctx, int32_t rank, int32_t world, fhes_allgather_fn all_gather,
+                                 fhes_bcast_fn broadcast, void *user);
+void fhes_comm_destroy(fhes_comm *comm);
+int32_t fhes_comm_rank(const fhes_comm *comm);
+int32_t fhes_comm_world(const fhes_comm *comm);
+/* 1 = RCCL, 0 = host callbacks */
+int32_t fhes_comm_is_rccl(const fhes_comm *comm);
+/* Block partition of n positions: rank r owns [lo, hi) = [min(r*c, n), min((r+1)*c, n)), c = ceil(n / world)
+ * (equal-sized segments, so the gathered rows are contiguous in position order). */
+int fhes_shard_range(int64_t n, int32_t world, int32_t rank, int64_t *lo, int64_t *hi);
+/* Host-buffer all-gather through the communicator's transport (RCCL: staged through the device). */
+int fhes_comm_all_gather_host(fhes_comm *comm, const void *send, void *recv, int64_t bytes_per_rank);
+/* In-place all-gather of arena rows: rank r contributes the `count_per_rank` ciphertexts at handles
+ * [first + r*count_per_rank, ...); afterwards every rank holds all world*count_per_rank rows. */
+int fhes_comm_all_gather_cts(fhes_comm *comm, int32_t first, int32_t count_per_rank);
+/* Broadcast of arena rows [first, first+count) from `root`. */
+int fhes_comm_broadcast_cts(fhes_comm *comm, int32_t first, int32_t count, int32_t root);
+/* Broadcast of the device-resident server keys (keyswitch key + bias, Fourier BSK in both layouts)
+ * from `root`; the other ranks need not have called fhes_upload_keys. */
+int fhes_comm_broadcast_keys(fhes_comm *comm, int32_t root);
+/* Position-sharded search.  op: "contains" (search.rs:17-20) -> 1 block, "find" (search.rs:23-28) ->
+ * 1 + num_blocks_usize blocks, "rfind_last" (the reverse scan of search.rs:155-159).  a / p are arena
+ * handles of the string (a_slots chars incl. terminator / padding) and the pattern, identical on every
+ * rank (fhes_comm_broadcast_cts).  Collective; out_handles (freshly allocated, one contiguous range)
+ * hold identical ciphertexts on every rank, bit-identical to the unsharded program. */
+int fhes_sharded_search(fhes_comm *comm, const char *op, int32_t a_first, int32_t a_slots, int32_t p_first,
+                        int32_t p_slots, int32_t num_blocks_usize, int32_t *out_handles, int32_t max_out,
+                        int32_t *n_out);
+/* Level 2: with a communicator attached, `contains` and `find` of fhes_string_op run position-sharded
+ * over its ranks (every rank makes the same call with the same operands).  NULL detaches. */
+int fhes_server_key_set_comm(fhes_server_key *sk, fhes_comm *comm);
 
 #ifdef __cplusplus
 }

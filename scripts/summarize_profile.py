@@ -3,6 +3,9 @@
   profiles/<tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary, verbatim
   profiles/<tag>_summary.json         per-kernel calls / avg duration / PMC bytes per launch
   profiles/pmc_traffic.json           what bench.py reports as roofline.traffic
+  profiles/<tag>_issue_rates.jsonl    scripts/micro/f64_rate: cycles per wave-instruction, clock under load
+  profiles/compute_roofline.json      SQ counters of the dominant blind-rotate kernel per wave and CMUX
+                                      iteration + issue costs: what bench.py turns into roofline_compute
 PMC handling follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in
 separate passes, are in KiB, and on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced
 reads -> doubled here (calibration: bsk_to_fourier reads exactly 48,627,712 B and reports 23,891 KiB).
@@ -60,6 +63,32 @@ for k in kern:
     if k in write:
         n, v = write[k]
         kern[k]["write_bytes_per_launch"] = v / n * 1024
+
+
+def pmc_all(sub):
+    """every counter of one pass, summed over the dispatches of a kernel (+ its total duration)"""
+    try:
+        f = newest(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    except ValueError:
+        return {}
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        did = r.get("Dispatch_Id", r.get("Dispatch_ID", ""))
+        if did not in seen[k]:
+            seen[k].add(did)
+            agg[k]["_dispatches"] += 1
+            agg[k]["_duration_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            agg[k]["_workgroups"] += float(r.get("Grid_Size", 0)) / max(float(r.get("Workgroup_Size", 1)), 1)
+    return agg
+
+
+sq = {}
+for sub in ("sqa", "sqb"):
+    for k, v in pmc_all(sub).items():
+        sq.setdefault(k, {}).update({(c if not c.startswith("_") else f"{sub}{c}"): x for c, x in v.items()})
 bench_line = None
 p = os.path.join(src, "bench_line.json")
 if os.path.exists(p) and os.path.getsize(p):
@@ -94,5 +123,54 @@ if br:
     params = extra.split()[-1] if "--params" in extra else "classic"
     name = "pmc_traffic.json" if params == "classic" else f"pmc_traffic_{params}.json"
     json.dump(traffic, open(os.path.join(dst, name), "w"), indent=1)
+# ---- compute roofline inputs: SQ counters of the dominant kernel ----
+rates_src = os.path.join(src, "issue_rates.jsonl")
+rates = []
+if os.path.exists(rates_src) and os.path.getsize(rates_src):
+    shutil.copy(rates_src, os.path.join(dst, f"{tag}_issue_rates.jsonl"))
+    rates = [json.loads(l) for l in open(rates_src) if l.strip().startswith("{")]
+if br and br[0] in sq:
+    c = sq[br[0]]
+    n_iter = 742 if "multibit" not in extra else None     # CMUX iterations per PBS (classic 2_2 set)
+    wgs = c.get("sqa_workgroups", 0)                      # one workgroup = one PBS, 4 waves
+    wave_iters = wgs * 4 * (n_iter or 1)
+    f64 = sum(c.get(x, 0) for x in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
+    wgs_b = c.get("sqb_workgroups", wgs) or wgs
+    dur_a, dur_b = c.get("sqa_duration_ns", 0) * 1e-9, c.get("sqb_duration_ns", 0) * 1e-9
+    clock = c.get("GRBM_GUI_ACTIVE", 0) / 8 / dur_a if dur_a else None     # MI355X_MICROARCH.md, DVFS give-back
+    def rate(instr, wps=2):
+        for r in rates:
+            if r["instr"] == instr and r["waves_per_simd"] == wps:
+                return r["cycles_from_wall_at_measured_clock"]
+        return None
+    c_f64 = rate("v_fma_f64")
+    mix = rate("mix 5 fma_f64 : 3 int")
+    c_other = (8 * mix - 5 * c_f64) / 3 if (mix and c_f64) else None
+    comp = {
+        "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc passes sqa / sqb of the bench command), profiles/{tag}_issue_rates.jsonl",
+        "kernel": br[0], "pbs_profiled": wgs, "cmux_iterations_per_pbs": n_iter,
+        "valu_per_wave_iter": c.get("SQ_INSTS_VALU", 0) / wave_iters if wave_iters else None,
+        "f64_per_wave_iter": f64 / (wgs_b * 4 * (n_iter or 1)) if wgs_b else None,
+        "lds_instr_per_wave_iter": c.get("SQ_INSTS_LDS", 0) / (wgs_b * 4 * (n_iter or 1)) if wgs_b else None,
+        "clock_ghz_under_load": clock / 1e9 if clock else None,
+        "issue_cycles_f64_2waves": c_f64, "issue_cycles_other_next_to_f64": c_other,
+        "valu_busy_frac": c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (c.get("GRBM_GUI_ACTIVE", 0) / 8 * 256 * 4) if c.get("GRBM_GUI_ACTIVE") else None,
+        "lds_array_busy_frac": c.get("SQ_LDS_IDX_ACTIVE", 0) / (dur_b * clock * 256) if (dur_b and clock) else None,
+        "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT", 0),
+        "wave_time_split": {"active_any": c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"] * (dur_a / dur_b if dur_b else 1) if c.get("SQ_WAVE_CYCLES") else None,
+                            "wait_any": c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+                            "wait_inst_any": c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+                            "wait_inst_lds": c.get("SQ_WAIT_INST_LDS", 0) / c["SQ_WAVE_CYCLES"] * (dur_a / dur_b if dur_b else 1) if c.get("SQ_WAVE_CYCLES") else None},
+        "raw": {k2: v2 for k2, v2 in c.items()},
+        "note": "SQ_* ACTIVE / WAIT / WAVE counters are quad-cycles; SQ_INSTS_* are wave-instructions; one workgroup = one PBS = 4 waves x cmux_iterations",
+    }
+    if comp["valu_per_wave_iter"] and c_f64 and c_other and clock and n_iter:
+        other = comp["valu_per_wave_iter"] - comp["f64_per_wave_iter"]
+        cyc = comp["f64_per_wave_iter"] * c_f64 + other * c_other
+        comp["issue_cycles_per_pbs_iteration_per_cu"] = cyc
+        comp["bound_pbs_per_s"] = 256 * clock / (n_iter * cyc)
+    json.dump(comp, open(os.path.join(dst, "compute_roofline.json" if "multibit" not in extra else f"compute_roofline_{extra.split()[-1]}.json"), "w"), indent=1)
+    out["compute_roofline"] = comp
+    json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 for k, v in kern.items():
     print(f"{k[:70]:70s} calls={v['calls']:5d} avg={v['avg_ms']:9.4f} ms  fetch/launch={v.get('fetch_bytes_per_launch', 0)/1e6:10.2f} MB")

@@ -96,8 +96,12 @@ def test_serialisation_round_trips(libs):
     ck = ClientKey(toy_params(), l=63, seed=9)
     s = FheString.new(ck, "hello", 7)
     blob = s.to_bytes()
-    assert blob[:4] == b"FHES" and len(blob) == 24 + 32 * 257 * 8
+    assert blob[:4] == b"FHES" and len(blob) == 24 + 2 * 32 + 32 * 257 * 8    # header | (degree, noise) per block | words
+    assert blob[24:24 + 64] == bytes([3, 0] * 32)                               # fresh encryption: degree 3, noise level 0
     s2 = FheString.from_bytes(blob)
+    lib = libs[0]
+    deg, noi = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
+    assert lib.fhes_ct_block_meta(s2._h, deg, noi) == 0 and list(deg) == [3] * 32 and list(noi) == [0] * 32
     ck2 = ClientKey.from_bytes(ck.to_bytes())
     assert s2.decrypt(ck2) == "hello" and s2.num_blocks == 32
     assert ck2.num_blocks_usize == ck.num_blocks_usize == 3
@@ -108,6 +112,24 @@ def test_serialisation_round_trips(libs):
         FheString.from_bytes(blob[:100])
     with pytest.raises(FheError):
         ClientKey.from_bytes(b"nope" + blob[4:])
+    # production mode (seed 0): 256-bit OS keys; two keys differ, encryption randomness is not in the blob,
+    # two encryptions of the same text differ, a restored key decrypts both
+    k1, k2 = ClientKey(toy_params(), l=63), ClientKey(toy_params(), l=63)
+    b1 = k1.to_bytes()
+    assert b1 != k2.to_bytes() and len(b1) == len(ck.to_bytes()) + 16         # mode word + 32-byte key instead of seed + counter
+    e1, e2 = FheString.new(k1, "same", 6), FheString.new(k1, "same", 6)
+    assert e1.to_bytes() != e2.to_bytes()
+    k1r = ClientKey.from_bytes(b1)
+    assert e1.decrypt(k1r) == e2.decrypt(k1r) == "same"
+    assert k1.to_bytes() == b1                                                # encrypting changed nothing that is serialised
+    # ServerKey blob (server_key.rs:11): header + standard-domain BSK + KSK; deserialising needs a device
+    p = toy_params()
+    n = lib.fhes_server_key_serialize(ck._h, None, 0)
+    assert n == 12 + C.sizeof(Params) + 8 + 4 + 4 + 8 + 8 + 8 * (lib.fhes_bsk_words(C.byref(p)) + lib.fhes_ksk_words(C.byref(p)))
+    buf = (C.c_uint8 * n)()
+    assert lib.fhes_server_key_serialize(ck._h, buf, n) == n and bytes(buf[:4]) == b"FHES"
+    assert not lib.fhes_server_key_deserialize(buf, n, 0)                     # no HIP device here: fails loudly
+    assert not lib.fhes_server_key_deserialize(buf, n - 8, 0) and b"truncated" in lib.fhes_last_error()
 
 
 def test_scratch_cells_are_reused(libs):

@@ -1,0 +1,88 @@
+"""Two ranks on the ONE GPU of the test box: the device path of the position-sharded search
+(fhes_sharded_search: find_all_range on each rank's block of positions, fhes_comm_all_gather_cts on
+arena rows, replicated reduction) with the host transport carried by gloo -- RCCL refuses two ranks on
+one device, the 8-GPU RCCL run is the driver's (bench.py --gpus N).  Every rank must end with the
+ciphertext bits of the unsharded program."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world_size, port, q):
+    import ctypes as C
+
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from fhe_string_amd._lib import check
+        from fhe_string_amd.parallel import Comm
+        from tests.helpers import World, ptr
+        from tests.progs import Prog, decode_result, num_blocks_usize, string_blocks
+        w = World("default", 255, 0xF4E50000)        # same seeds on every rank: identical keys
+        bu = num_blocks_usize(255)
+        ctx = w.ctx()
+        comm = Comm.host(ctx, dist)
+        text, pat = "the quick brown fox jumps over the lazy dog, twice over", "over"
+        a, b = string_blocks(text, 60), string_blocks(pat)
+        ha = check(w.lib.fhes_arena_alloc(ctx, len(a)))
+        hb = check(w.lib.fhes_arena_alloc(ctx, len(b)))
+        if rank == 0:                                  # only the root encrypts; inputs travel by broadcast
+            cts = w.encrypt(np.concatenate([a, b]))
+            check(w.lib.fhes_arena_upload(ctx, ha, len(a), ptr(cts[:len(a)])))
+            check(w.lib.fhes_arena_upload(ctx, hb, len(b), ptr(cts[len(a):])))
+        comm.broadcast_cts(ha, len(a), 0)
+        comm.broadcast_cts(hb, len(b), 0)
+        comm.broadcast_keys(0)
+
+        def fetch(handles):
+            out = np.zeros((len(handles), w.W), dtype=np.uint64)
+            check(w.lib.fhes_arena_download(ctx, handles[0], len(handles), ptr(out)))
+            return out
+
+        f = fetch(comm.sharded_search("find", ha, 61, hb, 5, bu))
+        c = fetch(comm.sharded_search("contains", ha, 61, hb, 5, bu))
+        pr = Prog(w.p, "find", [61, 5], bu)
+        ins = np.concatenate([np.arange(ha, ha + len(a)), np.arange(hb, hb + len(b))]).astype(np.int32)
+        outs = np.zeros(pr.n_outputs, dtype=np.int32)
+        check(w.lib.fhes_program_run(ctx, pr.h, ptr(ins), ptr(outs)))
+        ref = fetch([int(outs[0]) + k for k in range(pr.n_outputs)])
+        q.put((rank, decode_result("find", w.decrypt(f), bu), bool(w.decrypt(c)[0] & 1), bool(np.array_equal(f, ref)),
+               f[:, :8].tobytes()))
+        comm.close()
+        w.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_host_transport(libs):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    text = "the quick brown fox jumps over the lazy dog, twice over"
+    for rank, found, contains, same_bits, _ in results:
+        assert found == text.find("over"), rank
+        assert contains is True
+        assert same_bits, f"rank {rank}: sharded find differs from the unsharded program"
+    assert results[0][4] == results[1][4], "the two ranks hold different ciphertexts"

@@ -143,22 +143,49 @@ def test_batched_program_equals_single_runs(libs):
 
 
 def test_config4_contains_1024_sharded_path_single_rank(libs):
-    """BASELINE config 4 through the position-sharded path (ShardedSearch over DeviceExecutor,
-    world size 1 here; the 2-rank exchange is covered by tests/test_parallel_gloo.py)."""
-    from fhe_string_amd.parallel import DeviceExecutor, ShardedSearch
+    """BASELINE config 4 through the position-sharded C path (fhes_sharded_search) on an RCCL
+    communicator of world size 1; two ranks: tests/test_gpu_multirank.py (device path, host transport)
+    and tests/test_parallel_gloo.py (CPU).  Outputs must be bit-identical to the unsharded programs."""
+    from fhe_string_amd.parallel import Comm
     w = world("default", l=1024)
     bu = num_blocks_usize(1024)
     assert bu == 6
     rng = np.random.default_rng(0xF4E50004)
     s = "".join(chr(c) for c in rng.integers(0x20, 0x7F, size=1000))
     pat = s[700:708]
+    ctx = w.ctx()
+    comm = Comm.rccl(ctx, 0, 1, Comm.unique_id())
+    assert w.lib.fhes_comm_is_rccl(comm._h) == 1
     a = w.encrypt(string_blocks(s, 1024))
-    ss = ShardedSearch(DeviceExecutor(w.ctx(), w.p), bu)
+    ha = check(w.lib.fhes_arena_alloc(ctx, len(a)))
+    check(w.lib.fhes_arena_upload(ctx, ha, len(a), ptr(a)))
+    comm.broadcast_cts(ha, len(a), 0)      # no-op at world 1, exercises the entry point
+    comm.broadcast_keys(0)
+
+    def fetch(handles):
+        out = np.zeros((len(handles), w.W), dtype=np.uint64)
+        check(w.lib.fhes_arena_download(ctx, handles[0], len(handles), ptr(out)))
+        check(w.lib.fhes_arena_free(ctx, handles[0], len(handles)))
+        return out
+
     for p, expect in [(pat, True), ("\x7f" * 8, False)]:
-        r = ss.contains(a, w.encrypt(string_blocks(p)))
+        b = w.encrypt(string_blocks(p))
+        hb = check(w.lib.fhes_arena_alloc(ctx, len(b)))
+        check(w.lib.fhes_arena_upload(ctx, hb, len(b), ptr(b)))
+        r = fetch(comm.sharded_search("contains", ha, 1025, hb, 9, bu))
         assert bool(w.decrypt(r)[0] & 1) is expect
-    f = ss.find(a, w.encrypt(string_blocks(pat)))
-    assert decode_result("find", w.decrypt(f), bu) == s.find(pat)
+        if expect:
+            f = fetch(comm.sharded_search("find", ha, 1025, hb, 9, bu))
+            assert decode_result("find", w.decrypt(f), bu) == s.find(pat)
+            # the unsharded program computes the same ciphertext bits
+            pr = Prog(w.p, "contains", [1025, 9], bu)
+            ins = np.concatenate([np.arange(ha, ha + len(a)), np.arange(hb, hb + len(b))]).astype(np.int32)
+            outs = np.zeros(pr.n_outputs, dtype=np.int32)
+            check(w.lib.fhes_program_run(ctx, pr.h, ptr(ins), ptr(outs)))
+            assert np.array_equal(fetch([int(outs[0])]), r)
+        check(w.lib.fhes_arena_free(ctx, hb, len(b)))
+    check(w.lib.fhes_arena_free(ctx, ha, len(a)))
+    comm.close()
 
 
 def test_config3_split_256(libs):

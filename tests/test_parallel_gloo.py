@@ -1,7 +1,8 @@
-"""N > 1 path on CPU: two gloo ranks shard the positions of find_all, all-gather found[], and run
-the replicated reduction.  The executor here is the oracle (test infrastructure); on the GPU the
-same ShardedSearch runs over DeviceExecutor + RCCL.  Results must be bit-identical to the
-unsharded programs."""
+"""N > 1 path on CPU: two gloo ranks shard the positions of find_all (fhes_shard_range), all-gather
+found[] through the C communicator (fhes_comm_create_host / fhes_comm_all_gather_host, carried by gloo)
+and run the replicated reduction.  The executor here is the oracle (test infrastructure: there is no
+GPU in this container); on a GPU the whole path is fhes_sharded_search over RCCL or the same host
+transport (tests/test_gpu_multirank.py).  Results must be bit-identical to the unsharded programs."""
 import os
 import socket
 
@@ -10,7 +11,7 @@ import pytest
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from fhe_string_amd.parallel import ShardedSearch, shard_range
+from fhe_string_amd.parallel import Comm, ShardedSearch, shard_range
 from tests.helpers import World
 from tests.progs import Prog, decode_result, num_blocks_usize, string_blocks
 
@@ -44,7 +45,9 @@ def _worker(rank, world_size, port, q):
         a = w.encrypt(string_blocks(text, 12))
         b = w.encrypt(string_blocks(pat))
         m = w.encrypt(string_blocks(miss))
-        ss = ShardedSearch(OracleExecutor(w), bu, dist)
+        comm = Comm.host(None, dist)                 # C communicator, host transport over gloo, no device
+        assert (comm.rank, comm.world) == (rank, world_size)
+        ss = ShardedSearch(OracleExecutor(w), bu, comm)
         found = ss.find_all(a, b)
         res_find = ss.find(a, b)
         res_contains = ss.contains(a, b)
@@ -55,6 +58,7 @@ def _worker(rank, world_size, port, q):
         q.put((rank, bool(np.array_equal(found, ref_found)), bool(np.array_equal(res_find, ref_find)),
                decode_result("find", w.decrypt(res_find), bu), bool(w.decrypt(res_contains)[0] & 1),
                bool(w.decrypt(res_miss)[0] & 1)))
+        comm.close()
     finally:
         dist.destroy_process_group()
 
@@ -65,7 +69,8 @@ def test_shard_range_partitions():
             parts = [shard_range(n, ws, r) for r in range(ws)]
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(ws - 1))
-            assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+            chunk = -(-n // ws)                      # equal segments: the gathered rows are contiguous
+            assert all(b - a <= chunk for a, b in parts) and all(a == min(r * chunk, n) for r, (a, b) in enumerate(parts))
 
 
 def test_sharded_search_two_gloo_ranks(libs):
