@@ -76,6 +76,7 @@ SIGNATURES = {
     "fhes_program_compile": (_P, [_PP, C.c_char_p, _P, C.c_int32, C.c_int32]),
     "fhes_program_destroy": (None, [_P]),
     "fhes_program_scratch_cells": (C.c_int32, [_P]),
+    "fhes_program_out_meta": (C.c_int, [_P, _P, _P]),
     "fhes_program_info": (C.c_int, [_P, _P]),
     "fhes_program_out_parts": (C.c_int32, [_P, _P, C.c_int32]),
     "fhes_op_signature": (C.c_char_p, [C.c_char_p]),

@@ -152,6 +152,13 @@ class _Ct:
     def num_blocks(self):
         return _L().fhes_ct_num_blocks(self._h)
 
+    def block_meta(self):
+        """(degree, noise level) per block: fhes_ct_block_meta"""
+        n = self.num_blocks
+        deg, noi = (C.c_uint8 * n)(), (C.c_uint8 * n)()
+        check(_L().fhes_ct_block_meta(self._h, deg, noi))
+        return list(deg), list(noi)
+
     def to_bytes(self):
         n = check(_L().fhes_ct_serialize(self._h, None, 0))
         buf = (C.c_uint8 * n)()

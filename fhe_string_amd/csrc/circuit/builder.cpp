@@ -188,8 +188,12 @@ Program Builder::finish(const std::vector<Blk> &outputs, const std::string &name
   // re-bootstrapped here; combinations of INPUT blocks only (re-wiring, trivial constants) carry
   // no new noise and are materialised by the linear kernel.
   std::vector<int32_t> out_slots;
+  std::vector<uint32_t> out_deg;
+  std::vector<double> out_noise;
   for (Blk o : outputs) {
     if (!o.trivial() && (o.noise > 1.0 || o.deg >= (uint32_t)msg_mod())) o = clean(o);
+    out_deg.push_back(o.deg);
+    out_noise.push_back(o.trivial() ? 0.0 : o.noise);
     if (o.terms.size() == 1 && o.terms[0].coef == 1 && o.cst == 0) {
       out_slots.push_back(o.terms[0].slot);
     } else {
@@ -244,6 +248,8 @@ Program Builder::finish(const std::vector<Blk> &outputs, const std::string &name
   prog.level_ptr.push_back((int32_t)order.size());
   if (order.empty()) prog.level_ptr = {0};
   for (int32_t s : out_slots) prog.out_slots.push_back(remap(s));
+  prog.out_deg = out_deg;
+  prog.out_noise = out_noise;
   return prog;
 }
 

@@ -52,6 +52,8 @@ struct Program {
   std::vector<Table> luts;
   std::vector<int32_t> out_slots;       // one per output block
   std::vector<int32_t> out_parts;       // block counts of the result objects (sum == out_slots.size())
+  std::vector<uint32_t> out_deg;        // per output block: degree bound and noise (bootstrap units) as it
+  std::vector<double> out_noise;        // crosses the program boundary (clean: < msg_mod, <= 1)
   int64_t n_pbs = 0;
   std::string name;
 };

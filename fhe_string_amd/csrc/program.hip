@@ -140,6 +140,15 @@ int32_t fhes_program_out_parts(const fhes_program *fp, int32_t *parts, int32_t m
   return n;
 }
 
+int fhes_program_out_meta(const fhes_program *fp, int32_t *degree, double *noise) {
+  if (!fp || !degree || !noise) return fail(FHES_ERR_INVALID, "null argument");
+  for (size_t i = 0; i < fp->prog.out_slots.size(); i++) {
+    degree[i] = i < fp->prog.out_deg.size() ? (int32_t)fp->prog.out_deg[i] : -1;
+    noise[i] = i < fp->prog.out_noise.size() ? fp->prog.out_noise[i] : -1.0;
+  }
+  return FHES_OK;
+}
+
 const char *fhes_op_signature(const char *op) { return op ? circ::op_signature(op) : nullptr; }
 
 int fhes_program_export(const fhes_program *fp, int32_t *level_ptr, int32_t *term_ptr, int32_t *term_idx,

@@ -195,6 +195,10 @@ int fhes_program_info(const fhes_program *prog, int64_t info[8]);
 /* Block counts of the result objects, in order (e.g. find -> {1, Bu}; split -> {n, n*Bu, n*Bu};
  * strip_prefix -> {1, slots*Bc}).  Returns the number of parts. */
 int32_t fhes_program_out_parts(const fhes_program *prog, int32_t *parts, int32_t max_parts);
+/* Degree bound and noise (in units of one bootstrap output) of every output block as the builder tracks
+ * them: results cross the program boundary clean (degree < message modulus, noise <= 1), so that a
+ * following operation may treat them like fresh operands.  Arrays of n_outputs entries. */
+int fhes_program_out_meta(const fhes_program *prog, int32_t *degree, double *noise);
 /* Arena cells one instance of the program occupies while it runs (results excluded): node
  * results share cells once every reader of the previous occupant ran in an earlier level. */
 int32_t fhes_program_scratch_cells(const fhes_program *prog);

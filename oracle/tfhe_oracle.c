@@ -502,3 +502,127 @@ uint64_t oracle_lwe_phase(const uint64_t *ct, const uint64_t *sk, int32_t dim) {
   for (int i = 0; i < dim; i++) acc -= ct[i] * sk[i];
   return acc;
 }
+
+/* ---- independent client side (test infrastructure) ------------------------------------------
+ * Key generation, encryption and decoding restated here from the published scheme, with a PRNG of
+ * their own (xoshiro256**, Box-Muller), so that a parity test can run WITHOUT the product's
+ * client.cpp on either side: keys made here go in through fhes_upload_keys, inputs encrypted here,
+ * outputs decoded here.  Shortint encoding (tfhe-rs shortint, the set named at
+ * /root/reference/src/lib.rs:45): value v in [0, 2^(message_bits+carry_bits)) sits at
+ * v * 2^(63 - message_bits - carry_bits), one padding bit on top.
+ * GGSW row (i, level l, row r): a GLWE encryption of zero with g_l = 2^(64 - B*(l+1)) added to the
+ * constant coefficient of component r when the plaintext bit is 1 (classic: the key bit s_i;
+ * multi-bit: prod_t [s_{jg+t} == bit (g-1-t) of c]).  Keyswitch row (i, l): LWE encryption under
+ * the small key of S_i * 2^(64 - b*(l+1)). */
+typedef struct { uint64_t s[4]; int have_spare; double spare; } orng;
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static uint64_t orng_next(orng *r) {
+  const uint64_t res = rotl64(r->s[1] * 5, 7) * 9, t = r->s[1] << 17;
+  r->s[2] ^= r->s[0]; r->s[3] ^= r->s[1]; r->s[1] ^= r->s[2]; r->s[0] ^= r->s[3];
+  r->s[2] ^= t; r->s[3] = rotl64(r->s[3], 45);
+  return res;
+}
+static void orng_seed(orng *r, uint64_t seed, uint64_t stream) {
+  uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ull);
+  for (int i = 0; i < 4; i++) {  /* splitmix64 */
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    r->s[i] = z ^ (z >> 31);
+  }
+  r->have_spare = 0;
+  for (int i = 0; i < 8; i++) (void)orng_next(r);
+}
+static double orng_gauss(orng *r) {
+  if (r->have_spare) { r->have_spare = 0; return r->spare; }
+  const double u1 = ((double)(orng_next(r) >> 11) + 1.0) * 0x1p-53, u2 = (double)(orng_next(r) >> 11) * 0x1p-53;
+  const double m = sqrt(-2.0 * log(u1)), a = 6.283185307179586476925286766559 * u2;
+  r->spare = m * sin(a);
+  r->have_spare = 1;
+  return m * cos(a);
+}
+static uint64_t orng_noise(orng *r, double std_rel) { return (uint64_t)(int64_t)llrint(orng_gauss(r) * std_rel * 0x1p64); }
+
+int oracle_keygen(const oracle_params *p, uint64_t seed, uint64_t *big_sk, uint64_t *small_sk, uint64_t *bsk,
+                  uint64_t *ksk) {
+  if (!p || !big_sk || !small_sk || !bsk || !ksk) return -1;
+  const int N = p->poly_size, k = p->glwe_dim, kp1 = k + 1, L = p->pbs_level, n = p->lwe_dim, big = k * N;
+  const int g = p->grouping_factor > 1 ? p->grouping_factor : 1;
+  orng r;
+  orng_seed(&r, seed, 1);
+  for (int i = 0; i < big; i++) big_sk[i] = orng_next(&r) >> 63;
+  for (int i = 0; i < n; i++) small_sk[i] = orng_next(&r) >> 63;
+  const long n_ggsw = g > 1 ? ((long)(n / g) << g) : n;
+  const long rows = n_ggsw * L * kp1;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (long row_id = 0; row_id < rows; row_id++) {
+    const long i = row_id / (L * kp1);
+    const int l = (int)((row_id / kp1) % L), row = (int)(row_id % kp1);
+    uint64_t *glwe = bsk + (size_t)row_id * kp1 * N, *body = glwe + (size_t)k * N;
+    orng q;
+    orng_seed(&q, seed, 0x100000000ull + (uint64_t)row_id);
+    for (int j = 0; j < N; j++) body[j] = orng_noise(&q, p->glwe_noise_std);
+    for (int c = 0; c < k; c++) {
+      uint64_t *a = glwe + (size_t)c * N;
+      for (int j = 0; j < N; j++) a[j] = orng_next(&q);
+      for (int s = 0; s < N; s++) {  /* body += a * S_c, negacyclic */
+        if (!big_sk[(size_t)c * N + s]) continue;
+        for (int j = 0; j < N - s; j++) body[j + s] += a[j];
+        for (int j = N - s; j < N; j++) body[j + s - N] -= a[j];
+      }
+    }
+    uint64_t bit;
+    if (g == 1) bit = small_sk[i];
+    else {
+      const long grp = i >> g;
+      const int cc = (int)(i & ((1 << g) - 1));
+      bit = 1;
+      for (int t = 0; t < g; t++) bit &= (small_sk[grp * g + t] == (uint64_t)((cc >> (g - 1 - t)) & 1)) ? 1u : 0u;
+    }
+    if (bit) glwe[(size_t)row * N] += 1ull << (64 - p->pbs_base_log * (l + 1));
+  }
+  const long krows = (long)big * p->ks_level;
+#pragma omp parallel for schedule(static)
+  for (long rr = 0; rr < krows; rr++) {
+    const int i = (int)(rr / p->ks_level), l = (int)(rr % p->ks_level);
+    uint64_t *ct = ksk + (size_t)rr * (n + 1);
+    orng q;
+    orng_seed(&q, seed, 0x200000000ull + (uint64_t)rr);
+    uint64_t b = orng_noise(&q, p->lwe_noise_std);
+    for (int j = 0; j < n; j++) {
+      ct[j] = orng_next(&q);
+      if (small_sk[j]) b += ct[j];
+    }
+    if (big_sk[i]) b += 1ull << (64 - p->ks_base_log * (l + 1));
+    ct[n] = b;
+  }
+  return 0;
+}
+
+void oracle_encrypt_blocks(const oracle_params *p, const uint64_t *big_sk, uint64_t seed, const uint8_t *values,
+                           int64_t count, uint64_t *out) {
+  const int big = p->glwe_dim * p->poly_size, bits = p->message_bits + p->carry_bits;
+  for (int64_t q = 0; q < count; q++) {
+    orng r;
+    orng_seed(&r, seed, 0x300000000ull + (uint64_t)q);
+    uint64_t *ct = out + (size_t)q * (big + 1);
+    uint64_t b = orng_noise(&r, p->glwe_noise_std) + ((uint64_t)values[q] << (63 - bits));
+    for (int j = 0; j < big; j++) {
+      ct[j] = orng_next(&r);
+      if (big_sk[j]) b += ct[j];
+    }
+    ct[big] = b;
+  }
+}
+
+/* decoded value including the padding bit: round(phase / delta) mod 2^(bits+1) */
+void oracle_decrypt_blocks(const oracle_params *p, const uint64_t *big_sk, const uint64_t *cts, int64_t count,
+                           uint8_t *values) {
+  const int big = p->glwe_dim * p->poly_size, bits = p->message_bits + p->carry_bits;
+  for (int64_t q = 0; q < count; q++) {
+    const uint64_t ph = oracle_lwe_phase(cts + (size_t)q * (big + 1), big_sk, big);
+    const uint64_t delta = 1ull << (63 - bits);
+    values[q] = (uint8_t)(((ph + delta / 2) >> (63 - bits)) & (uint64_t)((2u << bits) - 1));
+  }
+}

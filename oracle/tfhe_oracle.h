@@ -119,6 +119,16 @@ int oracle_exec_levels(const oracle_ctx *c, uint64_t *arena, size_t stride, int3
 /* phase = body - <mask, sk> (sk entries 0/1), for decrypt checks. */
 uint64_t oracle_lwe_phase(const uint64_t *ct, const uint64_t *sk, int32_t dim);
 
+/* Independent client side (own PRNG, no product code): secret keys as 0/1 words, standard-domain
+ * BSK / KSK in the layouts of oracle_set_keys, shortint encryption and decoding (value incl. the
+ * padding bit).  A parity test built on these never touches fhe_string_amd/csrc/client.cpp. */
+int oracle_keygen(const oracle_params *p, uint64_t seed, uint64_t *big_sk /*[kN]*/, uint64_t *small_sk /*[n]*/,
+                  uint64_t *bsk, uint64_t *ksk);
+void oracle_encrypt_blocks(const oracle_params *p, const uint64_t *big_sk, uint64_t seed, const uint8_t *values,
+                           int64_t count, uint64_t *out /*[count][kN+1]*/);
+void oracle_decrypt_blocks(const oracle_params *p, const uint64_t *big_sk, const uint64_t *cts, int64_t count,
+                           uint8_t *values);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,3 +80,49 @@ class World:
 @functools.lru_cache(maxsize=None)
 def world(which="toy", l=255, seed=0xF4E50000):
     return World(which, l, seed)
+
+
+class OracleWorld:
+    """A key set made WITHOUT the product's client code: oracle_keygen / oracle_encrypt_blocks /
+    oracle_decrypt_blocks (own PRNG, oracle/tfhe_oracle.c).  Only the parameter struct comes from the
+    product library.  `ctx()` uploads these keys through the Level-0 ABI (fhes_upload_keys)."""
+
+    def __init__(self, which="toy", seed=0x0AC1E):
+        self.lib = _lib.load(strict=False)
+        self.orc = oracle_lib.load()
+        self.p = Params()
+        check(getattr(self.lib, "fhes_params_" + which)(C.byref(self.p)))
+        self.W, self.N, self.n = self.p.ct_words(), self.p.poly_size, self.p.lwe_dim
+        self.seed, self._enc = seed, 0
+        self.big_sk = np.zeros(self.W - 1, dtype=np.uint64)
+        self.small_sk = np.zeros(self.n, dtype=np.uint64)
+        self.bsk = np.zeros(self.lib.fhes_bsk_words(C.byref(self.p)), dtype=np.uint64)
+        self.ksk = np.zeros(self.lib.fhes_ksk_words(C.byref(self.p)), dtype=np.uint64)
+        assert self.orc.oracle_keygen(C.addressof(self.p), seed, ptr(self.big_sk), ptr(self.small_sk), ptr(self.bsk), ptr(self.ksk)) == 0
+        self.oc = self.orc.oracle_ctx_create(C.addressof(self.p))
+        assert self.oc and self.orc.oracle_set_keys(self.oc, ptr(self.bsk), ptr(self.ksk)) == 0
+        self._ctx = None
+
+    def encrypt(self, values):
+        v = np.ascontiguousarray(values, dtype=np.uint8)
+        out = np.zeros((len(v), self.W), dtype=np.uint64)
+        self._enc += 1
+        self.orc.oracle_encrypt_blocks(C.addressof(self.p), ptr(self.big_sk), self.seed + 7919 * self._enc, ptr(v), len(v), ptr(out))
+        return out
+
+    def decrypt(self, cts):
+        cts = np.ascontiguousarray(cts, dtype=np.uint64).reshape(-1, self.W)
+        out = np.zeros(len(cts), dtype=np.uint8)
+        self.orc.oracle_decrypt_blocks(C.addressof(self.p), ptr(self.big_sk), ptr(cts), len(cts), ptr(out))
+        return out
+
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = check_ptr(self.lib.fhes_ctx_create(C.byref(self.p), 0))
+            check(self.lib.fhes_upload_keys(self._ctx, ptr(self.bsk), ptr(self.ksk)))
+        return self._ctx
+
+    def close(self):
+        if self._ctx is not None:
+            self.lib.fhes_ctx_destroy(self._ctx)
+            self._ctx = None

@@ -34,6 +34,9 @@ def load():
         "oracle_pbs": (None, [_P, _P, _P, _P]),
         "oracle_exec_levels": (C.c_int, [_P, _P, C.c_size_t, C.c_int32] + [_P] * 8 + [C.c_int32]),
         "oracle_lwe_phase": (C.c_uint64, [_P, _P, C.c_int32]),
+        "oracle_keygen": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P]),
+        "oracle_encrypt_blocks": (None, [_P, _P, C.c_uint64, _P, C.c_int64, _P]),
+        "oracle_decrypt_blocks": (None, [_P, _P, _P, C.c_int64, _P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

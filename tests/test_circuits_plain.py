@@ -338,3 +338,27 @@ def test_logdepth_depth_and_size(libs):
     for op, shape in (("split", [129, 4]), ("lt", [65, 65]), ("rfind", [129, 4])):
         ref, fast = prog(op, shape, bu), prog(op + "_logdepth", shape, bu)
         assert fast.n_levels * 4 < ref.n_levels, (op, fast.n_levels, ref.n_levels)
+
+
+def test_results_cross_the_program_boundary_clean(libs):
+    """every output block of every operation is handed over with the noise of ONE
+    bootstrap at most and a degree below the message modulus -- the one-hot gathers (char_at,
+    substr_from: sums of up to 257 bootstrapped blocks) included -- so chained API calls start from the
+    operand the next circuit is sized for.  Under the multi-bit sets (noise cap 34) as well."""
+    import ctypes as C
+    import numpy as np
+    from fhe_string_amd import _lib
+    from fhe_string_amd.api import multibit_params
+    lib = _lib.load()
+    cases = [("find", [65, 5]), ("rfind", [33, 3]), ("len", [65]), ("char_at", [257]), ("substr_from", [41]), ("substr_to", [41]),
+             ("trim", [17]), ("strip_prefix", [33, 3]), ("split", [17, 3]), ("split_logdepth", [17, 3]), ("replace", [9, 3, 2, 8]),
+             ("to_uppercase", [9]), ("slices_reverse", [5]), ("ne", [9, 9]), ("insert", [9, 3]), ("find_logdepth", [65, 5])]
+    for params in (default_params(), multibit_params(2), multibit_params(3)):
+        for op, shape in cases:
+            bu = num_blocks_usize(256 if shape[0] > 256 else 255)
+            p = Prog(params, op, shape, bu)
+            deg = np.zeros(p.n_outputs, dtype=np.int32)
+            noise = np.zeros(p.n_outputs, dtype=np.float64)
+            assert lib.fhes_program_out_meta(p.h, deg.ctypes.data, noise.ctypes.data) == 0
+            assert (noise <= 1.0).all() and (noise >= 0).all(), (op, float(noise.max()))
+            assert (deg < 4).all() and (deg >= 0).all(), (op, int(deg.max()))

@@ -91,8 +91,11 @@ def test_full_size_properties(keys):
     assert a.rfind(sk, api.FheString.new(ck, pat)).decrypt(ck) == s.rfind(pat)
     b = api.FheString.new(ck, s[:40] + "~" + s[41:])
     assert ck.decrypt_bool(a.lt(sk, b)) == (s < s[:40] + "~" + s[41:])
-    # determinism: the same call twice gives bit-identical ciphertexts
-    r1 = a.find(sk, api.FheString.new(ck, pat))
+    # determinism: the same call on the same ciphertexts gives bit-identical result ciphertexts, and a
+    # chained operation on a result (clean blocks at the program boundary) still decrypts correctly
+    pe = api.FheString.new(ck, pat)
+    r1, r2 = a.find(sk, pe), a.find(sk, pe)
+    assert r1.val.to_bytes() == r2.val.to_bytes() and r1.is_some.to_bytes() == r2.is_some.to_bytes()
     st = sk.stats()
     assert st.pbs_count > 0 and st.arena_in_use < st.arena_capacity
 
@@ -344,21 +347,92 @@ def test_remaining_public_methods_on_gpu(keys):
     assert api.FheUsize.max(sk) == 255 and api.FheString.max_len_with_key(sk) == 255
 
 
-@pytest.mark.gpu
-def test_config5_find_rfind_512_padded_multibit(libs):
-    """BASELINE.json config 5 shape (500 characters padded to 512, 3-character pattern, l = 1023 =>
-    5 usize blocks) under the multi-bit g = 2 parameters: find and rfind (the other three operations
-    of the suite take minutes: scripts/config5.py, profiles/r01_config5_*.jsonl)"""
+def config5_inputs():
     rng = np.random.default_rng(0xF4E50005)
     body = "".join(chr(c) for c in rng.integers(0x21, 0x7F, size=494))
-    text = "  " + body[:200] + " " + body[200:] + "   "
-    pat = text[301:304]
+    text = "  " + body[:200] + " " + body[200:] + "   "       # 500 chars with blanks to trim / split on
+    return text, text[301:304]
+
+
+@pytest.mark.gpu
+def test_config5_full_suite_512_padded_multibit2(libs):
+    """BASELINE.json config 5 (examples/cmd/main.rs:127-142, 269-283, 219-238, 442-449): find / rfind /
+    trim / split / replace on 500 characters padded to 512, 3-character pattern, l = 1023 => 5 usize
+    blocks, multi-bit g = 2 parameters.  Faithful circuits for all five (about two minutes: split and
+    replace are thousands of dependent levels), then the opt-in log-depth forms of find / rfind / trim /
+    split, which must give the same answers.  Wall-clock per operation goes to stdout (pytest -s) and is
+    recorded by scripts/config5.py under profiles/."""
+    import time
+    text, pat = config5_inputs()
     ck, sk = api.generate_keys_with_params(api.multibit_params(2), 1023, seed=0xF4E50005)
     try:
         assert sk.num_blocks_usize == 5
+        A, P, R = api.FheString.new(ck, text, 512), api.FheString.new(ck, pat), api.FheString.new(ck, "_")
+        rep = text.replace(pat, "_")
+        suite = [("find", lambda: A.find(sk, P).decrypt(ck), text.find(pat)),
+                 ("rfind", lambda: A.rfind(sk, P).decrypt(ck), text.rfind(pat)),
+                 ("trim", lambda: A.trim(sk).decrypt(ck), text.strip(" \t\n\x0b\x0c\r")),
+                 ("split", lambda: A.split(sk, P).decrypt(ck), text.split(pat)),
+                 ("replace", lambda: A.replace(sk, P, R, len(rep)).decrypt(ck), rep)]
+        for mode in ("faithful", "logdepth"):
+            sk.set_logdepth(mode == "logdepth")
+            for name, fn, want in suite:
+                if mode == "logdepth" and name == "replace":
+                    continue        # replace has no log-depth form (DESIGN.md 5.5)
+                t0 = time.time()
+                got = fn()
+                print(f"config5 g=2 {mode:9s} {name:8s} {time.time() - t0:7.2f} s")
+                assert got == want, (mode, name)
+        sk.set_logdepth(False)
+        assert ck.decrypt_bool(A.contains(sk, api.FheString.new(ck, "\x7f\x7f\x7f"))) is False
+    finally:
+        sk.close()
+
+
+@pytest.mark.gpu
+def test_config5_multibit3_find_rfind_and_cli_shaped_padded_pattern(libs):
+    """g = 3 find / rfind at 512, and the CLI's own shape: examples/cmd/main.rs:58-66 pads the PATTERN
+    with the same --pad as the input (513-slot pattern: 131 840 char pairs in find_all)"""
+    text, pat = config5_inputs()
+    ck, sk = api.generate_keys_with_params(api.multibit_params(3), 1023, seed=0xF4E50005)
+    try:
         A, P = api.FheString.new(ck, text, 512), api.FheString.new(ck, pat)
         assert A.find(sk, P).decrypt(ck) == text.find(pat)
         assert A.rfind(sk, P).decrypt(ck) == text.rfind(pat)
-        assert ck.decrypt_bool(A.contains(sk, api.FheString.new(ck, "\x7f\x7f\x7f"))) is False
+    finally:
+        sk.close()
+    ck, sk = api.generate_keys_with_params(api.default_params(), 1023, seed=0xF4E50005)
+    try:
+        A, Ppad = api.FheString.new(ck, text, 512), api.FheString.new(ck, pat, 512)
+        assert A.find(sk, Ppad).decrypt(ck) == text.find(pat)
+        sk.set_logdepth(True)
+        assert A.find(sk, Ppad).decrypt(ck) == text.find(pat)
+    finally:
+        sk.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["classic", "multibit2"])
+def test_chained_operations_start_from_clean_blocks(which, libs):
+    """results of one operation feed the next.  substr_from / trim build every output
+    block from up to (slots) bootstrapped one-hot terms; the boundary hands them over clean, so the
+    comparison / search that follows sees the operand noise it is sized for."""
+    params = api.default_params() if which == "classic" else api.multibit_params(2)
+    ck, sk = api.generate_keys_with_params(params, 255, seed=0xF4E50007)
+    try:
+        s = "  the needle is here, in a longer haystack of text  "
+        A = api.FheString.new(ck, s, 60)
+        tail = A.substr_from(sk, api.FheUsize.new(ck, 6))                       # 61 one-hot terms per block
+        assert tail.decrypt(ck) == s[6:]
+        assert ck.decrypt_bool(tail.eq(sk, api.FheString.new(ck, s[6:]))) is True
+        assert ck.decrypt_bool(tail.eq(sk, api.FheString.new(ck, s[6:-1] + "!"))) is False
+        assert tail.find(sk, api.FheString.new(ck, "needle")).decrypt(ck) == s[6:].find("needle")
+        assert tail.substr_to(sk, api.FheUsize.new(ck, 10)).decrypt(ck) == s[6:16]
+        t = A.trim(sk)
+        assert t.decrypt(ck) == s.strip()
+        assert ck.decrypt_bool(t.starts_with(sk, api.FheString.new(ck, "the"))) is True
+        assert t.trim(sk).len(sk).decrypt(ck) == len(s.strip())                # three operations deep
+        deg, noi = t.block_meta()
+        assert max(deg) <= 3 and max(noi) <= 1
     finally:
         sk.close()

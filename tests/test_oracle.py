@@ -161,3 +161,72 @@ def test_batched_oracle_run_equals_single_runs(libs):
         assert np.array_equal(single, out)
         got = decode_result("find", ww.decrypt(out), bu)
         assert (-1 if got is None else got) == t.find(q)
+
+
+# ---- the oracle with its OWN client side: no product key generation / encryption / decryption -----
+_TABLES = json.load(open(os.path.join(HERE, "golden", "reference_tables.json")))
+
+
+@pytest.fixture(scope="module")
+def ow(libs):
+    from tests.helpers import OracleWorld
+    return OracleWorld("toy")
+
+
+def _run_case_on(world_obj, op, args, bu):
+    from fhe_string_amd import _lib
+    from tests.progs import build_inputs, decode_generic
+    shape, digits = build_inputs(_lib.load(), op, args, bu)
+    p = Prog(world_obj.p, op, shape, bu)
+    cts = world_obj.encrypt(digits) if len(digits) else np.zeros((0, world_obj.W), dtype=np.uint64)
+    outs, _ = p.run_oracle(world_obj, cts, threads=os.cpu_count() or 4)
+    self_str = args[0]["s"] if "s" in args[0] else None
+    return decode_generic(op, world_obj.decrypt(outs), p.out_parts, bu, self_str)
+
+
+def _as_args(case):
+    if "args" in case:
+        return case["args"]
+    a = [{"s": case["a"], "pad": case["a_pad"]}]
+    if case["b"] is not None:
+        a.append({"s": case["b"], "pad": case["b_pad"]})
+    return a
+
+
+ALL_CASES = _TABLES["cases"] + _TABLES["cases_ext"]
+
+
+@pytest.mark.parametrize("case", ALL_CASES, ids=lambda c: f"{c['op']}-{str(_as_args(c)[0].get('s'))!r}-{len(_as_args(c))}")
+def test_every_reference_table_case_on_the_oracle_with_its_own_client(case, ow):
+    """all 168 cases of the reference's test tables through real encryption on the oracle, keys /
+    encryption / decoding by the oracle's own client code (toy parameters)"""
+    got = _run_case_on(ow, case["op"], _as_args(case), num_blocks_usize(255))
+    got = list(got) if isinstance(got, tuple) else got
+    assert got == case["expect"], case
+
+
+def test_product_and_oracle_clients_agree_on_the_encoding(w, ow):
+    """a block encrypted by the product's client decodes with the oracle's decoder (same Delta, same
+    padding-bit convention), for every value incl. the padding bit"""
+    vals = np.arange(32, dtype=np.uint8)
+    cts = w.encrypt(vals)
+    sk = np.ascontiguousarray(np.ctypeslib.as_array(C.cast(w.lib.fhes_client_key_big_sk(w.ck), C.POINTER(C.c_uint64)), (w.W - 1,)))
+    out = np.zeros(32, dtype=np.uint8)
+    w.orc.oracle_decrypt_blocks(C.addressof(w.p), ptr(sk), ptr(cts), 32, ptr(out))
+    assert list(out) == list(range(32))
+    assert list(ow.decrypt(ow.encrypt(vals))) == list(range(32))
+    assert list(w.decrypt(cts)) == list(range(32))
+
+
+REAL = [c for c in _TABLES["cases"] if c["op"] in ("eq", "contains", "starts_with", "is_empty", "lt", "find", "len")
+        and len(c["a"]) <= 8 and (c["a_pad"] or 0) <= 8][:12]
+
+
+def test_a_dozen_table_cases_at_the_real_parameter_set(libs):
+    """PARAM_MESSAGE_2_CARRY_2_KS_PBS on the oracle with the oracle's own keys (README example among them)"""
+    from tests.helpers import OracleWorld
+    real = OracleWorld("default", seed=0xF4E5)
+    bu = num_blocks_usize(255)
+    assert len(REAL) == 12
+    for case in REAL:
+        assert _run_case_on(real, case["op"], _as_args(case), bu) == case["expect"], case
