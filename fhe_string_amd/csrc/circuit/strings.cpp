@@ -5,6 +5,9 @@
 #include "strings.h"
 
 #include <algorithm>
+#include <array>
+#include <functional>
+#include <map>
 #include <stdexcept>
 
 namespace fhes {
@@ -423,8 +426,74 @@ struct S {
     for (size_t i = 0; i < a.size(); i++) v.push_back(if_then_else_zero(o.scalar_cmp(index, i, Cmp::GT), a[i]));
     return v;
   }
+  // mod.rs:183-195 in its opt-in form: v[i] = char_at(self, index + i) with index + i taken modulo
+  // T = msg_mod^Bu (scalar_add_parallelized wraps) and positions >= slots reading as 0 -- a left ROTATION
+  // by `index` of the string zero-extended to T positions.  The reference gathers every output char
+  // from all slots (slots^2 selections); a base-4 barrel shifter computes the same chars with one
+  // 4-way selection per position and digit of `index`: Bu stages of <= T * Bc * 4 lookups.
+  Str rotate_left_logdepth(const Str &a, const Radix &index, size_t T) {
+    Builder &b = o.b;
+    const size_t slots = a.size();
+    std::vector<std::map<size_t, Radix>> memo(index.size() + 1);
+    // [d == v] for trivial operands (a constant char selected by an encrypted digit)
+    std::vector<std::array<Blk, 4>> is_v(index.size());
+    std::vector<char> have_is(index.size(), 0);
+    std::function<Radix(int, size_t)> value = [&](int st, size_t i) -> Radix {
+      if (st == 0) return i < slots ? a[i] : term_char();
+      auto it = memo[st].find(i);
+      if (it != memo[st].end()) return it->second;
+      const int k = st - 1;  // digit of this stage
+      size_t stride = 1;
+      for (int t = 0; t < k; t++) stride *= (size_t)o.M;
+      const Blk &d = index[k];
+      Radix out((size_t)Bc, b.trivial(0));
+      if (d.trivial()) {
+        out = value(st - 1, (i + (size_t)d.cst * stride) % T);
+      } else {
+        for (int v = 0; v < o.M; v++) {
+          const Radix src = value(st - 1, (i + (size_t)v * stride) % T);
+          for (int q = 0; q < Bc; q++) {
+            const Blk &x = src[q];
+            if (x.trivial() && x.cst == 0) continue;
+            Blk term;
+            const uint64_t vv = (uint64_t)v;
+            if (x.trivial()) {
+              if (!have_is[k]) {
+                for (int u = 0; u < o.M; u++) {
+                  const uint64_t uu = (uint64_t)u;
+                  is_v[k][u] = b.pbs(b.tame(d, 1), [uu](uint64_t dv) { return dv == uu ? 1 : 0; });
+                }
+                have_is[k] = 1;
+              }
+              term = b.scale(is_v[k][v], x.cst);
+            } else {
+              term = b.bivar(d, x, b.params().message_bits, [vv](uint64_t dv, uint64_t xv) { return dv == vv ? xv : 0; });
+            }
+            Blk acc = b.add(out[q], term);
+            acc.deg = std::max(out[q].deg, term.deg);  // the four terms are mutually exclusive
+            out[q] = acc;
+          }
+        }
+      }
+      memo[st][i] = out;
+      return out;
+    };
+    Str v;
+    for (size_t i = 0; i < slots; i++) v.push_back(value((int)index.size(), i));
+    return v;
+  }
+
   // mod.rs:183-195
   Str substr_from(const Str &a, const Radix &index) {
+    if (fast) {
+      size_t T = 1;
+      bool small = true;
+      for (size_t t = 0; t < index.size(); t++) {
+        T *= (size_t)o.M;
+        if (T > 8192) { small = false; break; }
+      }
+      if (small && T >= a.size()) return rotate_left_logdepth(a, index, T);
+    }
     Str v;
     for (size_t i = 0; i < a.size(); i++) v.push_back(char_at(a, o.scalar_add(index, i)));
     return v;

@@ -281,7 +281,7 @@ def test_remaining_public_methods(libs):
 # ---- opt-in log-depth circuits ("<op>_logdepth"): same results as the faithful circuits --------
 LOGDEPTH_OPS = {"find", "rfind", "lt", "le", "gt", "ge", "split", "rsplit", "split_inclusive", "split_terminator",
                 "rsplit_terminator", "splitn", "rsplitn", "split_once", "rsplit_once", "trim", "trim_start", "trim_end",
-                "strip_suffix", "split_ascii_whitespace"}
+                "strip_prefix", "strip_suffix", "split_ascii_whitespace", "substr_from", "substr_end"}
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["op"] in LOGDEPTH_OPS],
@@ -330,6 +330,23 @@ def test_logdepth_equals_faithful_on_random_inputs(libs):
         w = "".join(rnd.choice("a b\t") for _ in range(rnd.randint(0, 7)))
         for op in ("trim", "trim_start", "trim_end", "split_ascii_whitespace"):
             assert run_ext(op + "_logdepth", [S(w)])[0] == run_ext(op, [S(w)])[0], (op, w)
+    # the barrel shifter behind substr_from (rotation modulo 4^Bu, zero-extended): every index incl. the
+    # ones whose index + i wraps, every output block
+    bu = num_blocks_usize(255)
+    from fhe_string_amd import _lib
+    from tests.progs import build_inputs
+    for trial in range(40):
+        la = rnd.randint(0, 9)
+        a = "".join(rnd.choice("abc xy") for _ in range(la))
+        pad = rnd.choice([None, la + rnd.randint(0, 3)])
+        i, j = rnd.choice([rnd.randint(0, 12), rnd.randint(0, 255), 255, 250]), rnd.randint(0, 14)
+        for op, args in (("substr_from", [S(a, pad), {"u": i}]), ("substr_end", [S(a, pad), {"u": i % 13}, {"u": j}]),
+                         ("strip_prefix", [S(a, pad), S(a[:rnd.randint(0, 2)])]), ("split_once", [S(a, pad), S(rnd.choice(["a", "c ", "x"]))]),
+                         ("rsplit_once", [S(a, pad), S(rnd.choice(["a", "c ", "x"]))]), ("strip_suffix", [S(a, pad), S(a[la - rnd.randint(0, 2):] if la else "")])):
+            shape, digits = build_inputs(_lib.load(), op, args, bu)
+            ref = prog(op, shape, bu).run_plain(digits.astype("int64"))
+            fast = prog(op + "_logdepth", shape, bu).run_plain(digits.astype("int64"))
+            assert [int(v) % 4 for v in ref] == [int(v) % 4 for v in fast], (op, a, pad, i, j)
 
 
 def test_logdepth_depth_and_size(libs):
@@ -338,6 +355,8 @@ def test_logdepth_depth_and_size(libs):
     for op, shape in (("split", [129, 4]), ("lt", [65, 65]), ("rfind", [129, 4])):
         ref, fast = prog(op, shape, bu), prog(op + "_logdepth", shape, bu)
         assert fast.n_levels * 4 < ref.n_levels, (op, fast.n_levels, ref.n_levels)
+    ref, fast = prog("trim", [129], bu), prog("trim_logdepth", [129], bu)     # barrel shifter instead of slots^2 selections
+    assert fast.n_pbs * 4 < ref.n_pbs and fast.n_levels * 2 < ref.n_levels, (fast.n_pbs, ref.n_pbs)
 
 
 def test_results_cross_the_program_boundary_clean(libs):
