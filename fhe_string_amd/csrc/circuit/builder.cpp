@@ -7,8 +7,25 @@
 namespace fhes {
 namespace circ {
 
+// Noise cap of a lookup input in units of one bootstrap output.  The variance of a
+// bootstrap output is dominated by the rounding of the one-level decomposition, 2^(2(63-B))/3 per
+// coefficient times (1 + kN/2) per CMUX times n CMUX -- 2^49 for B = 23, n = 742, which is what the oracle
+// measures -- so the cap scales with 4^(B-23) from the values fixed for the 2^23 sets (256 classic, 34
+// multi-bit).  A set whose cap cannot even hold the packed comparison of four fresh blocks (34 units) has
+// no room to combine bootstrapped blocks at all: its circuits are refused (Level 0 still serves it).
+static double noise_cap_of(const fhes_params &p) {
+  double cap = p.grouping_factor > 1 ? 34.0 : 256.0;
+  for (int b = p.pbs_base_log; b < 23; b++) cap /= 4.0;
+  return cap;
+}
+
 Builder::Builder(const fhes_params &p, int32_t n_inputs)
-    : p_(p), n_inputs_(n_inputs), noise_cap_(p.grouping_factor > 1 ? 34.0 : 256.0) {}
+    : p_(p), n_inputs_(n_inputs), noise_cap_(noise_cap_of(p)) {
+  if (noise_cap_ < 34.0)
+    throw std::invalid_argument("this parameter set's bootstrap noise (one decomposition level of base 2^" + std::to_string(p.pbs_base_log) +
+                                ") leaves no room to combine bootstrapped blocks before the next lookup: the compiled circuits "
+                                "(Level 1 / Level 2) need pbs_base_log >= 23; fhes_pbs_batch (Level 0) still runs it");
+}
 
 Blk Builder::input(int32_t i, uint32_t deg) const {
   if (i < 0 || i >= n_inputs_) throw std::logic_error("input index out of range");

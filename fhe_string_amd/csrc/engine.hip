@@ -51,7 +51,9 @@ void host_fft_tables(int N, std::vector<double> &twist, std::vector<double> &tw)
 static bool kernels_support(const fhes_params &p, std::string *why) {
   if (p.glwe_dim != 1) { *why = "HIP kernels support glwe_dim == 1 only"; return false; }
   if (p.pbs_level != 1) { *why = "HIP kernels support pbs_level == 1 only"; return false; }
-  if (p.pbs_base_log != 23) { *why = "HIP kernels are instantiated for pbs_base_log == 23"; return false; }
+  // one decomposition level; the base is a template parameter of the blind-rotate kernels: 2^23 (the
+  // parameter sets of this engine) and 2^18 (the value recalled for tfhe-rs's multi-bit sets)
+  if (p.pbs_base_log != 23 && p.pbs_base_log != 18) { *why = "HIP kernels are instantiated for pbs_base_log 23 and 18"; return false; }
   if (p.poly_size != 2048 && p.poly_size != 256) { *why = "HIP kernels are instantiated for poly_size 2048 (and 256 for tests)"; return false; }
   if (p.ks_level > dev::KS_MAXLV || p.ks_base_log > 7) { *why = "keyswitch decomposition too large"; return false; }
   // keyswitch_kernel keeps the rounded prefix of a mask coefficient in 32 bits
@@ -281,14 +283,15 @@ static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d, unsigned long lon
   return FHES_OK;
 }
 
-template <int LOGN, int G, bool PIPE, bool LAT = false>
+template <int LOGN, int G, bool PIPE, bool LAT = false, int BL = 23>
 static int launch_br_mb(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_mb<LOGN, G, PIPE, LAT, 18>(ctx, d);
   constexpr int N = 1 << LOGN, M = N / 2;
   const int n_deg = (ctx->dims.n / G) * ((1 << G) - 1);
   constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
   const size_t lds = (size_t)2 * SLOTS * 16 + (size_t)M * 16 + (size_t)((n_deg + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_mb_kernel<LOGN, 23, G, PIPE, LAT>;
-  const unsigned bit = 8 + 4 * (G - 2) + (PIPE ? 1 : 0) + (LAT ? 2 : 0);
+  auto kern = dev::blind_rotate_mb_kernel<LOGN, BL, G, PIPE, LAT>;
+  const unsigned bit = 8 + 4 * (G - 2) + (PIPE ? 1 : 0) + (LAT ? 2 : 0);  // per context: one base per parameter set
   if (!(ctx->attr_done & (1u << bit))) {
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -319,12 +322,13 @@ static int launch_br_v4(fhes_ctx *ctx, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
-template <int LOGN, int PRIO = 0>
+template <int LOGN, int PRIO = 0, int BL = 23>
 static int launch_br_v5(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_v5<LOGN, PRIO, 18>(ctx, d);
   constexpr int N = 1 << LOGN, M = N / 2;
   constexpr int SLOTS = M;
   const size_t lds = (size_t)2 * N * 8 + (size_t)2 * SLOTS * 16 + (size_t)(M / 2) * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_v5_kernel<LOGN, 23, PRIO>;
+  auto kern = dev::blind_rotate_v5_kernel<LOGN, BL, PRIO>;
   if (!(ctx->attr_done & (1u << (20 + PRIO)))) {
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -351,6 +355,8 @@ static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
     return lat ? launch_br_mb<8, 2, true, true>(ctx, d) : launch_br_mb<8, 2, false>(ctx, d);
   }
   int variant = ctx->br_variant;
+  if (ctx->dims.pbs_base_log != 23 && variant != 0 && (variant < 5 || variant > 7))
+    return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variants 1-4 are instantiated for pbs_base_log 23 only");
   // auto: variant 5 for every launch size (measured round 2: 3.26 ms for <= 256 ciphertexts against
   // 3.39 ms of the register-resident latency build, 120 k against 114.6 k PBS/s of variant 4 in wide launches)
   if (variant == 0) variant = 5;

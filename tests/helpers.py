@@ -20,10 +20,14 @@ class World:
         self.lib = _lib.load(strict=False)
         self.orc = oracle_lib.load()
         self.p = Params()
+        b18 = which.endswith("_b18")                     # same set with the one-level decomposition base 2^18
+        which = which[:-4] if b18 else which
         if which[-1] in "23" and "multibit" in which:   # "multibit2", "toy_multibit3", ...
             check(getattr(self.lib, "fhes_params_" + which[:-1])(C.byref(self.p), int(which[-1])))
         else:
             check(getattr(self.lib, "fhes_params_" + which)(C.byref(self.p)))
+        if b18:
+            self.p.pbs_base_log = 18
         self.W = self.p.ct_words()
         self.N = self.p.poly_size
         self.n = self.p.lwe_dim

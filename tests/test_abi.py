@@ -85,6 +85,12 @@ def test_compile_rejects_bad_requests(libs):
     lib, _ = libs
     p = Params()
     lib.fhes_params_default(C.byref(p))
+    q = Params()
+    lib.fhes_params_multibit(C.byref(q), 2)
+    q.pbs_base_log = 18        # Level 0 runs it; its bootstrap noise leaves no room for the compiled circuits
+    sh2 = np.array([3, 2], dtype=np.int32)
+    assert not lib.fhes_program_compile(C.byref(q), b"find", sh2.ctypes.data_as(C.c_void_p), 2, 4)
+    assert b"pbs_base_log >= 23" in lib.fhes_last_error()
     sh = np.array([3, 2], dtype=np.int32)
     assert not lib.fhes_program_compile(C.byref(p), b"no_such_op", sh.ctypes.data_as(C.c_void_p), 2, 4)
     assert b"unknown operation" in lib.fhes_last_error()
@@ -147,3 +153,22 @@ def test_scratch_cells_are_reused(libs):
         widest = max(int(pr.level_ptr[i + 1] - pr.level_ptr[i]) for i in range(pr.n_levels))
         assert cells >= widest
     assert lib.fhes_program_scratch_cells(Prog(p, "find", [65, 5], 4).h) < 1000   # 1665 nodes
+
+
+def test_integration_doc_matches_the_header(libs):
+    """INTEGRATION.md's `FhesParams` (the Rust binding a maintainer copies) is the header's fhes_params,
+    field for field -- a stale doc here silently shifts every field after the gap -- and every extern
+    function the doc declares exists in the header; the ctypes mirror has the same fields too."""
+    header = open(os.path.join(ROOT, "include", "fhe_string_amd.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    body = re.search(r"typedef struct fhes_params \{(.*?)\} fhes_params;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = [(m.group(2), {"int32_t": "i32", "double": "f64"}[m.group(1)]) for m in re.finditer(r"(int32_t|double)\s+(\w+)\s*;", body)]
+    rust = re.search(r"pub struct FhesParams \{(.*?)\}", doc, flags=re.S).group(1)
+    r_fields = [(m.group(1), m.group(2)) for m in re.finditer(r"pub (\w+): (\w+)", rust)]
+    assert c_fields == r_fields and len(c_fields) == 12
+    assert [n for n, _ in c_fields] == [n for n, _ in Params._fields_]
+    assert C.sizeof(Params) == 56 and "sizeof = 56" in header.replace("(sizeof = 56)", "sizeof = 56")
+    declared = set(declared_symbols())
+    for fn in re.findall(r"pub fn (fhes_\w+)\(", doc):
+        assert fn in declared, f"INTEGRATION.md declares {fn}, the header does not"

@@ -10,7 +10,9 @@ from tests.helpers import ptr, world
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["toy", "default", "toy_multibit2", "toy_multibit3", "multibit2", "multibit3"])
+# "*_b18": pbs_base_log 18 (the decomposition recalled for tfhe-rs's multi-bit sets): Level 0 serves it
+@pytest.fixture(scope="module", params=["toy", "default", "toy_multibit2", "toy_multibit3", "multibit2", "multibit3",
+                                        "default_b18", "multibit2_b18", "toy_multibit3_b18"])
 def w(request, libs):
     return world(request.param)
 
