@@ -274,14 +274,21 @@ struct S {
   // W <= 7: an equality lookup and a boolean-gated lookup.
   std::vector<Blk> suppress_overlaps_logdepth(const std::vector<Blk> &m, const Radix &s_len, size_t W) {
     Builder &b = o.b;
-    const size_t n = m.size();
-    if (n == 0) return {};
+    if (m.empty()) return {};
     if (W == 0) return m;  // len(s) <= 1: nothing is ever covered
-    const int K = (int)W + 1;  // number of states
     // lm1 = max(len(s) - 1, 0) as ONE block (len(s) <= W + 1 <= 8 lives in the two low blocks)
     Blk lo2 = s_len.size() > 1 ? b.add(b.tame(s_len[0], 1), b.scale(b.tame(s_len[1], o.M), o.M)) : b.tame(s_len[0], 1);
     Blk lm1 = b.pbs(lo2, [](uint64_t v) { return v > 0 ? v - 1 : 0; });
     lm1.deg = (uint32_t)W;
+    return overlap_automaton(m, lm1, W).first;
+  }
+
+  // The automaton itself: `cover` (one block, <= W) = positions covered after an accepted match.
+  // Returns (accepted[i], state BEFORE position i) -- state 0 = free, k > 0 = k more covered positions.
+  std::pair<std::vector<Blk>, std::vector<Blk>> overlap_automaton(const std::vector<Blk> &m, const Blk &lm1, size_t W) {
+    Builder &b = o.b;
+    const size_t n = m.size();
+    const int K = (int)W + 1;  // number of states
     const int vbits = W <= 3 ? 2 : 3;  // bits of a state value
     // gate(c, x) = c ? x : 0 for a boolean c and a state value x
     auto gate = [&](const Blk &c, const Blk &x) -> Blk {
@@ -352,11 +359,13 @@ struct S {
             fn[i] = comp;
           }
         }
-    std::vector<Blk> out(n);
+    std::vector<Blk> out(n), before(n);
     out[0] = m[0];
+    before[0] = b.trivial(0);
     for (size_t i = 1; i < n; i++) {
       // out_i = m_i & [state before i == 0]
       const Blk &c = val[i - 1];
+      before[i] = c;
       if (c.trivial()) { out[i] = c.cst == 0 ? m[i] : b.trivial(0); continue; }
       if (m[i].trivial()) {
         out[i] = m[i].cst ? b.pbs(b.tame(c, 1), [](uint64_t x) { return x == 0 ? 1 : 0; }) : b.trivial(0);
@@ -364,7 +373,7 @@ struct S {
       }
       out[i] = b.bivar(c, m[i], 1, [](uint64_t x, uint64_t y) { return (x == 0 && y) ? 1 : 0; });
     }
-    return out;
+    return {out, before};
   }
 
   // search.rs:114-152 (iterates `matches` front to back, exactly as the code does)
@@ -431,28 +440,35 @@ struct S {
   // by `index` of the string zero-extended to T positions.  The reference gathers every output char
   // from all slots (slots^2 selections); a base-4 barrel shifter computes the same chars with one
   // 4-way selection per position and digit of `index`: Bu stages of <= T * Bc * 4 lookups.
-  Str rotate_left_logdepth(const Str &a, const Radix &index, size_t T) {
+  Str rotate_left_logdepth(const Str &a, const Radix &index, size_t T) { return rotate_logdepth(a, index, T, false, a.size()); }
+
+  // out[i] = a[(i + index) mod T] (left) or a[(i - index) mod T] (right), a zero-extended to T positions,
+  // for i < n_out; elements are radixes of any width (chars, booleans)
+  std::vector<Radix> rotate_logdepth(const std::vector<Radix> &a, const Radix &index, size_t T, bool right, size_t n_out) {
     Builder &b = o.b;
     const size_t slots = a.size();
+    const size_t width = a.empty() ? 1 : a[0].size();
+    const Radix zero(width, b.trivial(0));
     std::vector<std::map<size_t, Radix>> memo(index.size() + 1);
     // [d == v] for trivial operands (a constant char selected by an encrypted digit)
     std::vector<std::array<Blk, 4>> is_v(index.size());
     std::vector<char> have_is(index.size(), 0);
     std::function<Radix(int, size_t)> value = [&](int st, size_t i) -> Radix {
-      if (st == 0) return i < slots ? a[i] : term_char();
+      if (st == 0) return i < slots ? a[i] : zero;
       auto it = memo[st].find(i);
       if (it != memo[st].end()) return it->second;
       const int k = st - 1;  // digit of this stage
       size_t stride = 1;
       for (int t = 0; t < k; t++) stride *= (size_t)o.M;
       const Blk &d = index[k];
-      Radix out((size_t)Bc, b.trivial(0));
+      Radix out(width, b.trivial(0));
+      auto from = [&](size_t v) { return right ? (i + T - (v * stride) % T) % T : (i + v * stride) % T; };
       if (d.trivial()) {
-        out = value(st - 1, (i + (size_t)d.cst * stride) % T);
+        out = value(st - 1, from((size_t)d.cst));
       } else {
         for (int v = 0; v < o.M; v++) {
-          const Radix src = value(st - 1, (i + (size_t)v * stride) % T);
-          for (int q = 0; q < Bc; q++) {
+          const Radix src = value(st - 1, from((size_t)v));
+          for (size_t q = 0; q < width; q++) {
             const Blk &x = src[q];
             if (x.trivial() && x.cst == 0) continue;
             Blk term;
@@ -478,22 +494,23 @@ struct S {
       memo[st][i] = out;
       return out;
     };
-    Str v;
-    for (size_t i = 0; i < slots; i++) v.push_back(value((int)index.size(), i));
+    std::vector<Radix> v;
+    for (size_t i = 0; i < n_out; i++) v.push_back(value((int)index.size(), i));
     return v;
+  }
+  // msg_mod^Bu when it is small enough for the shifter networks, else 0
+  size_t usize_modulus() const {
+    size_t T = 1;
+    for (int t = 0; t < Bu; t++) {
+      T *= (size_t)o.M;
+      if (T > 8192) return 0;
+    }
+    return T;
   }
 
   // mod.rs:183-195
   Str substr_from(const Str &a, const Radix &index) {
-    if (fast) {
-      size_t T = 1;
-      bool small = true;
-      for (size_t t = 0; t < index.size(); t++) {
-        T *= (size_t)o.M;
-        if (T > 8192) { small = false; break; }
-      }
-      if (small && T >= a.size()) return rotate_left_logdepth(a, index, T);
-    }
+    if (fast && (int)index.size() == Bu && usize_modulus() >= a.size()) return rotate_left_logdepth(a, index, usize_modulus());
     Str v;
     for (size_t i = 0; i < a.size(); i++) v.push_back(char_at(a, o.scalar_add(index, i)));
     return v;
@@ -557,9 +574,239 @@ struct S {
     return v;
   }
 
+  // ---- replace.rs:37-104, opt-in parallel form -------------------------------------------------------
+  // The reference's loop walks the OUTPUT index i with the state (in_match, j, n) and reads the input at
+  // c = i + n * (len(p) - len(s)).  Read along the INPUT instead, it is a transducer: at a position c
+  // reached in the free state, an occurrence of p (found[c]) emits max(len(s), 1) symbols -- s, or ONE zero
+  // when s is empty (the loop spends a step on s's terminator, replace.rs:91-94) -- and moves the pointer
+  // to c + len(p) + [len(s) == 0]; anything else emits self[c] and moves it by one.  So:
+  //   1. which positions are accepted / copied / skipped is the finite automaton of find_all_non_overlapping
+  //      with cover = len(p) + [len(s) == 0] - 1 positions after a match (prefix scan, overlap_automaton);
+  //   2. every position c owns K = max(max_len(s), 1) slots of a virtual array V[c*K + j]: slot 0 holds s[0]
+  //      (accepted) or self[c] (copied), slot j >= 1 holds s[j] when accepted and j < len(s); everything
+  //      else is empty;
+  //   3. the output is V with the empty slots squeezed out: slot E moves left by offset(c) = sum over c' < c
+  //      of (K - emitted(c')), a non-decreasing function -- an order-preserving compaction, which a
+  //      butterfly network routes without collisions when the offset digits are consumed least significant
+  //      first (base 4: Bu stages of one 4-way selection per slot and payload block).
+  // Preconditions that only public sizes decide (else the faithful loop is used): no n_max, max_len(p) <= 7
+  // (automaton states in one block), max_len(s) <= 4, and l + slots(self) <= msg_mod^Bu so that the
+  // reference's own pointer arithmetic never wraps.  The one case the automaton cannot express -- an EMPTY
+  // pattern with a non-empty replacement, where the loop never advances and emits s forever -- is computed
+  // separately (s[i mod len(s)]) and selected by the encrypted flag [len(p) == 0 & len(s) > 0].
+  // redundant radix arithmetic for the prefix sums: blocks may carry up to 15 before they are normalised
+  Radix lazy_add(const Radix &x, const Radix &y) {
+    Builder &b = o.b;
+    Radix xn = x, yn = y;
+    bool need = false;
+    for (size_t k = 0; k < x.size(); k++)
+      if (x[k].deg + y[k].deg >= (uint32_t)b.space() || x[k].noise + y[k].noise > b.noise_cap() / 4) need = true;
+    if (need) { xn = normalize(x); yn = normalize(y); }
+    Radix r;
+    for (size_t k = 0; k < x.size(); k++) r.push_back(b.add(xn[k], yn[k]));
+    return r;
+  }
+  Radix normalize(const Radix &x) {  // carry propagation to clean digits (ripple; carries are < msg_mod)
+    Builder &b = o.b;
+    const uint64_t m = (uint64_t)o.M;
+    Radix out;
+    Blk carry = b.trivial(0);
+    for (size_t k = 0; k < x.size(); k++) {
+      Blk t = b.add(x[k], carry);
+      if (t.trivial()) { out.push_back(b.trivial((uint64_t)t.cst % m)); carry = b.trivial((uint64_t)t.cst / m); continue; }
+      if (t.deg < (uint32_t)o.M && t.noise <= 1.0) { out.push_back(t); carry = b.trivial(0); continue; }
+      out.push_back(b.pbs(t, [m](uint64_t v) { return v % m; }));
+      carry = (k + 1 < x.size() && t.deg >= (uint32_t)o.M) ? b.pbs(t, [m](uint64_t v) { return v / m; }) : b.trivial(0);
+    }
+    return out;
+  }
+
+  bool replace_fast_applies(const Str &a, const Str &p, const Str &sub, const Radix *n_max, size_t l) const {
+    const size_t T = usize_modulus();
+    return fast && !n_max && max_len(p) <= 7 && max_len(sub) <= 4 && T != 0 && l + a.size() <= T && l >= 1;
+  }
+
+  Str replace_logdepth(const Str &a, const Str &p, const Str &sub, size_t l) {
+    Builder &b = o.b;
+    const size_t slots = a.size(), n_pos = slots - 1, Pmax = max_len(p), Smax = max_len(sub);
+    const size_t K = std::max<size_t>(Smax, 1), T = usize_modulus();
+    const uint64_t m = (uint64_t)o.M;
+    std::vector<Blk> found = find_all(a, p);
+    Radix p_len = len(p), s_len = len(sub);
+    Blk s_zero = o.scalar_eq(s_len, 0), p_zero = o.scalar_eq(p_len, 0);
+    auto low_value = [&](const Radix &r, uint32_t bound) {  // a length <= bound <= 7 as ONE block
+      Blk v = r.size() > 1 ? b.add(b.tame(r[0], 1), b.scale(b.tame(r[1], o.M), o.M)) : b.tame(r[0], 1);
+      v.deg = std::min<uint32_t>(v.deg, bound);
+      return v;
+    };
+    // cover = max(len(p) + [len(s) == 0] - 1, 0) <= Pmax
+    Blk cover;
+    if (Pmax == 0) cover = b.trivial(0);
+    else {
+      Blk pv = low_value(p_len, (uint32_t)Pmax);
+      cover = b.bivar(pv, s_zero, 1, [](uint64_t pl, uint64_t z) { return pl + z > 0 ? pl + z - 1 : 0; });
+      cover.deg = (uint32_t)Pmax;
+    }
+    // 1. automaton over every slot of self (the last one can only be copied)
+    std::vector<Blk> mext = found;
+    mext.push_back(o.trivial_bool(false));
+    std::vector<Blk> acc(slots), copy(slots), covered(slots);
+    if (Pmax == 0) {
+      for (size_t c = 0; c < slots; c++) { acc[c] = mext[c]; copy[c] = o.bitnot_(mext[c]); covered[c] = o.trivial_bool(false); }
+    } else {
+      auto au = overlap_automaton(mext, cover, Pmax);
+      for (size_t c = 0; c < slots; c++) {
+        acc[c] = au.first[c];
+        const Blk &st = au.second[c];
+        if (st.trivial()) {
+          covered[c] = o.trivial_bool(st.cst > 0);
+          copy[c] = st.cst > 0 ? o.trivial_bool(false) : o.bitnot_(mext[c]);
+        } else {
+          covered[c] = b.pbs(b.tame(st, 1), [](uint64_t x) { return x > 0 ? 1 : 0; });
+          copy[c] = mext[c].trivial() ? (mext[c].cst ? o.trivial_bool(false) : o.bitnot_(covered[c]))
+                                      : b.bivar(st, mext[c], 1, [](uint64_t x, uint64_t y) { return (x == 0 && !y) ? 1 : 0; });
+        }
+      }
+    }
+    // 2. gap(c) = K - emitted(c): K when skipped, K - 1 when copied, K - max(len(s), 1) when accepted
+    Blk acc_gap_val = b.trivial(0);  // K - max(len(s), 1), one block
+    if (K > 1) {
+      Blk sv = low_value(s_len, (uint32_t)Smax);
+      const uint64_t KK = K;
+      acc_gap_val = b.pbs(sv, [KK](uint64_t sl) { const uint64_t e = sl > 1 ? sl : 1; return e < KK ? KK - e : 0; });
+      acc_gap_val.deg = (uint32_t)(K - 1);
+    }
+    std::vector<Radix> gap(slots);
+    for (size_t c = 0; c < slots; c++) {
+      Blk g = b.scale(covered[c], (int64_t)K);
+      Blk t2 = b.scale(copy[c], (int64_t)(K - 1));
+      Blk t3 = b.trivial(0);
+      if (K > 1 && !(acc[c].trivial() && acc[c].cst == 0))
+        t3 = acc[c].trivial() ? acc_gap_val : b.bivar(acc[c], acc_gap_val, 2, [](uint64_t ab, uint64_t gv) { return ab ? gv : 0; });
+      Blk sum = b.add(b.add(g, t2), t3);
+      sum.deg = (uint32_t)K;  // mutually exclusive terms
+      Radix r;
+      r.push_back(sum);
+      for (int k = 1; k < Bu; k++) r.push_back(b.trivial(0));
+      gap[c] = r;
+    }
+    // exclusive prefix sums (Sklansky over lazily normalised radixes)
+    std::vector<Radix> incl = gap;
+    for (size_t span = 1; span < slots; span <<= 1)
+      for (size_t i = 0; i < slots; i++)
+        if ((i / span) & 1) incl[i] = lazy_add(incl[i], incl[(i / span) * span - 1]);
+    std::vector<Radix> offset(slots);
+    offset[0] = usize(0);
+    for (size_t c = 1; c < slots; c++) offset[c] = normalize(incl[c - 1]);
+    // 3. slots of V: payload = Bc char blocks + Bu offset digits, all zero when the slot is empty
+    std::vector<Blk> j_lt_s(K);  // [j < len(s)], j >= 1
+    for (size_t j = 1; j < K; j++) j_lt_s[j] = o.scalar_cmp(s_len, j, Cmp::GT);
+    const size_t PW = (size_t)Bc + (size_t)Bu;
+    auto gate_blk = [&](const Blk &cnd, const Blk &x) -> Blk {
+      if (x.trivial()) return b.scale(cnd, x.cst);
+      if (cnd.trivial()) return cnd.cst ? x : b.trivial(0);
+      return b.bivar(cnd, x, b.params().message_bits, [](uint64_t cb, uint64_t xv) { return cb ? xv : 0; });
+    };
+    std::vector<Radix> V(slots * K, Radix(PW, b.trivial(0)));
+    for (size_t c = 0; c < slots; c++) {
+      Blk present0 = o.bitnot_(covered[c]);
+      for (size_t j = 0; j < K; j++) {
+        Radix e(PW, b.trivial(0));
+        Blk present;
+        if (j == 0) {
+          present = present0;
+          for (int q = 0; q < Bc; q++) {
+            Blk x = b.add(gate_blk(acc[c], sub[0][q]), gate_blk(copy[c], a[c][q]));
+            x.deg = (uint32_t)(o.M - 1);
+            e[q] = x;
+          }
+        } else {
+          present = o.bitand_(acc[c], j_lt_s[j]);
+          for (int q = 0; q < Bc; q++) e[q] = gate_blk(present, sub[j][q]);
+        }
+        for (int k = 0; k < Bu; k++) e[(size_t)Bc + k] = gate_blk(present, offset[c][k]);
+        V[c * K + j] = e;
+      }
+    }
+    // compaction network, least significant digit first: the element at E whose digit k is v moves to E - v*4^k
+    const size_t VT = slots * K;
+    std::vector<std::map<size_t, Radix>> memo((size_t)Bu + 1);
+    std::function<Radix(int, size_t)> value = [&](int st, size_t r) -> Radix {
+      if (r >= VT) return Radix(PW, b.trivial(0));
+      if (st == 0) return V[r];
+      auto it = memo[st].find(r);
+      if (it != memo[st].end()) return it->second;
+      const int k = st - 1;
+      size_t stride = 1;
+      for (int t = 0; t < k; t++) stride *= (size_t)o.M;
+      Radix out(PW, b.trivial(0));
+      for (int v = 0; v < o.M; v++) {
+        const size_t src_pos = r + (size_t)v * stride;
+        if (src_pos >= VT) break;
+        const Radix src = value(st - 1, src_pos);
+        const Blk &d = src[(size_t)Bc + k];
+        const uint64_t vv = (uint64_t)v;
+        if (d.trivial()) {
+          if ((uint64_t)d.cst != vv) continue;
+          for (size_t q = 0; q < PW; q++) {
+            if (q == (size_t)Bc + k) continue;
+            Blk accb = b.add(out[q], src[q]);
+            accb.deg = std::max(out[q].deg, src[q].deg);
+            out[q] = accb;
+          }
+          continue;
+        }
+        for (size_t q = 0; q < PW; q++) {
+          if (q == (size_t)Bc + k) continue;            // the consumed digit is dropped
+          if (q > (size_t)Bc + k || q < (size_t)Bc) {   // chars and the digits still to come
+            const Blk &x = src[q];
+            if (x.trivial() && x.cst == 0) continue;
+            Blk term;
+            if (x.trivial()) {
+              Blk is_v = b.pbs(b.tame(d, 1), [vv](uint64_t dv) { return dv == vv ? 1 : 0; });
+              term = b.scale(is_v, x.cst);
+            } else {
+              term = b.bivar(d, x, b.params().message_bits, [vv](uint64_t dv, uint64_t xv) { return dv == vv ? xv : 0; });
+            }
+            Blk accb = b.add(out[q], term);
+            accb.deg = std::max(out[q].deg, term.deg);  // collision-free routing: at most one source is non-zero
+            out[q] = accb;
+          }
+        }
+      }
+      memo[st][r] = out;
+      return out;
+    };
+    Str vmain;
+    for (size_t i = 0; i < l; i++) {
+      Radix e = value(Bu, i);
+      vmain.push_back(Radix(e.begin(), e.begin() + Bc));
+    }
+    // the degenerate case: empty pattern, non-empty replacement, at least one start position
+    Str v;
+    if (n_pos >= 1 && Smax >= 1) {
+      Blk dg = o.bitand_(p_zero, o.bitnot_(s_zero));
+      std::vector<Blk> s_is;
+      for (size_t d = 1; d <= Smax; d++) s_is.push_back(o.scalar_eq(s_len, d));
+      for (size_t i = 0; i < l; i++) {
+        std::vector<Radix> terms;
+        for (size_t d = 1; d <= Smax; d++) terms.push_back(o.zero_unless(s_is[d - 1], sub[i % d]));
+        Radix deg_c = sum_exclusive(terms, Bc);
+        v.push_back(o.if_then_else(dg, deg_c, vmain[i]));
+      }
+    } else {
+      v = vmain;
+    }
+    (void)m;
+    (void)T;
+    v.push_back(term_char());
+    return v;
+  }
+
   // replace.rs:37-104
   Str replace_opt(const Str &a, const Str &p, const Str &sub, const Radix *n_max, size_t l, size_t max_len_key) {
     l = std::min(l, max_len_key);
+    if (replace_fast_applies(a, p, sub, n_max, l)) return replace_logdepth(a, p, sub, l);
     std::vector<Blk> found = find_all(a, p);
     Radix p_len = len(p), s_len = len(sub);
     Radix len_diff = o.sub(p_len, s_len);
@@ -789,10 +1036,24 @@ struct S {
       next_fast.resize(n);
       for (size_t i = 0; i < n; i++) next_fast[i] = V[n - i];
     }
+    // split.rs:283-285 for all i at once: element_at_bool(matches, i - len(p)) with the subtraction modulo
+    // T = msg_mod^Bu is a right ROTATION of the zero-extended `matches` by len(p): a barrel shifter
+    // (Bu stages of n lookups) instead of n one-hot gathers over n entries
+    std::vector<Blk> shifted;
+    if (fast && usize_modulus() >= matches.size() && usize_modulus() >= n) {
+      std::vector<Radix> mm;
+      for (const Blk &x : matches) mm.push_back(Radix{x});
+      for (const Radix &r : rotate_logdepth(mm, p_len, usize_modulus(), true, n)) shifted.push_back(r[0]);
+    }
     for (size_t i = n; i-- > 0;) {
       Blk is_some;
       if (i == 0) {
         is_some = o.trivial_bool(true);
+      } else if (!shifted.empty()) {
+        Blk i_lt_n_hidden = o.scalar_cmp(n_hidden, i, Cmp::GT);
+        Blk mi = shifted[i];
+        mi.deg = 1;
+        is_some = o.bitand_(i_lt_n_hidden, mi);
       } else {
         Radix i_sub_plen = o.sub(usize(i), p_len);
         Blk mi = element_at_bool(matches, i_sub_plen);

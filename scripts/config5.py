@@ -48,7 +48,7 @@ def main():
     for m in (["faithful", "logdepth"] if mode == "both" else [mode]):
         sk.set_logdepth(m == "logdepth")
         for name, fhe, std in ops:
-            if name not in only or (m == "logdepth" and name == "replace"):
+            if name not in only:
                 continue
             sk.reset_stats()
             t0 = time.time()

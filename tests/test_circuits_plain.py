@@ -281,7 +281,7 @@ def test_remaining_public_methods(libs):
 # ---- opt-in log-depth circuits ("<op>_logdepth"): same results as the faithful circuits --------
 LOGDEPTH_OPS = {"find", "rfind", "lt", "le", "gt", "ge", "split", "rsplit", "split_inclusive", "split_terminator",
                 "rsplit_terminator", "splitn", "rsplitn", "split_once", "rsplit_once", "trim", "trim_start", "trim_end",
-                "strip_prefix", "strip_suffix", "split_ascii_whitespace", "substr_from", "substr_end"}
+                "strip_prefix", "strip_suffix", "split_ascii_whitespace", "substr_from", "substr_end", "replace", "replacen"}
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["op"] in LOGDEPTH_OPS],
@@ -381,3 +381,37 @@ def test_results_cross_the_program_boundary_clean(libs):
             assert lib.fhes_program_out_meta(p.h, deg.ctypes.data, noise.ctypes.data) == 0
             assert (noise <= 1.0).all() and (noise >= 0).all(), (op, float(noise.max()))
             assert (deg < 4).all() and (deg >= 0).all(), (op, int(deg.max()))
+
+
+def test_logdepth_replace_equals_the_references_loop(libs):
+    """replace_logdepth (automaton + compaction network) against the faithful loop of replace.rs:65-99 on
+    every output block: overlapping and padded patterns, empty pattern (the loop never advances and emits
+    the replacement forever), empty replacement (the loop spends a slot on a zero), replacement longer
+    and shorter than the pattern, outputs cut at l"""
+    import numpy as np
+    from fhe_string_amd import _lib
+    from tests.progs import build_inputs
+    rnd = random.Random(0x5EED)
+    bu = num_blocks_usize(255)
+    seen = {"empty_p": 0, "empty_s": 0, "grow": 0, "shrink": 0}
+    for trial in range(150):
+        la = rnd.randint(0, 8)
+        a = "".join(rnd.choice("xa") for _ in range(la))
+        p = "".join(rnd.choice("xa") for _ in range(rnd.randint(0, 3)))
+        r = "".join(rnd.choice("yz") for _ in range(rnd.randint(0, 3)))
+        a_pad = rnd.choice([None, la + rnd.randint(0, 3)])
+        p_pad = rnd.choice([None, len(p) + rnd.randint(0, 3)])
+        r_pad = rnd.choice([None, len(r) + rnd.randint(0, 1)])
+        l = rnd.randint(1, 14)
+        seen["empty_p"] += p == ""
+        seen["empty_s"] += r == ""
+        seen["grow"] += len(r) > len(p)
+        seen["shrink"] += len(r) < len(p)
+        args = [S(a, a_pad), S(p, p_pad), S(r, r_pad), {"i": l}]
+        shape, digits = build_inputs(_lib.load(), "replace", args, bu)
+        ref = prog("replace", shape, bu).run_plain(digits.astype("int64"))
+        fast = prog("replace_logdepth", shape, bu).run_plain(digits.astype("int64"))
+        assert [int(v) % 4 for v in ref] == [int(v) % 4 for v in fast], (a, a_pad, p, p_pad, r, r_pad, l)
+    assert min(seen.values()) > 5, seen
+    ref, fast = prog("replace", [65, 4, 2, 60], bu), prog("replace_logdepth", [65, 4, 2, 60], bu)
+    assert fast.n_levels * 10 < ref.n_levels and fast.n_pbs * 2 < ref.n_pbs, (fast.n_pbs, ref.n_pbs, fast.n_levels, ref.n_levels)

@@ -359,8 +359,8 @@ def test_config5_full_suite_512_padded_multibit2(libs):
     """BASELINE.json config 5 (examples/cmd/main.rs:127-142, 269-283, 219-238, 442-449): find / rfind /
     trim / split / replace on 500 characters padded to 512, 3-character pattern, l = 1023 => 5 usize
     blocks, multi-bit g = 2 parameters.  Faithful circuits for all five (about two minutes: split and
-    replace are thousands of dependent levels), then the opt-in log-depth forms of find / rfind / trim /
-    split, which must give the same answers.  Wall-clock per operation goes to stdout (pytest -s) and is
+    replace are thousands of dependent levels), then the opt-in log-depth forms of all five, which must
+    give the same answers.  Wall-clock per operation goes to stdout (pytest -s) and is
     recorded by scripts/config5.py under profiles/."""
     import time
     text, pat = config5_inputs()
@@ -377,8 +377,6 @@ def test_config5_full_suite_512_padded_multibit2(libs):
         for mode in ("faithful", "logdepth"):
             sk.set_logdepth(mode == "logdepth")
             for name, fn, want in suite:
-                if mode == "logdepth" and name == "replace":
-                    continue        # replace has no log-depth form
                 t0 = time.time()
                 got = fn()
                 print(f"config5 g=2 {mode:9s} {name:8s} {time.time() - t0:7.2f} s")
