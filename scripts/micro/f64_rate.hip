@@ -12,11 +12,12 @@
 #define REP8(S) S S S S S S S S
 #define REP64(S) REP8(REP8(S))
 
-enum { K_FMA64, K_ADD64, K_MUL64, K_FMA32, K_DPP, K_CVT, K_LSHLADD64, K_SUB64, K_CNDMASK, K_PERMSWAP, K_AND, K_MIX, K_CND_INDEP, K_CND_SGPR, K_XOR, K_ADDC, K_COUNT };
+enum { K_FMA64, K_ADD64, K_MUL64, K_FMA32, K_DPP, K_CVT, K_LSHLADD64, K_SUB64, K_CNDMASK, K_PERMSWAP, K_AND, K_MIX, K_CND_INDEP, K_CND_SGPR, K_XOR, K_ADDC, K_MAD64, K_MULLO, K_MAD24, K_COUNT };
 static const char *kNames[K_COUNT] = {"v_fma_f64", "v_add_f64", "v_mul_f64", "v_fma_f32", "v_mov_b32_dpp", "v_cvt_f64_i32",
                                       "v_lshl_add_u64", "v_sub_co+v_subb (pair)", "v_cndmask_b32", "v_permlane32_swap",
                                       "v_and_b32", "mix 5 fma_f64 : 3 int",
-                                      "v_cndmask_b32 vcc (independent)", "v_cndmask_b32 e64 sgpr cond", "v_xor_b32", "v_add_co+v_addc (pair)"};
+                                      "v_cndmask_b32 vcc (independent)", "v_cndmask_b32 e64 sgpr cond", "v_xor_b32", "v_add_co+v_addc (pair)",
+                                      "v_mad_u64_u32", "v_mul_lo_u32", "v_mad_u32_u24"};
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void k(unsigned long long *stamps, double *sink, int iters, double a, double b) {
@@ -43,6 +44,9 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *stamps, double *si
     if (KIND == K_CND_SGPR) { REP8(asm volatile("v_cndmask_b32 %0, %4, %5, %6\n v_cndmask_b32 %1, %5, %4, %6\n v_cndmask_b32 %2, %4, %5, %6\n v_cndmask_b32 %3, %5, %4, %6\n v_cndmask_b32 %0, %4, %5, %6\n v_cndmask_b32 %1, %5, %4, %6\n v_cndmask_b32 %2, %4, %5, %6\n v_cndmask_b32 %3, %5, %4, %6" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(j0), "v"(j1), "s"(smask));) }
     if (KIND == K_XOR) { REP8(asm volatile("v_xor_b32 %0, %1, %2\n v_xor_b32 %1, %2, %3\n v_xor_b32 %2, %3, %0\n v_xor_b32 %3, %0, %1\n v_xor_b32 %0, %1, %2\n v_xor_b32 %1, %2, %3\n v_xor_b32 %2, %3, %0\n v_xor_b32 %3, %0, %1" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
     if (KIND == K_ADDC) { REP8(asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %3, vcc\n v_add_co_u32 %2, vcc, %2, %0\n v_addc_co_u32 %3, vcc, %3, %1, vcc\n v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %3, vcc\n v_add_co_u32 %2, vcc, %2, %0\n v_addc_co_u32 %3, vcc, %3, %1, vcc" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "vcc");) }
+    if (KIND == K_MAD64) { REP8(asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %3, %4, %1\n v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %5, %2, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %3, %4, %1\n v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %5, %2, %1" : "+v"(u0), "+v"(u1) : "v"(i0), "v"(i1), "v"(i2), "v"(i3) : "vcc");) }
+    if (KIND == K_MULLO) { REP8(asm volatile("v_mul_lo_u32 %0, %1, %4\n v_mul_lo_u32 %1, %2, %4\n v_mul_lo_u32 %2, %3, %4\n v_mul_lo_u32 %3, %0, %4\n v_mul_lo_u32 %0, %1, %4\n v_mul_lo_u32 %1, %2, %4\n v_mul_lo_u32 %2, %3, %4\n v_mul_lo_u32 %3, %0, %4" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(j0));) }
+    if (KIND == K_MAD24) { REP8(asm volatile("v_mad_u32_u24 %0, %1, %4, %0\n v_mad_u32_u24 %1, %2, %4, %1\n v_mad_u32_u24 %2, %3, %4, %2\n v_mad_u32_u24 %3, %0, %4, %3\n v_mad_u32_u24 %0, %1, %4, %0\n v_mad_u32_u24 %1, %2, %4, %1\n v_mad_u32_u24 %2, %3, %4, %2\n v_mad_u32_u24 %3, %0, %4, %3" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(j0));) }
     if (KIND == K_MIX) { REP8(asm volatile("v_fma_f64 %0, %0, %12, %13\n v_and_b32 %8, %9, %10\n v_fma_f64 %1, %1, %12, %13\n v_fma_f64 %2, %2, %12, %13\n v_and_b32 %9, %10, %11\n v_fma_f64 %3, %3, %12, %13\n v_fma_f64 %4, %4, %12, %13\n v_and_b32 %10, %11, %8" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(i0), "+v"(i1), "+v"(i2) : "v"(i3), "v"(a), "v"(b));) }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -115,6 +119,9 @@ int main() {
     run<K_CND_SGPR>(d_st, d_sink, wps, n_cu);
     run<K_XOR>(d_st, d_sink, wps, n_cu);
     run<K_ADDC>(d_st, d_sink, wps, n_cu);
+    run<K_MAD64>(d_st, d_sink, wps, n_cu);
+    run<K_MULLO>(d_st, d_sink, wps, n_cu);
+    run<K_MAD24>(d_st, d_sink, wps, n_cu);
   }
   return 0;
 }
