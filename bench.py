@@ -282,71 +282,73 @@ def main():
     pcie_bytes = cts_host.nbytes + res_host.nbytes
     text, pat = pairs[0]
 
-    # ---- ONE string, start positions sharded over the ranks (fhes_sharded_search: block of
-    # positions per rank, one all-gather of found[] on arena rows over RCCL, replicated reduction).
-    # Untimed for `value`; reported as wall-clock per operation.  Inputs travel by ncclBroadcast from rank 0.
-    sharded = None
-    try:
-        from fhe_string_amd.parallel import Comm
-        free_outputs(B)
-        sync()
-        if dist and rehearsal:
-            comm = Comm.host(ctx, dist)
-        elif dist:
-            comm = Comm.rccl_from_torch(ctx, dist)
-        else:
-            comm = Comm.rccl(ctx, 0, 1, Comm.unique_id())
-        t_k = time.perf_counter()
-        comm.broadcast_keys(0)
-        sync()
-        keys_ms = (time.perf_counter() - t_k) * 1e3
+    def measure_sharded():
+        # ---- ONE string, start positions sharded over the ranks (fhes_sharded_search: block of
+        # positions per rank, one all-gather of found[] on arena rows over RCCL, replicated reduction).
+        # Untimed for `value`; reported as wall-clock per operation.  Inputs travel by ncclBroadcast from rank 0.
+        sharded = None
+        try:
+            from fhe_string_amd.parallel import Comm
+            free_outputs(B)
+            sync()
+            if dist and rehearsal:
+                comm = Comm.host(ctx, dist)
+            elif dist:
+                comm = Comm.rccl_from_torch(ctx, dist)
+            else:
+                comm = Comm.rccl(ctx, 0, 1, Comm.unique_id())
+            t_k = time.perf_counter()
+            comm.broadcast_keys(0)
+            sync()
+            keys_ms = (time.perf_counter() - t_k) * 1e3
 
-        def sharded_case(name, op, s_text, s_pad, s_pat, bu_case, reps):
-            a_blk = np.concatenate([blocks(s_text), np.zeros(((s_pad - len(s_text)) if s_pad else 0) * 4, dtype=np.uint8)])
-            p_blk = blocks(s_pat)
-            ha = check(lib.fhes_arena_alloc(ctx, len(a_blk)))
-            hb = check(lib.fhes_arena_alloc(ctx, len(p_blk)))
-            if rank == 0:
-                c_in = np.zeros((len(a_blk) + len(p_blk), W), dtype=np.uint64)
-                m_in = np.concatenate([a_blk, p_blk])
-                check(lib.fhes_client_encrypt_blocks(ck, m_in.ctypes.data, len(m_in), c_in.ctypes.data))
-                check(lib.fhes_arena_upload(ctx, ha, len(a_blk), c_in[:len(a_blk)].ctypes.data))
-                check(lib.fhes_arena_upload(ctx, hb, len(p_blk), c_in[len(a_blk):].ctypes.data))
-            comm.broadcast_cts(ha, len(a_blk), 0)
-            comm.broadcast_cts(hb, len(p_blk), 0)
-            best, val = None, None
-            for _ in range(reps):
-                barrier()
-                check(lib.fhes_reset_stats(ctx))
-                t_s = time.perf_counter()
-                hs = comm.sharded_search(op, ha, len(a_blk) // 4, hb, len(p_blk) // 4, bu_case)
-                sync()
-                d_s = time.perf_counter() - t_s
-                st_s = Stats()
-                check(lib.fhes_get_stats(ctx, C.byref(st_s)))
-                res = np.zeros((len(hs), W), dtype=np.uint64)
-                check(lib.fhes_arena_download(ctx, hs[0], len(hs), res.ctypes.data))
-                v = np.zeros(len(hs), dtype=np.uint8)
-                check(lib.fhes_client_decrypt_blocks(ck, res.ctypes.data, len(hs), v.ctypes.data))
-                check(lib.fhes_arena_free(ctx, hs[0], len(hs)))
-                val = bool(v[0] & 1) if op == "contains" else (sum(int(v[1 + k] & 3) << (2 * k) for k in range(bu_case)) if v[0] & 1 else -1)
-                if best is None or d_s < best[0]:
-                    best = (d_s, int(st_s.pbs_count))
-            check(lib.fhes_arena_free(ctx, ha, len(a_blk)))
-            check(lib.fhes_arena_free(ctx, hb, len(p_blk)))
-            want = (s_pat in s_text) if op == "contains" else s_text.find(s_pat)
-            return {"op": name, "wall_ms": round(best[0] * 1e3, 3), "pbs_this_rank": best[1], "result_ok": bool(val == want)}
+            def sharded_case(name, op, s_text, s_pad, s_pat, bu_case, reps):
+                a_blk = np.concatenate([blocks(s_text), np.zeros(((s_pad - len(s_text)) if s_pad else 0) * 4, dtype=np.uint8)])
+                p_blk = blocks(s_pat)
+                ha = check(lib.fhes_arena_alloc(ctx, len(a_blk)))
+                hb = check(lib.fhes_arena_alloc(ctx, len(p_blk)))
+                if rank == 0:
+                    c_in = np.zeros((len(a_blk) + len(p_blk), W), dtype=np.uint64)
+                    m_in = np.concatenate([a_blk, p_blk])
+                    check(lib.fhes_client_encrypt_blocks(ck, m_in.ctypes.data, len(m_in), c_in.ctypes.data))
+                    check(lib.fhes_arena_upload(ctx, ha, len(a_blk), c_in[:len(a_blk)].ctypes.data))
+                    check(lib.fhes_arena_upload(ctx, hb, len(p_blk), c_in[len(a_blk):].ctypes.data))
+                comm.broadcast_cts(ha, len(a_blk), 0)
+                comm.broadcast_cts(hb, len(p_blk), 0)
+                best, val = None, None
+                for _ in range(reps):
+                    barrier()
+                    check(lib.fhes_reset_stats(ctx))
+                    t_s = time.perf_counter()
+                    hs = comm.sharded_search(op, ha, len(a_blk) // 4, hb, len(p_blk) // 4, bu_case)
+                    sync()
+                    d_s = time.perf_counter() - t_s
+                    st_s = Stats()
+                    check(lib.fhes_get_stats(ctx, C.byref(st_s)))
+                    res = np.zeros((len(hs), W), dtype=np.uint64)
+                    check(lib.fhes_arena_download(ctx, hs[0], len(hs), res.ctypes.data))
+                    v = np.zeros(len(hs), dtype=np.uint8)
+                    check(lib.fhes_client_decrypt_blocks(ck, res.ctypes.data, len(hs), v.ctypes.data))
+                    check(lib.fhes_arena_free(ctx, hs[0], len(hs)))
+                    val = bool(v[0] & 1) if op == "contains" else (sum(int(v[1 + k] & 3) << (2 * k) for k in range(bu_case)) if v[0] & 1 else -1)
+                    if best is None or d_s < best[0]:
+                        best = (d_s, int(st_s.pbs_count))
+                check(lib.fhes_arena_free(ctx, ha, len(a_blk)))
+                check(lib.fhes_arena_free(ctx, hb, len(p_blk)))
+                want = (s_pat in s_text) if op == "contains" else s_text.find(s_pat)
+                return {"op": name, "wall_ms": round(best[0] * 1e3, 3), "pbs_this_rank": best[1], "result_ok": bool(val == want)}
 
-        rng4 = np.random.default_rng(0xF4E50004)
-        s4 = "".join(chr(c) for c in rng4.integers(0x20, 0x7F, size=1000))
-        cases = [sharded_case("config 2: find, 64-char input / 4-char pattern", "find", text, None, pat, 4, 3),
-                 sharded_case("config 4: contains, 1000 chars padded to 1024 / 8-char pattern", "contains", s4, 1024, s4[700:708], 6, 2)]
-        sharded = {"world": world_size, "transport": "host callbacks over gloo (rehearsal)" if (dist and rehearsal) else "RCCL (ncclAllGather on arena rows)",
-                   "key_broadcast_ms": round(keys_ms, 2), "cases": cases,
-                   "note": "positions of find_all sharded over the ranks through the C ABI (fhes_sharded_search); wall-clock of one operation on one string, max over repetitions' best on rank 0; the serial first-match scan of `find` is replicated, not sharded"}
-        comm.close()
-    except Exception as e:     # the headline measurement stands on its own
-        sharded = {"error": repr(e)}
+            rng4 = np.random.default_rng(0xF4E50004)
+            s4 = "".join(chr(c) for c in rng4.integers(0x20, 0x7F, size=1000))
+            cases = [sharded_case("config 2: find, 64-char input / 4-char pattern", "find", text, None, pat, 4, 3),
+                     sharded_case("config 4: contains, 1000 chars padded to 1024 / 8-char pattern", "contains", s4, 1024, s4[700:708], 6, 2)]
+            sharded = {"world": world_size, "transport": "host callbacks over gloo (rehearsal)" if (dist and rehearsal) else "RCCL (ncclAllGather on arena rows)",
+                       "key_broadcast_ms": round(keys_ms, 2), "cases": cases,
+                       "note": "positions of find_all sharded over the ranks through the C ABI (fhes_sharded_search); wall-clock of one operation on one string, max over repetitions' best on rank 0; the serial first-match scan of `find` is replicated, not sharded"}
+            comm.close()
+        except Exception as e:     # the headline measurement stands on its own
+            sharded = {"error": repr(e)}
+        return sharded
 
     dt_max = dt
     if dist:
@@ -436,10 +438,30 @@ def main():
                                  "(`traffic`, `physical_gbs`: PMC FETCH_SIZE x2 + WRITE_SIZE) is a few percent of the HBM peak: HBM does not bind "
                                  "this kernel, see roofline_compute"},
             "roofline_compute": comp,
-            "sharded": sharded,
+            "sharded": None,
         }
         if world_size == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline("default" if args.params == "classic" else args.params, pairs)
+    else:
+        line = None
+
+    # The position-sharded section runs AFTER the headline numbers are final and under a watchdog: a
+    # collective that never returns (a mis-configured fabric) must not cost the run its JSON line.
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(float(os.environ.get("FHES_BENCH_SHARDED_TIMEOUT", "240"))):
+            if rank == 0:
+                line["sharded"] = {"error": "timed out: the position-sharded section did not return"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    sharded = measure_sharded()
+    done.set()
+    if rank == 0:
+        line["sharded"] = sharded
         print(json.dumps(line), flush=True)
 
     lib.fhes_program_destroy(prog)

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--params", choices=["classic", "multibit2", "multibit3"], default="classic",
                     help="PARAM_MESSAGE_2_CARRY_2_KS_PBS or the multi-bit 2_2 sets (BASELINE.json config 5)")
+    ap.add_argument("--logdepth", action="store_true",
+                    help="opt-in parallel-prefix circuits (identical results, far fewer dependent levels; DESIGN.md 5.5)")
     a = ap.parse_args()
 
     print("Generating keys...")
@@ -34,6 +36,8 @@ def main():
     params = api.default_params() if a.params == "classic" else api.multibit_params(int(a.params[-1]))
     ck, sk = api.generate_keys_with_params(params, a.l, seed=a.seed)
     print(f"Done. ({time.time() - t0:.2f}s)")
+    if a.logdepth:
+        sk.set_logdepth(True)
     s, p, sub, n = a.input, a.pattern, a.substitution, a.n
     print("Encrypting input / pattern / substitution / n...")
     se = api.FheString.new(ck, s, a.pad)

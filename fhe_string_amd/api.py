@@ -103,6 +103,13 @@ class ServerKey:
         dependent levels.  Default off: the reference's own circuits."""
         check(_L().fhes_server_key_set_logdepth(self._h, 1 if enabled else 0))
 
+    def set_comm(self, comm):
+        """Attach a `fhe_string_amd.parallel.Comm` (one process per GPU): `contains` / `find` then run
+        position-sharded over its ranks -- every rank makes the same call with the same operands and gets
+        the same ciphertext (fhes_server_key_set_comm).  None detaches."""
+        check(_L().fhes_server_key_set_comm(self._h, comm._h if comm is not None else None))
+        self._comm = comm
+
     def stats(self):
         st = _lib.Stats()
         check(_L().fhes_get_stats(self.ctx, C.byref(st)))

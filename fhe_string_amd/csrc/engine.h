@@ -58,6 +58,7 @@ struct fhes_ctx {
   std::vector<Timed> pending;         // launches whose events are not yet read
   std::vector<hipEvent_t> ev_free;    // recycled events
   int br_variant = 0;
+  int ks_tb = 0;        // developer knob FHES_KS_TB: 16 = 16 ciphertexts per keyswitch block (default 8)
   int ks_min_cps = 8;   // smallest mask range per keyswitch split (developer knob FHES_KS_MIN_CPS)
 
   explicit fhes_ctx(const fhes_params &pp) : p(pp), dims(pp) {}

@@ -204,7 +204,10 @@ static int ensure_ks_out(fhes_ctx *ctx, int64_t nodes) {
 static int launch_keyswitch(fhes_ctx *ctx, const dev::NodeDesc &d) {
   const Dims &dm = ctx->dims;
   FHES_HIP(hipMemsetAsync(ctx->ks_out, 0, (size_t)d.v_count * ctx->ks_stride * sizeof(uint64_t), ctx->stream));
-  const int tiles = (d.v_count + dev::KS_TB - 1) / dev::KS_TB;
+  // 8 ciphertexts per block; FHES_KS_TB=16 forces 16 (measured no faster: kernels.hip.h)
+  const bool wide = ctx->ks_tb == dev::KS_TB_WIDE;
+  const int tb = wide ? dev::KS_TB_WIDE : dev::KS_TB;
+  const int tiles = (d.v_count + tb - 1) / tb;
   // wide launches: at most one split per KS_IC-coefficient chunk; small launches (the latency
   // path, a handful of tiles) split down to FHES_KS_MIN_CPS coefficients so that the 61 MB key is
   // streamed by all CUs
@@ -215,10 +218,15 @@ static int launch_keyswitch(fhes_ctx *ctx, const dev::NodeDesc &d) {
   const int cps = dm.big / splits;
   dim3 grid(tiles, splits), block(256);
   const int jpt = ctx->ks_stride / 256;
-#define KS_LAUNCH(J)                                                                              \
-  hipLaunchKernelGGL((dev::keyswitch_kernel<J>), grid, block, 0, ctx->stream, d, ctx->arena,     \
-                     ctx->ct_stride, dm.big, ctx->ksk, ctx->ksk_bias, dm.ks_level, dm.ks_base_log, \
-                     ctx->ks_stride, dm.n, cps, ctx->ks_out)
+#define KS_LAUNCH(J)                                                                                        \
+  if (wide)                                                                                                 \
+    hipLaunchKernelGGL((dev::keyswitch_kernel<J, dev::KS_TB_WIDE>), grid, block, 0, ctx->stream, d, ctx->arena, \
+                       ctx->ct_stride, dm.big, ctx->ksk, ctx->ksk_bias, dm.ks_level, dm.ks_base_log,       \
+                       ctx->ks_stride, dm.n, cps, ctx->ks_out);                                             \
+  else                                                                                                      \
+    hipLaunchKernelGGL((dev::keyswitch_kernel<J, dev::KS_TB>), grid, block, 0, ctx->stream, d, ctx->arena, \
+                       ctx->ct_stride, dm.big, ctx->ksk, ctx->ksk_bias, dm.ks_level, dm.ks_base_log,       \
+                       ctx->ks_stride, dm.n, cps, ctx->ks_out)
   switch (jpt) {
     case 1: KS_LAUNCH(1); break;
     case 2: KS_LAUNCH(2); break;
@@ -516,6 +524,7 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
     ctx->n_cus = prop.multiProcessorCount;
   }
+  if (const char *e3 = getenv("FHES_KS_TB")) ctx->ks_tb = atoi(e3);  // developer knob: 8 / 16 force the tile height
   if (const char *e2 = getenv("FHES_KS_MIN_CPS")) {
     const int v = atoi(e2);
     if (v >= 1 && v <= dev::KS_IC && (v & (v - 1)) == 0) ctx->ks_min_cps = v;

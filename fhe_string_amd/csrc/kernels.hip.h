@@ -239,11 +239,12 @@ __device__ __forceinline__ int32_t resolve(const NodeDesc &d, int32_t inst, int3
 // mask split are combined with u64 atomics (integer adds commute: deterministic).
 // ks_out [count][ks_stride] must be zero on entry.
 // ------------------------------------------------------------------------------------------
-constexpr int KS_TB = 8;     // ciphertexts per block
+constexpr int KS_TB = 8;     // ciphertexts per block (narrow launches)
+constexpr int KS_TB_WIDE = 16;  // developer knob FHES_KS_TB=16 (measured: no faster, see the loop below)
 constexpr int KS_IC = 64;    // mask coefficients staged per chunk
 constexpr int KS_MAXLV = 8;  // ks_level limit
 
-template <int JPT>
+template <int JPT, int TB>
 __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64_t *__restrict__ arena,
                                                         int ct_stride, int big,
                                                         const uint64_t *__restrict__ ksk,
@@ -253,28 +254,28 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
                                                         uint64_t *__restrict__ ks_out) {
   // digits are staged biased: u = d + B/2 in [0, B), so that the product u * K needs no sign
   // handling; sum_{i,l} (B/2) * K[i][l][j] is the precomputed `ksk_bias[j]` (added once).
-  __shared__ __attribute__((aligned(8))) uint8_t dig[KS_IC][KS_MAXLV][KS_TB];
+  __shared__ __attribute__((aligned(8))) uint8_t dig[KS_IC][KS_MAXLV][TB];
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
   const int i_begin = blockIdx.y * coeffs_per_split;
   const int i_end = i_begin + coeffs_per_split;
-  const int vbase = tile * KS_TB;  // virtual index (relative to v0) of this block's first ciphertext
-  const int nodes_here = min(KS_TB, d.v_count - vbase);
+  const int vbase = tile * TB;  // virtual index (relative to v0) of this block's first ciphertext
+  const int nodes_here = min(TB, d.v_count - vbase);
   const int total = ks_level * ks_base_log;
   const int B = 1 << ks_base_log;
 
   // sum u*K split into a 64-bit sum of u*K_lo and a 32-bit sum of u*K_hi (mod 2^32)
-  uint64_t acc_lo[KS_TB][JPT];
-  uint32_t acc_hi[KS_TB][JPT];
+  uint64_t acc_lo[TB][JPT];
+  uint32_t acc_hi[TB][JPT];
 #pragma unroll
-  for (int b = 0; b < KS_TB; ++b)
+  for (int b = 0; b < TB; ++b)
 #pragma unroll
     for (int q = 0; q < JPT; ++q) { acc_lo[b][q] = 0; acc_hi[b][q] = 0; }
 
   for (int chunk = i_begin; chunk < i_end; chunk += KS_IC) {
     const int lim = min(KS_IC, i_end - chunk);  // small launches split finer than one chunk
-    // stage the digits of KS_TB x KS_IC mask coefficients
-    for (int idx = tid; idx < KS_TB * KS_IC; idx += 256) {
+    // stage the digits of TB x KS_IC mask coefficients
+    for (int idx = tid; idx < TB * KS_IC; idx += 256) {
       const int b = idx / KS_IC, ii = idx % KS_IC;
       if (ii >= lim) continue;
       uint64_t x = 0;
@@ -295,20 +296,27 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
       }
     }
     __syncthreads();
+    // (Round 2, measured per 16 384 ciphertexts: this loop 11.7 ms; a second 64-bit accumulator instead of the
+    // 32-bit one 11.6 ms -- the compiler already emits v_mad_u64_u32 for both; 16 ciphertexts per block 11.9 ms;
+    // key words of the next row requested one row ahead 13.5 ms.  The loop runs at 67 % of the multiplier
+    // rate: 48 multiply-accumulates per row and wave against the latency of the row's three key loads, four
+    // waves per SIMD.)
     for (int ii = 0; ii < lim; ++ii) {
       const uint64_t *krow = ksk + ((size_t)(chunk + ii) * ks_level) * ks_stride;
       for (int l = 0; l < ks_level; ++l) {
         uint64_t kv[JPT];
 #pragma unroll
         for (int q = 0; q < JPT; ++q) kv[q] = krow[(size_t)l * ks_stride + tid + 256 * q];
-        const uint64_t packed = *reinterpret_cast<const uint64_t *>(&dig[ii][l][0]);
+        uint64_t packed[TB / 8];
 #pragma unroll
-        for (int b = 0; b < KS_TB; ++b) {
-          const uint32_t u = (uint32_t)(packed >> (8 * b)) & 0xFFu;
+        for (int w8 = 0; w8 < TB / 8; ++w8) packed[w8] = *reinterpret_cast<const uint64_t *>(&dig[ii][l][8 * w8]);
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+          const uint32_t u = (uint32_t)(packed[b / 8] >> (8 * (b % 8))) & 0xFFu;
 #pragma unroll
           for (int q = 0; q < JPT; ++q) {
             acc_lo[b][q] += (uint64_t)u * (uint32_t)kv[q];          // v_mad_u64_u32
-            acc_hi[b][q] += u * (uint32_t)(kv[q] >> 32);            // v_mul_lo_u32 + v_add
+            acc_hi[b][q] += u * (uint32_t)(kv[q] >> 32);            // a second v_mad_u64_u32 (low dword kept)
           }
         }
       }
@@ -317,8 +325,8 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
   }
 
 #pragma unroll
-  for (int b = 0; b < KS_TB; ++b) {
-    if (b >= nodes_here) break;
+  for (int b = 0; b < TB; ++b) {
+    if (b >= nodes_here) continue;  // (no `break`: the loop must unroll fully, acc[][] lives in registers)
     const int v = d.v0 + vbase + b;
     const int inst = v / d.count, node = d.first + v % d.count;
     uint64_t *dst = ks_out + (size_t)(vbase + b) * ks_stride;

@@ -60,10 +60,22 @@ def _worker(rank, world_size, port, q):
         outs = np.zeros(pr.n_outputs, dtype=np.int32)
         check(w.lib.fhes_program_run(ctx, pr.h, ptr(ins), ptr(outs)))
         ref = fetch([int(outs[0]) + k for k in range(pr.n_outputs)])
-        q.put((rank, decode_result("find", w.decrypt(f), bu), bool(w.decrypt(c)[0] & 1), bool(np.array_equal(f, ref)),
-               f[:, :8].tobytes()))
         comm.close()
         w.close()
+        # Level 2: the reference's own method signatures over an attached communicator
+        from fhe_string_amd import api
+        ck, sk = api.generate_keys_with_params(api.default_params(), 255, seed=0xF4E50000)
+        comm2 = Comm.host(sk.ctx, dist)
+        sk.set_comm(comm2)
+        A, P = api.FheString.new(ck, text, 60), api.FheString.new(ck, pat)
+        api_find = A.find(sk, P).decrypt(ck)
+        api_contains = ck.decrypt_bool(A.contains(sk, P))
+        api_miss = ck.decrypt_bool(A.contains(sk, api.FheString.new(ck, "zebra")))
+        sk.set_comm(None)
+        comm2.close()
+        sk.close()
+        q.put((rank, decode_result("find", w.decrypt(f), bu), bool(w.decrypt(c)[0] & 1), bool(np.array_equal(f, ref)),
+               f[:, :8].tobytes(), (api_find, api_contains, api_miss)))
     finally:
         dist.destroy_process_group()
 
@@ -81,8 +93,9 @@ def test_two_ranks_one_gpu_host_transport(libs):
         p.join(timeout=120)
         assert p.exitcode == 0
     text = "the quick brown fox jumps over the lazy dog, twice over"
-    for rank, found, contains, same_bits, _ in results:
+    for rank, found, contains, same_bits, _, level2 in results:
         assert found == text.find("over"), rank
         assert contains is True
         assert same_bits, f"rank {rank}: sharded find differs from the unsharded program"
+        assert level2 == (text.find("over"), True, False), (rank, level2)
     assert results[0][4] == results[1][4], "the two ranks hold different ciphertexts"
