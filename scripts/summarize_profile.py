@@ -109,6 +109,20 @@ if bench_line and "roofline" in bench_line:
              "rocprof_dominant_blind_rotate_kernel": dom,
              "rocprof_total_ms": round(prof_total, 1),
              "ratio": round(prof_total / bench_total, 4) if bench_total else None}
+# the same comparison on AVERAGES (what the bench line's roofline.launch_ms is): rocprofv3's per-kernel average
+# mixes in the single-find launches of the untimed section (a few ciphertexts, ~3 ms each), so average over the
+# dispatches of the batched steps only (>= 512 workgroups, as bench.py's timed launches are)
+try:
+    trace = newest(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+    durs = [(float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6 for r in csv.DictReader(open(trace))
+            if "blind_rotate" in r["Kernel_Name"] and int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1) >= 512]
+    if check is not None and durs and bench_line:
+        check["rocprof_avg_ms_of_batched_launches"] = round(sum(durs) / len(durs), 4)
+        check["rocprof_batched_launches"] = len(durs)
+        check["bench_launch_ms"] = bench_line["roofline"]["launch_ms"]
+        check["avg_ratio"] = round(check["rocprof_avg_ms_of_batched_launches"] / bench_line["roofline"]["launch_ms"], 4)
+except (ValueError, KeyError):
+    pass
 extra = sys.argv[2] if len(sys.argv) > 2 else ""      # e.g. "--params multibit2"
 out = {"tag": tag, "command": f"python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline {extra}".strip() + " (under rocprofv3)",
        "duration_cross_check": check,
