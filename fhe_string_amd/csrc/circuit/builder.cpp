@@ -198,6 +198,87 @@ Blk Builder::bivar(const Blk &x, const Blk &y, int shift,
   return r;
 }
 
+// Memory-bounded schedule.  The level schedule runs every node as soon as its operands
+// exist, so a gather -- thousands of bootstrapped terms per sum, e.g. the slots^2 selections of the faithful
+// `substr_from` -- has all its terms alive at once (trim at 512 characters: 1.32 M cells = 22 GB).  When a
+// level is wider than `max_nodes`, the OUTPUTS are cut into consecutive groups and every node that feeds one
+// group only (its whole cone: index arithmetic, equality flags, selections, the final sums) is scheduled
+// with that group: first the nodes shared between groups in their level order, then group 0's cone level
+// by level, then group 1's, ...  Same nodes, same arithmetic, more and smaller launches; the cell allocator
+// (program.hip) re-uses the cells of a group once its results exist.  A consumer of a group-exclusive node is
+// exclusive to the same group, so shared nodes never wait for a group.
+static void tile_wide_levels(Program &prog, size_t max_nodes) {
+  const int32_t nin = prog.n_inputs;
+  const int32_t nn = (int32_t)prog.nodes.size();
+  const int nl = (int)prog.level_ptr.size() - 1;
+  if (nn == 0 || nl < 2) return;
+  size_t widest = 0;
+  for (int li = 0; li < nl; li++) widest = std::max<size_t>(widest, (size_t)(prog.level_ptr[li + 1] - prog.level_ptr[li]));
+  if (widest <= max_nodes) return;
+  const bool has_linear = prog.nodes.back().lut < 0;
+  const int32_t lin_lo = has_linear ? prog.level_ptr[nl - 1] : nn;  // linear nodes stay together at the end
+  std::vector<int32_t> level_of(nn);
+  for (int li = 0; li < nl; li++)
+    for (int32_t j = prog.level_ptr[li]; j < prog.level_ptr[li + 1]; j++) level_of[j] = li;
+  // consecutive outputs -> groups (the blocks of one result char / integer are consecutive outputs)
+  const int32_t n_out = (int32_t)prog.out_slots.size();
+  const int32_t n_groups = (int32_t)std::min<int64_t>(n_out, (int64_t)((size_t)lin_lo / max_nodes + 1) * 2);
+  if (n_groups < 2) return;
+  std::vector<int32_t> group_of_out(n_out);
+  for (int32_t k = 0; k < n_out; k++) group_of_out[k] = (int32_t)((int64_t)k * n_groups / n_out);
+  // owner[j]: the one GROUP whose cone holds node j, -1 = none yet, -2 = several
+  std::vector<int32_t> owner(nn, -1);
+  auto claim = [&](int32_t node, int32_t who) {
+    if (owner[node] == -1) owner[node] = who;
+    else if (owner[node] != who) owner[node] = -2;
+  };
+  for (int32_t k = 0; k < n_out; k++)
+    if (prog.out_slots[k] >= nin) claim(prog.out_slots[k] - nin, group_of_out[k]);
+  for (int32_t j = nn - 1; j >= 0; j--) {  // nodes are in level order: consumers come after producers
+    if (owner[j] == -1) continue;          // dead nodes were eliminated; keep the guard
+    for (const auto &t : prog.nodes[j].terms)
+      if (t.slot >= nin) claim(t.slot - nin, owner[j]);
+  }
+  // new order: shared by level | group 0 by level | group 1 by level | ... | linear nodes
+  std::vector<std::vector<std::vector<int32_t>>> bucket(n_groups + 1, std::vector<std::vector<int32_t>>(nl));
+  for (int32_t j = 0; j < lin_lo; j++) {
+    const int32_t b = owner[j] >= 0 ? 1 + owner[j] : 0;
+    bucket[b][level_of[j]].push_back(j);
+  }
+  std::vector<int32_t> order, lp{0};
+  for (auto &grp : bucket)
+    for (auto &lv : grp) {
+      if (lv.empty()) continue;
+      order.insert(order.end(), lv.begin(), lv.end());
+      lp.push_back((int32_t)order.size());
+    }
+  if (has_linear) {
+    for (int32_t j = lin_lo; j < nn; j++) order.push_back(j);
+    lp.push_back((int32_t)order.size());
+  }
+  // only worth it when it does not lengthen the schedule: a program whose results hang off a serial chain
+  // (faithful split: every slice bound is cleaned at its own step of the scan) would turn each of those
+  // steps into a launch of its own
+  {
+    int64_t exclusive = 0;
+    for (int32_t j = 0; j < lin_lo; j++) exclusive += owner[j] >= 0;
+    const int64_t added = (int64_t)lp.size() - 1 - nl;
+    if (added > 0 && exclusive / added < 1024) return;  // the added launches would not be wide ones
+  }
+  std::vector<int32_t> new_pos(nn);
+  for (int32_t k = 0; k < nn; k++) new_pos[order[k]] = k;
+  std::vector<Node> moved(nn);
+  for (int32_t k = 0; k < nn; k++) moved[k] = std::move(prog.nodes[order[k]]);
+  prog.nodes = std::move(moved);
+  auto remap = [&](int32_t sl) { return sl >= nin ? nin + new_pos[sl - nin] : sl; };
+  for (auto &nd : prog.nodes) {
+    for (auto &t : nd.terms) t.slot = remap(t.slot);
+    std::sort(nd.terms.begin(), nd.terms.end());
+  }
+  for (int32_t &sl : prog.out_slots) sl = remap(sl);
+  prog.level_ptr = lp;
+}
+
 Program Builder::finish(const std::vector<Blk> &outputs, const std::string &name) {
   // 1. materialise outputs.  Results cross the program boundary as CLEAN blocks, like the results
   // of tfhe-rs's default operations: noise of one bootstrap, degree below the message modulus
@@ -267,6 +348,7 @@ Program Builder::finish(const std::vector<Blk> &outputs, const std::string &name
   for (int32_t s : out_slots) prog.out_slots.push_back(remap(s));
   prog.out_deg = out_deg;
   prog.out_noise = out_noise;
+  tile_wide_levels(prog, (size_t)1 << 16);
   return prog;
 }
 

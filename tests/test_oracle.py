@@ -230,3 +230,28 @@ def test_a_dozen_table_cases_at_the_real_parameter_set(libs):
     assert len(REAL) == 12
     for case in REAL:
         assert _run_case_on(real, case["op"], _as_args(case), bu) == case["expect"], case
+
+
+def test_one_level_decomposition_noise_scales_with_the_base(libs):
+    """sigma of a bootstrap output: 2^48.9 for the 2^23 base, 2^53.6 for 2^18 (x 2^(23-18) as the rounding of
+    the one-level decomposition predicts: 2^(2(63-B))/3 per coefficient x (1 + kN/2) x n).  This is what
+    Builder's noise cap scales with (x 4^(B-23)) and why the compiled circuits refuse the 2^18 sets: one
+    bivariate lookup of two such blocks (17 units) would sit ~3 sigma from the decoding margin 2^58."""
+    import math
+    from tests.helpers import World
+    rms = {}
+    for which in ("default", "default_b18"):
+        ww = World(which)
+        vals = np.array([3, 7, 12, 0, 5, 9], dtype=np.uint8)
+        cts = ww.encrypt(vals)
+        _, poly = ww.lut_poly(lambda x: x)
+        sk = np.ascontiguousarray(np.ctypeslib.as_array(C.cast(ww.lib.fhes_client_key_big_sk(ww.ck), C.POINTER(C.c_uint64)), (ww.W - 1,)))
+        es = []
+        for i, v in enumerate(vals):
+            ph = ww.orc.oracle_lwe_phase(ptr(ww.oracle_pbs(cts[i], poly)), ptr(sk), ww.W - 1)
+            e = (int(ph) - (int(v) << 59)) % (1 << 64)
+            es.append(e - (1 << 64) if e >= (1 << 63) else e)
+        rms[which] = math.log2(math.sqrt(sum(e * e for e in es) / len(es)))
+    assert 47.5 < rms["default"] < 50.0, rms
+    assert 52.5 < rms["default_b18"] < 54.8, rms
+    assert 4.0 < rms["default_b18"] - rms["default"] < 5.6, rms     # 2^5 from the 5 dropped bits
