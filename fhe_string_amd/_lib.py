@@ -73,6 +73,8 @@ SIGNATURES = {
     "fhes_debug_fft_tables": (C.c_int, [_PP, _P, _P]),
     "fhes_debug_phase_profile": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "fhes_debug_keyswitch": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "fhes_debug_keyswitch_words": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "fhes_set_keyswitch_mfma_min": (C.c_int, [_P, C.c_int32]),
     "fhes_program_compile": (_P, [_PP, C.c_char_p, _P, C.c_int32, C.c_int32]),
     "fhes_program_destroy": (None, [_P]),
     "fhes_program_scratch_cells": (C.c_int32, [_P]),
@@ -101,6 +103,8 @@ SIGNATURES = {
     "fhes_ct_serialize": (C.c_int64, [_P, _P, C.c_int64]),
     "fhes_ct_deserialize": (_P, [_P, C.c_int64]),
     "fhes_ct_block_meta": (C.c_int, [_P, _P, _P]),
+    "fhes_ct_slice": (_P, [_P, _P, C.c_int32, C.c_int32]),
+    "fhes_ct_concat": (_P, [_P, _P, C.c_int32]),
     "fhes_server_key_serialize": (C.c_int64, [_P, _P, C.c_int64]),
     "fhes_server_key_deserialize": (_P, [_P, C.c_int64, C.c_int32]),
     "fhes_string_op": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _i32p]),

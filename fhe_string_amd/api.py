@@ -359,6 +359,26 @@ class FheString(_Ct):
         o = _op(k, "rfind", self, s)
         return FheOption(BooleanBlock(o[0]), FheUsize(o[1]))
 
+    def chars(self, k):
+        """the Vec<FheAsciiChar> behind the string (mod.rs:42-43), terminator and padding included"""
+        bc = k.num_blocks_char
+        return [FheAsciiChar(check_ptr(_L().fhes_ct_slice(k._h, self._h, i * bc, bc))) for i in range(self.num_blocks // bc)]
+
+    def _pred_scan(self, k, name, p):
+        flags = [p(k, c) for c in self.chars(k)]     # the closure runs here, on every slot (mod.rs:329-336)
+        arr = (C.c_void_p * max(len(flags), 1))(*[f._h for f in flags])
+        v = _Ct(check_ptr(_L().fhes_ct_concat(k._h, arr, len(flags))))
+        o = _op(k, name, v)
+        return FheOption(BooleanBlock(o[0]), FheUsize(o[1]))
+
+    def find_pred_unchecked(self, k, p):
+        """search.rs:196-203: first index i with p(k, self[i]) == 1; p: (ServerKey, FheAsciiChar) -> BooleanBlock"""
+        return self._pred_scan(k, "find_pred", p)
+
+    def rfind_pred_unchecked(self, k, p):
+        """search.rs:205-213"""
+        return self._pred_scan(k, "rfind_pred", p)
+
     def starts_with(self, k, s):
         return BooleanBlock(_op(k, "starts_with", self, s)[0])
 

@@ -1116,13 +1116,18 @@ const char *op_signature(const std::string &op_full) {
     if (op == e.name) return e.sig;
   if (op == "find_all_range") return "SSII";
   if (op == "any_of" || op == "index_of" || op == "rindex_of") return "I";
+  // find_pred_unchecked / rfind_pred_unchecked (search.rs:196-213): the closure runs on the caller's side,
+  // L = its results, one BooleanBlock per character, as one ciphertext object
+  if (op == "find_pred" || op == "rfind_pred") return "L";
   return nullptr;
 }
 
 Program compile_op(const fhes_params &p, const std::string &op_full, const std::vector<int32_t> &shape,
                    int32_t num_blocks_usize) {
   bool fast = false;
-  const std::string op = base_op(op_full, &fast);
+  std::string op = base_op(op_full, &fast);
+  if (op == "find_pred") op = "index_of";
+  if (op == "rfind_pred") op = "rindex_of";
   const int msg_mod = 1 << p.message_bits;
   int Bc = 0;
   for (int v = 1; v < 128; v *= msg_mod) Bc++;  // lib.rs:60-61

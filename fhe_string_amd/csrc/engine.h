@@ -34,6 +34,8 @@ struct fhes_ctx {
   uint64_t *ksk = nullptr;   // [big][ks_level][ks_stride]
   uint64_t *ksk_bias = nullptr;  // [ks_stride]: (B/2) * sum_{i,l} ksk[i][l][j]  (biased-digit keyswitch)
   int ks_stride = 0;
+  int8_t *ksk_pk = nullptr;  // keyswitch key as signed byte planes in MFMA B-fragment order (keyswitch_mfma_kernel)
+  int ks_n_wb = 0;           // blocks of 16 key words: ceil((n + 1) / 16)
   double2 *bsk_f = nullptr;  // canonical [n_ggsw][2][2][M]   (multi-bit: [n/g][2^g][2][2][M])
   double2 *bsk_e = nullptr;  // engine layout for blind-rotate variants 2/3 and multi-bit: [n_ggsw][2][2][8][M/8]
   double2 *twist = nullptr, *tw = nullptr;
@@ -48,6 +50,8 @@ struct fhes_ctx {
   // per-launch scratch
   uint64_t *ks_out = nullptr;
   int64_t ks_out_nodes = 0;
+  int8_t *ks_dig = nullptr;    // digits of a wide launch, A-fragment order: [ceil(nodes / 128) * 8][ksteps][64][16]
+  uint64_t *ks_body = nullptr; // [nodes]
   unsigned char *desc_buf = nullptr;  // staging for fhes_pbs_batch descriptors
   size_t desc_cap = 0;
 
@@ -59,6 +63,7 @@ struct fhes_ctx {
   std::vector<hipEvent_t> ev_free;    // recycled events
   int br_variant = 0;
   int ks_tb = 0;        // developer knob FHES_KS_TB: 16 = 16 ciphertexts per keyswitch block (default 8)
+  int ks_mfma_min = 1;  // launches of at least this many ciphertexts take the matrix-core keyswitch (FHES_KS_MFMA_MIN; 0 = never)
   int ks_min_cps = 8;   // smallest mask range per keyswitch split (developer knob FHES_KS_MIN_CPS)
 
   explicit fhes_ctx(const fhes_params &pp) : p(pp), dims(pp) {}

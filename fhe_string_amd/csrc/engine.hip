@@ -193,16 +193,40 @@ static dev::NodeDesc make_desc(const DevNodeArrays &a, int32_t first, int32_t co
 static int ensure_ks_out(fhes_ctx *ctx, int64_t nodes) {
   if (nodes <= ctx->ks_out_nodes) return FHES_OK;
   if (ctx->ks_out) FHES_HIP(hipFree(ctx->ks_out));
-  ctx->ks_out = nullptr;
+  if (ctx->ks_dig) FHES_HIP(hipFree(ctx->ks_dig));
+  if (ctx->ks_body) FHES_HIP(hipFree(ctx->ks_body));
+  ctx->ks_out = nullptr; ctx->ks_dig = nullptr; ctx->ks_body = nullptr;
   ctx->ks_out_nodes = 0;
-  const int64_t cap = std::max<int64_t>(nodes, 1024);
+  const int64_t cap = ((std::max<int64_t>(nodes, 1024) + 127) / 128) * 128;  // whole 128-row tiles of the MFMA keyswitch
   FHES_HIP(hipMalloc(&ctx->ks_out, (size_t)cap * ctx->ks_stride * sizeof(uint64_t)));
+  FHES_HIP(hipMalloc(&ctx->ks_dig, (size_t)cap * ctx->dims.big * ctx->dims.ks_level));
+  FHES_HIP(hipMalloc(&ctx->ks_body, (size_t)cap * sizeof(uint64_t)));
   ctx->ks_out_nodes = cap;
+  return FHES_OK;
+}
+
+// wide launches: digits -> i8 matrix product on the matrix cores (kernels.hip.h K1b); same integers, same bits
+static int launch_keyswitch_mfma(fhes_ctx *ctx, const dev::NodeDesc &d) {
+  const Dims &dm = ctx->dims;
+  const int ksteps = dm.big * dm.ks_level / 64;
+  hipLaunchKernelGGL(dev::keyswitch_digits_kernel, dim3(d.v_count), dim3(128), 0, ctx->stream, d, ctx->arena,
+                     ctx->ct_stride, dm.big, dm.ks_level, dm.ks_base_log, ksteps, ctx->ks_dig, ctx->ks_body);
+  FHES_HIP(hipGetLastError());
+  const int row_blocks = (d.v_count + 127) / 128, col_blocks = (ctx->ks_n_wb + 1) / 2;
+  // few row blocks: split the digit range so that the launch still covers the chip (u64 atomics: exact)
+  int splits = 1;
+  while (splits < 16 && row_blocks * col_blocks * splits < 512 && ksteps % (splits * 2) == 0) splits *= 2;
+  if (splits > 1) FHES_HIP(hipMemsetAsync(ctx->ks_out, 0, (size_t)d.v_count * ctx->ks_stride * sizeof(uint64_t), ctx->stream));
+  hipLaunchKernelGGL(dev::keyswitch_mfma_kernel, dim3(row_blocks, col_blocks, splits), dim3(256), 0, ctx->stream,
+                     ctx->ks_dig, ctx->ksk_pk, ctx->ks_body, ctx->ks_out, ctx->ks_stride, ksteps, ctx->ks_n_wb, dm.n,
+                     d.v_count, ksteps / splits, splits > 1 ? 1 : 0);
+  FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
 
 static int launch_keyswitch(fhes_ctx *ctx, const dev::NodeDesc &d) {
   const Dims &dm = ctx->dims;
+  if (ctx->ks_mfma_min > 0 && d.v_count >= ctx->ks_mfma_min && ctx->ksk_pk) return launch_keyswitch_mfma(ctx, d);
   FHES_HIP(hipMemsetAsync(ctx->ks_out, 0, (size_t)d.v_count * ctx->ks_stride * sizeof(uint64_t), ctx->stream));
   // 8 ciphertexts per block; FHES_KS_TB=16 forces 16 (measured no faster: kernels.hip.h)
   const bool wide = ctx->ks_tb == dev::KS_TB_WIDE;
@@ -524,6 +548,7 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
     ctx->n_cus = prop.multiProcessorCount;
   }
+  if (const char *e5 = getenv("FHES_KS_MFMA_MIN")) ctx->ks_mfma_min = atoi(e5);  // developer knob: 0 = VALU keyswitch only, 1 = always MFMA
   if (const char *e3 = getenv("FHES_KS_TB")) ctx->ks_tb = atoi(e3);  // developer knob: 8 / 16 force the tile height
   if (const char *e2 = getenv("FHES_KS_MIN_CPS")) {
     const int v = atoi(e2);
@@ -587,7 +612,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->root); (void)hipFree(ctx->lut_polys);
-  (void)hipFree(ctx->ks_out); (void)hipFree(ctx->desc_buf);
+  (void)hipFree(ctx->ks_out); (void)hipFree(ctx->ks_dig); (void)hipFree(ctx->ks_body); (void)hipFree(ctx->ksk_pk); (void)hipFree(ctx->desc_buf);
   for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
   for (auto &ev : ctx->ev_free) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -614,6 +639,29 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
     for (auto &v : bias) v *= half_base;
     if (!ctx->ksk_bias) FHES_HIP(hipMalloc(&ctx->ksk_bias, bias.size() * 8));
     FHES_HIP(hipMemcpy(ctx->ksk_bias, bias.data(), bias.size() * 8, hipMemcpyHostToDevice));
+    // the same key as signed byte planes in MFMA B-fragment order (kernels.hip.h K1b):
+    // kpk[k / 64][word / 16][byte plane][lane][16], k = l * big + i, lane = word % 16 + 16 * ((k % 64) / 16)
+    if (((size_t)d.big * d.ks_level) % 64 == 0) {
+      const int ksteps = d.big * d.ks_level / 64, n_wb = (d.n + 1 + 15) / 16;
+      std::vector<int8_t> pk((size_t)ksteps * n_wb * 8 * 64 * 16, 0);
+      for (int k = 0; k < ksteps * 64; k++) {
+        const int l = k / d.big, i = k % d.big;
+        const uint64_t *krow = &padded[((size_t)i * d.ks_level + l) * ctx->ks_stride];
+        const int s = k >> 6, g = (k & 63) >> 4, j = k & 15;
+        for (int word = 0; word <= d.n; word++) {
+          uint64_t v = krow[word];
+          const size_t base = ((((size_t)s * n_wb + (word >> 4)) * 8) * 64 + ((word & 15) + 16 * g)) * 16 + j;
+          for (int t = 0; t < 8; t++) {
+            const int8_t sb = (int8_t)(uint8_t)(v & 0xFF);
+            v = (v >> 8) + (sb < 0 ? 1 : 0);
+            pk[base + (size_t)t * 64 * 16] = sb;
+          }
+        }
+      }
+      if (!ctx->ksk_pk) FHES_HIP(hipMalloc(&ctx->ksk_pk, pk.size()));
+      FHES_HIP(hipMemcpy(ctx->ksk_pk, pk.data(), pk.size(), hipMemcpyHostToDevice));
+      ctx->ks_n_wb = n_wb;
+    }
   }
   // bootstrapping key -> Fourier domain on the device
   {
@@ -824,8 +872,27 @@ int fhes_debug_phase_profile(fhes_ctx *ctx, int32_t count, int32_t in_handle, do
   return rc;
 }
 
+int fhes_set_keyswitch_mfma_min(fhes_ctx *ctx, int32_t min_count) {
+  if (!ctx || min_count < 0) return fail(FHES_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->ks_mfma_min = min_count;
+  return FHES_OK;
+}
+
+static int debug_keyswitch_impl(fhes_ctx *ctx, int32_t count, const int32_t *in_handles, uint32_t *a_tilde, uint64_t *words);
+
 int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles, uint32_t *a_tilde) {
-  if (!ctx || !in_handles || !a_tilde || count <= 0) return fail(FHES_ERR_INVALID, "bad argument");
+  if (!a_tilde) return fail(FHES_ERR_INVALID, "bad argument");
+  return debug_keyswitch_impl(ctx, count, in_handles, a_tilde, nullptr);
+}
+
+int fhes_debug_keyswitch_words(fhes_ctx *ctx, int32_t count, const int32_t *in_handles, uint64_t *words) {
+  if (!words) return fail(FHES_ERR_INVALID, "bad argument");
+  return debug_keyswitch_impl(ctx, count, in_handles, nullptr, words);
+}
+
+static int debug_keyswitch_impl(fhes_ctx *ctx, int32_t count, const int32_t *in_handles, uint32_t *a_tilde, uint64_t *words) {
+  if (!ctx || !in_handles || count <= 0) return fail(FHES_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lk(ctx->mu);
   FHES_HIP(hipSetDevice(ctx->device));
   if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
@@ -847,6 +914,10 @@ int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles
   FHES_HIP(hipMemcpy(h.data(), ctx->ks_out, h.size() * 8, hipMemcpyDeviceToHost));
   int lg = 0;
   while ((1 << lg) < 2 * ctx->dims.N) lg++;
+  if (words)
+    for (int c = 0; c < count; c++)
+      memcpy(words + (size_t)c * (ctx->dims.n + 1), &h[(size_t)c * ctx->ks_stride], sizeof(uint64_t) * (ctx->dims.n + 1));
+  if (a_tilde)
   for (int c = 0; c < count; c++)
     for (int j = 0; j <= ctx->dims.n; j++)
       a_tilde[(size_t)c * (ctx->dims.n + 1) + j] =

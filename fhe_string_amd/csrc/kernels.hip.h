@@ -351,6 +351,141 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(NodeDesc d, const uint64
 }
 
 // ------------------------------------------------------------------------------------------
+// K1b: the keyswitch of a WIDE launch as an integer matrix product on the matrix cores.
+//     out[c][j] = body[c] * [j == n]  -  sum_k dig[c][k] * K[k][j]          (mod 2^64)
+// with k = l * big + i over the kN * ks_level signed digits of ciphertext c (|dig| <= 2^(base_log-1) <= 64)
+// is a (ciphertexts x digits) by (digits x key words) product.  A 64-bit key word is split into 8 signed
+// bytes  K = sum_b s_b * 256^b  (s_b in [-128, 127], borrow carried upwards; the carry out of byte 7 vanishes
+// mod 2^64), so the product becomes eight i8 x i8 -> i32 products, exact (|sum| <= 16384 * 64 * 128 < 2^31),
+// recombined with shifts in the epilogue.  Same integers as keyswitch_kernel, hence the same bits.
+// Against the VALU kernel (11.7 ms per 16 384 ciphertexts at the reference's parameters, 67 % of the
+// 64-bit multiplier rate) the matrix cores retire the 1.0e15 byte products of that launch in about a tenth.
+//   keyswitch_digits_kernel: one workgroup per ciphertext; linear combination of the inputs, rounding,
+//     balanced digits, written as i8 in MFMA A-fragment order  dig[row / 16][k / 64][lane][16]  with
+//     lane = row % 16 + 16 * ((k % 64) / 16), byte = k % 16; the body of the combination goes to body[row].
+//   keyswitch_mfma_kernel: v_mfma_i32_16x16x64_i8; a wave owns 64 ciphertexts x 16 key words (= 8 byte
+//     planes = 8 column tiles, so that a lane holds all 8 byte planes of ITS word: recombination needs no
+//     lane traffic), a workgroup 2 x 2 waves.  Both operands stream from L2 in fragment order (the key is
+//     packed once at upload: kpk[k / 64][word / 16][byte plane][lane][16]); no LDS.
+// A and B use the same (lane group, byte) -> k assignment, so the product sums every k exactly once
+// whatever order the instruction walks them in.
+// ------------------------------------------------------------------------------------------
+typedef int ksm_v4i __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(128) void keyswitch_digits_kernel(NodeDesc d, const uint64_t *__restrict__ arena,
+                                                               int ct_stride, int big, int ks_level,
+                                                               int ks_base_log, int ksteps,
+                                                               int8_t *__restrict__ dig, uint64_t *__restrict__ body) {
+  const int row = blockIdx.x;
+  const int v = d.v0 + row;
+  const int inst = v / d.count, node = d.first + v % d.count;
+  const int t0 = d.term_ptr[node], t1 = d.term_ptr[node + 1];
+  const int total = ks_level * ks_base_log;
+  const int B = 1 << ks_base_log;
+  for (int i0 = 16 * (int)threadIdx.x; i0 < big; i0 += 16 * (int)blockDim.x) {
+    uint64_t x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) x[u] = 0;
+    for (int t = t0; t < t1; ++t) {
+      const uint64_t *src = arena + (size_t)resolve(d, inst, d.term_idx[t]) * ct_stride + i0;
+      const uint64_t c = (uint64_t)d.term_coef[t];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) x[u] += c * src[u];
+    }
+    uint32_t pk[KS_MAXLV][4];
+#pragma unroll
+    for (int l = 0; l < KS_MAXLV; ++l) pk[l][0] = pk[l][1] = pk[l][2] = pk[l][3] = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      uint32_t w = (uint32_t)((((x[u] >> (64 - total - 1)) + 1) >> 1) & ((1ull << total) - 1));
+#pragma unroll
+      for (int l = KS_MAXLV - 1; l >= 0; --l) {
+        if (l >= ks_level) continue;
+        int dd = (int)(w & (uint32_t)(B - 1));
+        w >>= ks_base_log;
+        if (dd >= B / 2) { dd -= B; w += 1; }
+        pk[l][u >> 2] |= ((uint32_t)dd & 0xFFu) << (8 * (u & 3));
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < KS_MAXLV; ++l) {
+      if (l >= ks_level) continue;
+      const int k = l * big + i0;
+      const int lane = (row & 15) + 16 * ((k & 63) >> 4);
+      uint4 *dst = reinterpret_cast<uint4 *>(dig + ((((size_t)(row >> 4) * ksteps + (k >> 6)) * 64 + lane) << 4));
+      *dst = make_uint4(pk[l][0], pk[l][1], pk[l][2], pk[l][3]);
+    }
+  }
+  if (threadIdx.x == 0) {
+    uint64_t b = d.consts[node];
+    for (int t = t0; t < t1; ++t)
+      b += (uint64_t)d.term_coef[t] * arena[(size_t)resolve(d, inst, d.term_idx[t]) * ct_stride + big];
+    body[row] = b;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void keyswitch_mfma_kernel(const int8_t *__restrict__ dig,
+                                                                const int8_t *__restrict__ kpk,
+                                                                const uint64_t *__restrict__ body,
+                                                                uint64_t *__restrict__ ks_out, int ks_stride,
+                                                                int ksteps, int n_wb, int n_small, int count,
+                                                                int steps_per_split, int use_atomic) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rowtile0 = blockIdx.x * 8 + (wave & 1) * 4;  // 16-row tiles of this wave
+  const int wb = blockIdx.y * 2 + (wave >> 1);           // block of 16 key words
+  if (wb >= n_wb) return;                                // (no barriers in this kernel)
+  const int s0 = blockIdx.z * steps_per_split;
+  const int s1 = min(ksteps, s0 + steps_per_split);
+  const ksm_v4i *A = reinterpret_cast<const ksm_v4i *>(dig);
+  const ksm_v4i *Bm = reinterpret_cast<const ksm_v4i *>(kpk);
+  ksm_v4i acc[4][8];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[rt][t] = ksm_v4i{0, 0, 0, 0};
+  ksm_v4i a[4], b[8];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) a[rt] = A[((size_t)(rowtile0 + rt) * ksteps + s0) * 64 + lane];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) b[t] = Bm[(((size_t)s0 * n_wb + wb) * 8 + t) * 64 + lane];
+  for (int s = s0; s < s1; ++s) {
+    ksm_v4i an[4], bn[8];
+    const int sn = s + 1 < s1 ? s + 1 : s;  // the last step re-reads itself (no branch around the loads)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) an[rt] = A[((size_t)(rowtile0 + rt) * ksteps + sn) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bn[t] = Bm[(((size_t)sn * n_wb + wb) * 8 + t) * 64 + lane];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[rt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rt], b[t], acc[rt][t], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) a[rt] = an[rt];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) b[t] = bn[t];
+  }
+  // C layout: column = lane & 15 (the key word), row = (lane >> 4) * 4 + r (the ciphertext)
+  const int word = wb * 16 + (lane & 15);
+  if (word > n_small) return;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = (rowtile0 + rt) * 16 + (lane >> 4) * 4 + r;
+      if (row >= count) continue;
+      uint64_t sum = 0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) sum += (uint64_t)(int64_t)acc[rt][t][r] << (8 * t);
+      uint64_t val = (uint64_t)0 - sum;
+      if (word == n_small && blockIdx.z == 0) val += body[row];
+      uint64_t *dst = ks_out + (size_t)row * ks_stride + word;
+      if (use_atomic) atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)val);
+      else *dst = val;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K5: materialise linear combinations.  grid = nodes, block = 256.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void linear_kernel(NodeDesc d, uint64_t *__restrict__ arena,

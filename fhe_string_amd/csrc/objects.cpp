@@ -40,6 +40,7 @@ static uint64_t ipow(uint64_t b, int e) {
 }
 
 static int ensure_device(fhes_server_key *sk, fhes_ct *c) {
+  if (c->n_blocks == 0) return FHES_OK;  // an empty object owns no rows
   if (c->handle >= 0) {
     if (c->ctx != sk->ctx) return fail(FHES_ERR_INVALID, "ciphertext belongs to another server key");
     return FHES_OK;
@@ -199,6 +200,63 @@ void fhes_ct_destroy(fhes_ct *ct) {
 }
 
 int32_t fhes_ct_num_blocks(const fhes_ct *ct) { return ct ? ct->n_blocks : -1; }
+
+// a new device-resident object made of copies of blocks of other objects (one linear launch)
+static fhes_ct *gather_blocks(fhes_server_key *sk, const std::vector<std::pair<fhes_ct *, int32_t>> &src) {
+  const int32_t n = (int32_t)src.size();
+  auto *c = new fhes_ct;
+  c->n_blocks = n;
+  c->ct_words = Dims(sk->p).ct_words();
+  c->ctx = sk->ctx;
+  if (n == 0) return c;  // an empty object owns no rows
+  for (auto &e : src)
+    if (ensure_device(sk, e.first)) { delete c; return nullptr; }
+  const int32_t h = fhes_arena_alloc(sk->ctx, n);
+  if (h < 0) { delete c; return nullptr; }
+  std::vector<int32_t> term_ptr(n + 1), term_idx(n), outs(n);
+  std::vector<int64_t> coef(n, 1);
+  std::vector<uint64_t> consts(n, 0);
+  for (int32_t i = 0; i < n; i++) {
+    term_ptr[i] = i;
+    term_idx[i] = src[i].first->handle + src[i].second;
+    outs[i] = h + i;
+    c->degree.push_back(src[i].first->degree.empty() ? (uint8_t)(sk->msg_mod - 1) : src[i].first->degree[src[i].second]);
+    c->noise.push_back(src[i].first->noise.empty() ? 1 : src[i].first->noise[src[i].second]);
+  }
+  term_ptr[n] = n;
+  if (fhes_linear_batch(sk->ctx, n, term_ptr.data(), term_idx.data(), coef.data(), consts.data(), outs.data())) {
+    fhes_arena_free(sk->ctx, h, n);
+    delete c;
+    return nullptr;
+  }
+  c->handle = h;
+  return c;
+}
+
+fhes_ct *fhes_ct_slice(fhes_server_key *sk, fhes_ct *ct, int32_t first, int32_t count) {
+  if (!sk || !ct || first < 0 || count < 0 || first + count > ct->n_blocks) {
+    fail(FHES_ERR_INVALID, "slice [%d, %d) outside the object", first, first + count);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(sk->mu);
+  std::vector<std::pair<fhes_ct *, int32_t>> src;
+  for (int32_t i = 0; i < count; i++) src.push_back({ct, first + i});
+  return gather_blocks(sk, src);
+}
+
+fhes_ct *fhes_ct_concat(fhes_server_key *sk, fhes_ct *const *parts, int32_t n_parts) {
+  if (!sk || (!parts && n_parts) || n_parts < 0) {
+    fail(FHES_ERR_INVALID, "bad argument");
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(sk->mu);
+  std::vector<std::pair<fhes_ct *, int32_t>> src;
+  for (int32_t k = 0; k < n_parts; k++) {
+    if (!parts[k]) { fail(FHES_ERR_INVALID, "part %d is NULL", k); return nullptr; }
+    for (int32_t i = 0; i < parts[k]->n_blocks; i++) src.push_back({parts[k], i});
+  }
+  return gather_blocks(sk, src);
+}
 
 static int decrypt_values(const fhes_client_key *ck, fhes_ct *c, std::vector<uint8_t> *vals) {
   int rc = ensure_host(c);
@@ -436,6 +494,12 @@ int fhes_string_op(fhes_server_key *sk, const char *op_in, fhes_ct *const *args,
       shape.push_back(n);
       key += ":v" + std::to_string(n);
       ai += 3;
+      continue;
+    }
+    if (*c == 'L') {  // BooleanBlock per character, one object
+      shape.push_back(args[ai]->n_blocks);
+      key += ":l" + std::to_string(shape.back());
+      ai++;
       continue;
     }
     if (*c == 'C' || *c == 'B') {

@@ -165,6 +165,12 @@ int fhes_debug_phase_profile(fhes_ctx *ctx, int32_t count, int32_t in_handle, do
 /* test hook: keyswitch+modswitch only; a_tilde out is [count][n+1] u32 */
 int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles,
                          uint32_t *a_tilde);
+/* test hook: the keyswitched ciphertexts themselves, words [count][n+1] */
+int fhes_debug_keyswitch_words(fhes_ctx *ctx, int32_t count, const int32_t *in_handles, uint64_t *words);
+/* launches of at least `min_count` ciphertexts run the keyswitch as an i8 matrix product on the matrix
+ * cores (default 1 = always: measured faster at every launch size; 0 = never).  Both forms compute the
+ * same integers. */
+int fhes_set_keyswitch_mfma_min(fhes_ctx *ctx, int32_t min_count);
 
 /* ============================ Level 1: compiled circuits ================================ */
 typedef struct fhes_program fhes_program;
@@ -178,7 +184,9 @@ typedef struct fhes_program fhes_program;
  * start[n][Bu], end[n][Bu] as returned by the split family.  E.g. "find" -> "SS", "splitn" ->
  * "SUS" (self, n, pattern), "replacen" -> "SSSUI", "repeat" -> "SUI" (insert.rs:20),
  * "slices_len" -> "V" (split.rs:32), "slices_get" -> "VSU" (v, v.s, i; split.rs:46),
- * "slices_truncate" -> "VU" (split.rs:86), "slices_reverse" -> "V" (split.rs:229).
+ * "slices_truncate" -> "VU" (split.rs:86), "slices_reverse" -> "V" (split.rs:229), L = one
+ * BooleanBlock per character in one object ("find_pred" / "rfind_pred" -> "L": the index scan of
+ * find_pred_unchecked / rfind_pred_unchecked, search.rs:196-213, over the closure's results).
  * NULL if unknown. */
 const char *fhes_op_signature(const char *op);
 /* Compile a string operation for static shapes (host only, no device needed).
@@ -269,6 +277,13 @@ fhes_ct *fhes_ct_deserialize(const uint8_t *buf, int64_t len);
  * units of one bootstrap output (0 = fresh or trivial encryption); results of fhes_string_op are clean:
  * degree < message modulus (booleans: 1), noise <= 1.  Arrays of fhes_ct_num_blocks entries. */
 int fhes_ct_block_meta(const fhes_ct *ct, uint8_t *degree, uint8_t *noise);
+/* Block-level access for callers that evaluate their own per-character circuits (the closure of
+ * find_pred_unchecked / rfind_pred_unchecked, search.rs:196-213): a new object holding copies of
+ * `count` blocks from `first` (character i of a string = blocks [i*Bc, (i+1)*Bc)), and the
+ * concatenation of objects (e.g. one BooleanBlock per character -> the "L" operand of "find_pred" /
+ * "rfind_pred").  Device-side copies; the caller destroys the result. */
+fhes_ct *fhes_ct_slice(fhes_server_key *sk, fhes_ct *ct, int32_t first, int32_t count);
+fhes_ct *fhes_ct_concat(fhes_server_key *sk, fhes_ct *const *parts, int32_t n_parts);
 /* ServerKey blob (server_key.rs:11 derives serde): the standard-domain key material plus the block counts;
  * deserialising uploads it to `device` (Fourier transform on the device) and needs no client key. */
 int64_t fhes_server_key_serialize(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len);

@@ -168,6 +168,9 @@ def build_inputs(lib, op, args, bu):
             digits.append(np.array([(a["c"] >> (2 * k)) & 3 for k in range(4)], dtype=np.uint8))
         elif c == "B":      # {"b": 0/1}
             digits.append(np.array([int(a["b"])], dtype=np.uint8))
+        elif c == "L":      # {"l": [0/1, ...]} one BooleanBlock per character
+            shape.append(len(a["l"]))
+            digits.append(np.array([int(v) for v in a["l"]], dtype=np.uint8))
         elif c == "V":      # {"v": [(is_some, start, end), ...]}
             v = a["v"]
             shape.append(len(v))
@@ -232,7 +235,7 @@ def decode_result(op, outs, bu, s=None):
     split.rs:208-226)."""
     op = base_op(op)
     outs = [int(v) for v in outs]
-    if op in ("find", "rfind"):
+    if op in ("find", "rfind", "find_pred", "rfind_pred"):
         return radix_value(outs[1:1 + bu]) if outs[0] & 1 else None
     if op == "len":
         return radix_value(outs[:bu])

@@ -415,3 +415,15 @@ def test_logdepth_replace_equals_the_references_loop(libs):
     assert min(seen.values()) > 5, seen
     ref, fast = prog("replace", [65, 4, 2, 60], bu), prog("replace_logdepth", [65, 4, 2, 60], bu)
     assert fast.n_levels * 10 < ref.n_levels and fast.n_pbs * 2 < ref.n_pbs, (fast.n_pbs, ref.n_pbs, fast.n_levels, ref.n_levels)
+
+
+def test_find_pred_scans(libs):
+    """find_pred_unchecked / rfind_pred_unchecked (search.rs:196-213): the index scan over the closure's results"""
+    rnd = random.Random(11)
+    for op in ("find_pred", "rfind_pred", "find_pred_logdepth", "rfind_pred_logdepth"):
+        for n in (0, 1, 2, 7, 33):
+            for _ in range(4):
+                v = [rnd.randint(0, 1) if rnd.random() < 0.8 else 0 for _ in range(n)]
+                hits = [i for i, x in enumerate(v) if x]
+                want = (hits[-1] if op.startswith("r") else hits[0]) if hits else None
+                assert run_ext(op, [{"l": v}])[0] == want, (op, v)

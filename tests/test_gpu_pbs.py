@@ -165,3 +165,59 @@ def test_all_blind_rotate_variants_agree(libs):
         check(w.lib.fhes_set_kernel_variant(ctx, 0))
     check(w.lib.fhes_arena_free(ctx, h_in, count))
     check(w.lib.fhes_arena_free(ctx, h_out, count))
+
+
+def test_keyswitch_on_matrix_cores_equals_valu_keyswitch(w):
+    """wide launches run the keyswitch as an i8 matrix product (v_mfma_i32_16x16x64_i8): same integers as the
+    VALU kernel and as the oracle, word for word; ragged row counts, split digit range, linear combinations"""
+    ctx = w.ctx()
+    n1 = w.n + 1
+    try:
+        for count in (5, 129, 300):
+            rng = np.random.default_rng(count)
+            vals = rng.integers(0, 16, size=count).astype(np.uint8)
+            cts = w.encrypt(vals)
+            h = check(w.lib.fhes_arena_alloc(ctx, count))
+            check(w.lib.fhes_arena_upload(ctx, h, count, ptr(cts)))
+            handles = np.arange(h, h + count, dtype=np.int32)
+            out = {}
+            for mode in (0, 1):
+                check(w.lib.fhes_set_keyswitch_mfma_min(ctx, mode))
+                words = np.zeros((count, n1), dtype=np.uint64)
+                check(w.lib.fhes_debug_keyswitch_words(ctx, count, ptr(handles), ptr(words)))
+                out[mode] = words
+            bad = np.nonzero(out[0] != out[1])
+            assert bad[0].size == 0, f"count {count}: {bad[0].size} words differ, first at row {bad[0][:4]} word {bad[1][:4]}"
+            for i in (0, count - 1):
+                small = np.zeros(n1, dtype=np.uint64)
+                w.orc.oracle_keyswitch(w.oc, ptr(cts[i]), ptr(small))
+                assert np.array_equal(small, out[1][i]), f"row {i} differs from the oracle"
+            check(w.lib.fhes_arena_free(ctx, h, count))
+        # linear combinations 4*x + y + constant through the whole PBS, both keyswitch forms
+        n = 40
+        xs = np.arange(n, dtype=np.uint8) % 3           # 4*x + y + 1 <= 12: inside the message space
+        ys = (np.arange(n, dtype=np.uint8) // 3) % 4
+        cts = w.encrypt(np.concatenate([xs, ys]))
+        h = check(w.lib.fhes_arena_alloc(ctx, 3 * n))
+        check(w.lib.fhes_arena_upload(ctx, h, 2 * n, ptr(cts)))
+        t, _ = w.lut_poly(lambda v: (v + 3) % 16)
+        lid = check(w.lib.fhes_lut_register(ctx, ptr(t), 16))
+        term_ptr = (2 * np.arange(n + 1)).astype(np.int32)
+        term_idx = np.stack([h + np.arange(n), h + n + np.arange(n)], axis=1).reshape(-1).astype(np.int32)
+        term_coef = np.tile(np.array([4, 1], dtype=np.int64), n)
+        consts = np.full(n, np.uint64(1) << np.uint64(59), dtype=np.uint64)   # +1
+        lut_ids = np.full(n, lid, dtype=np.int32)
+        outs = (h + 2 * n + np.arange(n)).astype(np.int32)
+        res = {}
+        for mode in (0, 1):
+            check(w.lib.fhes_set_keyswitch_mfma_min(ctx, mode))
+            check(w.lib.fhes_pbs_batch(ctx, n, ptr(term_ptr), ptr(term_idx), ptr(term_coef), ptr(consts),
+                                       ptr(lut_ids), ptr(outs)))
+            r = np.zeros((n, w.W), dtype=np.uint64)
+            check(w.lib.fhes_arena_download(ctx, h + 2 * n, n, ptr(r)))
+            res[mode] = r
+        assert np.array_equal(res[0], res[1])
+        assert np.array_equal(w.decrypt(res[1]), ((4 * xs + ys + 1 + 3) % 16).astype(np.uint8))
+        check(w.lib.fhes_arena_free(ctx, h, 3 * n))
+    finally:
+        check(w.lib.fhes_set_keyswitch_mfma_min(ctx, 1))

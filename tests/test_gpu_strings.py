@@ -434,3 +434,26 @@ def test_chained_operations_start_from_clean_blocks(which, libs):
         assert max(deg) <= 3 and max(noi) <= 1
     finally:
         sk.close()
+
+
+@pytest.mark.gpu
+def test_find_pred_unchecked_with_caller_side_closures(keys):
+    """search.rs:196-213: the closure runs per character on the caller's side (fhes_ct_slice), its
+    BooleanBlocks are joined (fhes_ct_concat) and scanned on the device ("find_pred" / "rfind_pred")"""
+    ck, sk = keys
+    text = "ab Cd\te"
+    s = api.FheString.new(ck, text, 10)
+    chars = s.chars(sk)
+    assert [c.decrypt(ck) for c in chars] == [ord(c) for c in text] + [0] * 4   # padding to 10 + the terminator
+    assert s.find_pred_unchecked(sk, lambda k, c: c.is_whitespace(k)).decrypt(ck) == 2
+    assert s.rfind_pred_unchecked(sk, lambda k, c: c.is_whitespace(k)).decrypt(ck) == 5
+    assert s.find_pred_unchecked(sk, lambda k, c: c.is_uppercase(k)).decrypt(ck) == 3
+    assert s.rfind_pred_unchecked(sk, lambda k, c: c.is_lowercase(k)).decrypt(ck) == 6
+    assert api.FheString.new(ck, "abc").find_pred_unchecked(sk, lambda k, c: c.is_uppercase(k)).decrypt(ck) is None
+    sk.set_logdepth(True)
+    try:
+        assert s.rfind_pred_unchecked(sk, lambda k, c: c.is_whitespace(k)).decrypt(ck) == 5
+    finally:
+        sk.set_logdepth(False)
+    # the source string is untouched by the slices
+    assert s.decrypt(ck) == text
