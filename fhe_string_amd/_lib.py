@@ -71,7 +71,7 @@ SIGNATURES = {
     "fhes_set_kernel_variant": (C.c_int, [_P, C.c_int32]),
     "fhes_debug_bsk_fourier": (C.c_int, [_P, _P]),
     "fhes_debug_fft_tables": (C.c_int, [_PP, _P, _P]),
-    "fhes_debug_phase_profile": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "fhes_debug_fwd_tables": (C.c_int, [_P, _P, _P]),
     "fhes_debug_keyswitch": (C.c_int, [_P, C.c_int32, _P, _P]),
     "fhes_debug_keyswitch_words": (C.c_int, [_P, C.c_int32, _P, _P]),
     "fhes_set_keyswitch_mfma_min": (C.c_int, [_P, C.c_int32]),

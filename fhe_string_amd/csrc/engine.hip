@@ -48,6 +48,59 @@ void host_fft_tables(int N, std::vector<double> &twist, std::vector<double> &tw)
   if (M >= 4) { tw[2 * (M / 4)] = 0.0; tw[2 * (M / 4) + 1] = -1.0; }
 }
 
+// Tables of the forward transform (same values as the oracle: cosl / sinl in long double, exact entries at
+// the trivial angles).  root[t] = exp(i pi t / N), t < 2N; slot m of a spectrum is the evaluation at
+// root[(1 - 4 bitrev(m)) mod 2N]; psi[2^l + b] = twiddle of block b of the stage with 2^l blocks
+// = (root of the block's first slot)^half; odd_fix[odd m] = square of the last-stage twiddle of m's pair;
+// cdpp[e * M/8 + q] = constant of the lane-pair stage for the point the thread q holds in register e.
+void host_fwd_tables(int N, std::vector<double> &root, std::vector<double> &psi, std::vector<double> &odd_fix,
+                     std::vector<double> &cdpp) {
+  const int M = N / 2, TP = M / 8;
+  int logm = 0;
+  while ((1 << logm) < M) logm++;
+  root.assign((size_t)4 * N, 0.0);
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int t = 0; t < 2 * N; t++) {
+    const long double a = pi * (long double)t / (long double)N;
+    root[2 * t] = (double)cosl(a);
+    root[2 * t + 1] = (double)sinl(a);
+  }
+  root[0] = 1.0; root[1] = 0.0;
+  root[2 * (N / 2)] = 0.0; root[2 * (N / 2) + 1] = 1.0;
+  root[2 * N] = -1.0; root[2 * N + 1] = 0.0;
+  root[2 * (3 * N / 2)] = 0.0; root[2 * (3 * N / 2) + 1] = -1.0;
+  auto slot_exp = [&](int m) {
+    int f = 0;
+    for (int b = 0; b < logm; b++) f |= ((m >> b) & 1) << (logm - 1 - b);
+    return (long)((((1 - 4 * f) % (2 * N)) + 2 * N) % (2 * N));
+  };
+  psi.assign((size_t)2 * M, 0.0);
+  odd_fix.assign((size_t)2 * M, 0.0);
+  for (int l = 0; l < logm; l++) {
+    const int nb = 1 << l, half = M >> (l + 1);
+    for (int b = 0; b < nb; b++) {
+      const long e = (slot_exp(b * 2 * half) * half) % (2 * N);
+      psi[2 * (nb + b)] = root[2 * e];
+      psi[2 * (nb + b) + 1] = root[2 * e + 1];
+      if (half == 1) {
+        const long e2 = (2 * e) % (2 * N);
+        odd_fix[2 * (2 * b)] = 1.0;
+        odd_fix[2 * (2 * b + 1)] = root[2 * e2];
+        odd_fix[2 * (2 * b + 1) + 1] = root[2 * e2 + 1];
+      }
+    }
+  }
+  cdpp.assign((size_t)2 * M, 0.0);
+  const int LO = logm - 3 * ((logm - 1) / 3);  // the last 3-bit pass owns index bits [LO, LO + 3); LO = 1
+  for (int e = 0; e < 8; e++)
+    for (int q = 0; q < TP; q++) {
+      const int p = ((q >> LO) << (LO + 3)) | (e << LO) | (q & ((1 << LO) - 1));  // dev::fft_point<LOGM, LO, 3>
+      const double tre = psi[2 * (M / 2 + p / 2)], tim = psi[2 * (M / 2 + p / 2) + 1];
+      cdpp[2 * ((size_t)e * TP + q)] = (p & 1) ? -tre : tre;
+      cdpp[2 * ((size_t)e * TP + q) + 1] = tim;
+    }
+}
+
 static bool kernels_support(const fhes_params &p, std::string *why) {
   if (p.glwe_dim != 1) { *why = "HIP kernels support glwe_dim == 1 only"; return false; }
   if (p.pbs_level != 1) { *why = "HIP kernels support pbs_level == 1 only"; return false; }
@@ -275,42 +328,7 @@ static int launch_br_v1(fhes_ctx *ctx, const dev::NodeDesc &d) {
   }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_f,
-                     ctx->lut_polys, ctx->twist, ctx->tw);
-  FHES_HIP(hipGetLastError());
-  return FHES_OK;
-}
-
-template <int LOGN>
-static int launch_br_v2(fhes_ctx *ctx, const dev::NodeDesc &d) {
-  constexpr int N = 1 << LOGN, M = N / 2;
-  const size_t lds = (size_t)2 * N * 8 + (size_t)4 * M * 16 + (size_t)((ctx->dims.n + 1 + 3) & ~3) * 4;
-  auto kern = dev::blind_rotate_v2_kernel<LOGN, 23>;
-  if (!(ctx->attr_done & (1u << 2))) {  // per context: the attribute is per device
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ctx->attr_done |= 1u << 2;
-  }
-  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
-                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
-                     ctx->lut_polys, ctx->twist, ctx->tw);
-  FHES_HIP(hipGetLastError());
-  return FHES_OK;
-}
-
-template <int LOGN, bool DIAG>
-static int launch_br_v3(fhes_ctx *ctx, const dev::NodeDesc &d, unsigned long long *diag = nullptr) {
-  constexpr int N = 1 << LOGN, M = N / 2;
-  const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)(M / 2) * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_v3_kernel<LOGN, 23, DIAG>;
-  const unsigned bit = DIAG ? 4 : 3;
-  if (!(ctx->attr_done & (1u << bit))) {  // per context: the attribute is per device
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ctx->attr_done |= 1u << bit;
-  }
-  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
-                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
-                     ctx->lut_polys, ctx->twist, ctx->twist_inv, ctx->tw, diag);
+                     ctx->lut_polys, ctx->twist, ctx->tw, ctx->psi);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
@@ -321,7 +339,7 @@ static int launch_br_mb(fhes_ctx *ctx, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const int n_deg = (ctx->dims.n / G) * ((1 << G) - 1);
   constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
-  const size_t lds = (size_t)2 * SLOTS * 16 + (size_t)M * 16 + (size_t)((n_deg + 7) & ~7) * 2;
+  const size_t lds = (size_t)2 * SLOTS * 16 + (size_t)M * 16 + (size_t)(M / 2) * 16 + (size_t)M * 16 + (size_t)((n_deg + 7) & ~7) * 2;
   auto kern = dev::blind_rotate_mb_kernel<LOGN, BL, G, PIPE, LAT>;
   const unsigned bit = 8 + 4 * (G - 2) + (PIPE ? 1 : 0) + (LAT ? 2 : 0);  // per context: one base per parameter set
   if (!(ctx->attr_done & (1u << bit))) {
@@ -331,25 +349,7 @@ static int launch_br_mb(fhes_ctx *ctx, const dev::NodeDesc &d) {
   }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
-                     ctx->lut_polys, ctx->twist, ctx->twist_inv, ctx->tw, ctx->root);
-  FHES_HIP(hipGetLastError());
-  return FHES_OK;
-}
-
-template <int LOGN>
-static int launch_br_v4(fhes_ctx *ctx, const dev::NodeDesc &d) {
-  constexpr int N = 1 << LOGN, M = N / 2;
-  constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
-  const size_t lds = (size_t)2 * N * 8 + (size_t)2 * SLOTS * 16 + (size_t)(M / 2) * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_v4_kernel<LOGN, 23>;
-  if (!(ctx->attr_done & (1u << 5))) {
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ctx->attr_done |= 1u << 5;
-  }
-  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
-                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
-                     ctx->lut_polys, ctx->twist, ctx->twist_inv, ctx->tw);
+                     ctx->lut_polys, ctx->twist_inv, ctx->tw, ctx->root, ctx->psi, ctx->cdpp);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
@@ -359,7 +359,7 @@ static int launch_br_v5(fhes_ctx *ctx, const dev::NodeDesc &d) {
   if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_v5<LOGN, PRIO, 18>(ctx, d);
   constexpr int N = 1 << LOGN, M = N / 2;
   constexpr int SLOTS = M;
-  const size_t lds = (size_t)2 * N * 8 + (size_t)2 * SLOTS * 16 + (size_t)(M / 2) * 16 + (size_t)((ctx->dims.n + 1 + 7) & ~7) * 2;
+  const size_t lds = (size_t)2 * N * 8 + (size_t)2 * SLOTS * 16 + (size_t)2 * (M / 2) * 16;  // N = 2048: exactly 80 KB, two per CU
   auto kern = dev::blind_rotate_v5_kernel<LOGN, BL, PRIO>;
   if (!(ctx->attr_done & (1u << (20 + PRIO)))) {
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -368,13 +368,13 @@ static int launch_br_v5(fhes_ctx *ctx, const dev::NodeDesc &d) {
   }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
                      ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
-                     ctx->lut_polys, ctx->twist, ctx->twist_inv, ctx->tw);
+                     ctx->lut_polys, ctx->twist_inv, ctx->tw, ctx->psi, ctx->cdpp);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
 
-// variant: 0 = auto (variant 5), 1..7 = force (1 simple, 2 register-resident latency build, 3 / 4 earlier
-// throughput builds, 5 current, 6 / 7 = 5 with other wave-priority policies); all produce the same bits
+// variant: 0 = auto (variant 5), 1 = the simple kernel, 5 = the throughput kernel, 6 / 7 = 5 with other
+// wave-priority policies; all produce the same bits.  (Variants 2-4 of earlier rounds are gone.)
 static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
   if (ctx->dims.g > 1) {
     // multi-bit parameter sets: one kernel in three builds -- latency (launches of at most one
@@ -387,16 +387,13 @@ static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
     return lat ? launch_br_mb<8, 2, true, true>(ctx, d) : launch_br_mb<8, 2, false>(ctx, d);
   }
   int variant = ctx->br_variant;
-  if (ctx->dims.pbs_base_log != 23 && variant != 0 && (variant < 5 || variant > 7))
-    return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variants 1-4 are instantiated for pbs_base_log 23 only");
-  // auto: variant 5 for every launch size (measured round 2: 3.26 ms for <= 256 ciphertexts against
-  // 3.39 ms of the register-resident latency build, 120 k against 114.6 k PBS/s of variant 4 in wide launches)
-  if (variant == 0) variant = 5;
+  if (variant == 0) variant = 5;  // every launch size
+  if (variant != 1 && (variant < 5 || variant > 7)) return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d does not exist (1, 5, 6, 7)", variant);
+  if (ctx->dims.pbs_base_log != 23 && variant == 1)
+    return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant 1 is instantiated for pbs_base_log 23 only");
   if (ctx->dims.N == 2048)
-    return variant == 1 ? launch_br_v1<11>(ctx, d) : variant == 2 ? launch_br_v2<11>(ctx, d)
-         : variant == 4 ? launch_br_v4<11>(ctx, d) : variant == 5 ? launch_br_v5<11>(ctx, d) : variant == 6 ? launch_br_v5<11, 1>(ctx, d) : variant == 7 ? launch_br_v5<11, 2>(ctx, d) : launch_br_v3<11, false>(ctx, d);
-  return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 2 ? launch_br_v2<8>(ctx, d)
-       : variant == 4 ? launch_br_v4<8>(ctx, d) : variant == 5 ? launch_br_v5<8>(ctx, d) : variant == 6 ? launch_br_v5<8, 1>(ctx, d) : variant == 7 ? launch_br_v5<8, 2>(ctx, d) : launch_br_v3<8, false>(ctx, d);
+    return variant == 1 ? launch_br_v1<11>(ctx, d) : variant == 5 ? launch_br_v5<11>(ctx, d) : variant == 6 ? launch_br_v5<11, 1>(ctx, d) : launch_br_v5<11, 2>(ctx, d);
+  return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 5 ? launch_br_v5<8>(ctx, d) : variant == 6 ? launch_br_v5<8, 1>(ctx, d) : launch_br_v5<8, 2>(ctx, d);
 }
 
 static int take_event(fhes_ctx *ctx, hipEvent_t *e) {
@@ -578,20 +575,17 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
     if ((e = hipMalloc(&ctx->twist_inv, ti.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(twist_inv)");
     if ((e = hipMemcpy(ctx->twist_inv, ti.data(), ti.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy twist_inv");
   }
-  if (d.g > 1) {  // Fourier images of monomials (oracle: same cosl/sinl, same exact entries)
-    std::vector<double> root((size_t)4 * d.N);
-    const long double pi = 3.14159265358979323846264338327950288L;
-    for (int t = 0; t < 2 * d.N; t++) {
-      const long double a = pi * (long double)t / (long double)d.N;
-      root[2 * t] = (double)cosl(a);
-      root[2 * t + 1] = (double)sinl(a);
-    }
-    root[0] = 1.0; root[1] = 0.0;
-    root[2 * (d.N / 2)] = 0.0; root[2 * (d.N / 2) + 1] = 1.0;
-    root[2 * d.N] = -1.0; root[2 * d.N + 1] = 0.0;
-    root[2 * (3 * d.N / 2)] = 0.0; root[2 * (3 * d.N / 2) + 1] = -1.0;
+  {  // forward-transform tables; root also gives the Fourier images of monomials (multi-bit)
+    std::vector<double> root, psi, odd_fix, cdpp;
+    host_fwd_tables(d.N, root, psi, odd_fix, cdpp);
     if ((e = hipMalloc(&ctx->root, root.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(root)");
     if ((e = hipMemcpy(ctx->root, root.data(), root.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy root");
+    if ((e = hipMalloc(&ctx->psi, psi.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(psi)");
+    if ((e = hipMemcpy(ctx->psi, psi.data(), psi.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy psi");
+    if ((e = hipMalloc(&ctx->odd_fix, odd_fix.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(odd_fix)");
+    if ((e = hipMemcpy(ctx->odd_fix, odd_fix.data(), odd_fix.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy odd_fix");
+    if ((e = hipMalloc(&ctx->cdpp, cdpp.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(cdpp)");
+    if ((e = hipMemcpy(ctx->cdpp, cdpp.data(), cdpp.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy cdpp");
   }
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
@@ -611,7 +605,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
-  (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->root); (void)hipFree(ctx->lut_polys);
+  (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->root); (void)hipFree(ctx->psi); (void)hipFree(ctx->odd_fix); (void)hipFree(ctx->cdpp); (void)hipFree(ctx->lut_polys);
   (void)hipFree(ctx->ks_out); (void)hipFree(ctx->ks_dig); (void)hipFree(ctx->ks_body); (void)hipFree(ctx->ksk_pk); (void)hipFree(ctx->desc_buf);
   for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
   for (auto &ev : ctx->ev_free) (void)hipEventDestroy(ev);
@@ -672,9 +666,9 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
     if (!ctx->bsk_f) FHES_HIP(hipMalloc(&ctx->bsk_f, npoly * d.M * 16));
     const size_t lds = (size_t)d.M * 16;
     if (d.N == 2048)
-      hipLaunchKernelGGL((dev::bsk_to_fourier_kernel<11>), dim3(npoly), dim3(d.M / 8), lds, ctx->stream, tmp, ctx->bsk_f, ctx->twist, ctx->tw);
+      hipLaunchKernelGGL((dev::bsk_to_fourier_kernel<11>), dim3(npoly), dim3(d.M / 8), lds, ctx->stream, tmp, ctx->bsk_f, ctx->psi, ctx->odd_fix);
     else
-      hipLaunchKernelGGL((dev::bsk_to_fourier_kernel<8>), dim3(npoly), dim3(d.M / 8), lds, ctx->stream, tmp, ctx->bsk_f, ctx->twist, ctx->tw);
+      hipLaunchKernelGGL((dev::bsk_to_fourier_kernel<8>), dim3(npoly), dim3(d.M / 8), lds, ctx->stream, tmp, ctx->bsk_f, ctx->psi, ctx->odd_fix);
     FHES_HIP(hipGetLastError());
     if (!ctx->bsk_e) FHES_HIP(hipMalloc(&ctx->bsk_e, npoly * d.M * 16));
     if (d.N == 2048)
@@ -810,6 +804,15 @@ int fhes_debug_bsk_fourier(fhes_ctx *ctx, double *out) {
   return FHES_OK;
 }
 
+int fhes_debug_fwd_tables(const fhes_params *p, double *psi, double *odd_fix) {
+  if (!p || !psi || !odd_fix) return fail(FHES_ERR_INVALID, "null argument");
+  std::vector<double> root, a, b, c;
+  host_fwd_tables(p->poly_size, root, a, b, c);
+  memcpy(psi, a.data(), a.size() * 8);
+  memcpy(odd_fix, b.data(), b.size() * 8);
+  return FHES_OK;
+}
+
 int fhes_debug_fft_tables(const fhes_params *p, double *twist, double *tw) {
   if (!p || !twist || !tw) return fail(FHES_ERR_INVALID, "null argument");
   std::vector<double> a, b;
@@ -817,59 +820,6 @@ int fhes_debug_fft_tables(const fhes_params *p, double *twist, double *tw) {
   memcpy(twist, a.data(), a.size() * 8);
   memcpy(tw, b.data(), b.size() * 8);
   return FHES_OK;
-}
-
-// Developer hook: runs the throughput blind-rotate kernel in its DIAGNOSTIC build (s_memtime
-// stamps at every phase / barrier boundary) on `count` copies of a bootstrap of `in_handle` and
-// returns the average shader cycles per CMUX iteration spent in each of the 17 phases
-// (out[17]; order as FHES_STAMP in kernels.hip.h).  Never used by the product path.
-int fhes_debug_phase_profile(fhes_ctx *ctx, int32_t count, int32_t in_handle, double *out) {
-  if (!ctx || !out || count <= 0 || in_handle < 0 || in_handle >= ctx->capacity) return fail(FHES_ERR_INVALID, "bad argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  FHES_HIP(hipSetDevice(ctx->device));
-  if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
-  if (ctx->dims.N != 2048) return fail(FHES_ERR_UNSUPPORTED, "phase profile is built for N = 2048");
-  if (ctx->lut_tables.empty()) {
-    std::vector<uint64_t> t(ctx->dims.space());
-    for (size_t i = 0; i < t.size(); i++) t[i] = i;
-    if (lut_register_locked(ctx, t.data(), (int32_t)t.size()) < 0) return FHES_ERR_STATE;
-  }
-  const int32_t scratch = arena_alloc_locked(ctx, count);
-  if (scratch < 0) return scratch;
-  std::vector<int32_t> tp(count + 1), ti(count, in_handle), lut(count, 0), outh(count);
-  std::vector<int64_t> tc(count, 1);
-  std::vector<uint64_t> cs(count, 0);
-  for (int i = 0; i <= count; i++) tp[i] = i;
-  for (int i = 0; i < count; i++) outh[i] = scratch + i;
-  DevNodeArrays a;
-  int rc = stage_desc(ctx, count, tp.data(), ti.data(), tc.data(), cs.data(), lut.data(), outh.data(), &a);
-  if (rc == FHES_OK) rc = ensure_ks_out(ctx, count);
-  unsigned long long *diag = nullptr;
-  const size_t words = (size_t)count * 4 * 17;
-  if (rc == FHES_OK) {
-    dev::NodeDesc d = make_desc(a, 0, count, 0, count);
-    rc = launch_keyswitch(ctx, d);
-    if (rc == FHES_OK) {
-      hipError_t e = hipMalloc(&diag, words * 8);
-      if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(diag)");
-    }
-    if (rc == FHES_OK) rc = launch_br_v3<11, true>(ctx, d, diag);
-  }
-  if (rc == FHES_OK) {
-    std::vector<unsigned long long> h(words);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(h.data(), diag, words * 8, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = hip_fail(e, "diag copy");
-    else {
-      for (int k = 0; k < 17; k++) out[k] = 0;
-      for (size_t w = 0; w < (size_t)count * 4; w++)
-        for (int k = 0; k < 17; k++) out[k] += (double)h[w * 17 + k];
-      for (int k = 0; k < 17; k++) out[k] /= (double)count * 4 * ctx->dims.n;
-    }
-  }
-  if (diag) (void)hipFree(diag);
-  arena_free_locked(ctx, scratch, count);
-  return rc;
 }
 
 int fhes_set_keyswitch_mfma_min(fhes_ctx *ctx, int32_t min_count) {

@@ -6,8 +6,9 @@
 // rotate (n CMUX with the external product in the f64 Fourier domain) -> sample
 // extract.  The arithmetic follows the canonical op sequence of DESIGN.md section 4
 // (same as oracle/tfhe_oracle.c), so outputs are bit-identical to the oracle:
-//   * radix-2 DIF forward / DIT inverse FFT of N/2 complex points, twiddles from
-//     tables, complex multiply = {mul, fma, mul, fma} exactly as written below;
+//   * forward transform: radix-2 Cooley-Tukey stages with the negacyclic twist merged into the
+//     twiddles (natural order in, bit-reversed out; fused butterfly s = u + t v, d = 2u - s);
+//     inverse: radix-2 DIT (bit-reversed in, natural out) + untwist; twiddles from tables;
 //   * -ffp-contract=off: every FMA is explicit.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -108,6 +109,35 @@ __device__ __forceinline__ void inv_butterfly(double2 &a, double2 &b, double2 w)
   b = make_double2(__builtin_fma(2.0, u.x, -sre), __builtin_fma(2.0, u.y, -sim));
 }
 
+// forward (Cooley-Tukey, twist merged into the twiddles): s = u + t v in 4 FMAs, d = 2u - s in 2
+__device__ __forceinline__ void fwd_butterfly(double2 &a, double2 &b, double2 t) {
+  const double2 u = a, v = b;
+  double sre = __builtin_fma(t.x, v.x, u.x);
+  sre = __builtin_fma(-t.y, v.y, sre);
+  double sim = __builtin_fma(t.x, v.y, u.y);
+  sim = __builtin_fma(t.y, v.x, sim);
+  a = make_double2(sre, sim);
+  b = make_double2(__builtin_fma(2.0, u.x, -sre), __builtin_fma(2.0, u.y, -sim));
+}
+// last forward stage (adjacent slots): the even slot gets s = u + t v, the odd slot HOLDS h = v + t' u with
+// t' = (-t.x, t.y) = -conj(t), the true value u - t v divided by -t.  A lane pair computes both as
+// own + c * partner (fft_fwd_stage0_dpp); the Fourier key carries t^2 on its odd slots (bsk_to_fourier_kernel).
+__device__ __forceinline__ void fwd_butterfly_last(double2 &a, double2 &b, double2 t) {
+  const double2 u = a, v = b;
+  double sre = __builtin_fma(t.x, v.x, u.x);
+  sre = __builtin_fma(-t.y, v.y, sre);
+  double sim = __builtin_fma(t.x, v.y, u.y);
+  sim = __builtin_fma(t.y, v.x, sim);
+  double hre = __builtin_fma(-t.x, u.x, v.x);
+  hre = __builtin_fma(-t.y, u.y, hre);
+  double him = __builtin_fma(-t.x, u.y, v.y);
+  him = __builtin_fma(t.y, u.x, him);
+  a = make_double2(sre, sim);
+  b = make_double2(hre, him);
+}
+
+// FWD: tw = psi (psi[2^l + b]: block b of the stage with 2^l blocks, l = LOGM-1-beta);
+// inverse: tw = exp(-2 pi i t / M) table
 template <int LOGM, bool FWD, int LO, int NB>
 __device__ __forceinline__ void fft_butterflies(double2 (&x)[8], int q,
                                                 const double2 *__restrict__ tw) {
@@ -115,25 +145,22 @@ __device__ __forceinline__ void fft_butterflies(double2 (&x)[8], int q,
   for (int st = 0; st < NB; ++st) {
     const int fb = FWD ? (NB - 1 - st) : st;
     const int beta = LO + fb;           // absolute index bit of this stage
-    const int sh = LOGM - 1 - beta;     // twiddle stride = 2^sh
+    const int sh = LOGM - 1 - beta;     // inverse: twiddle stride = 2^sh; forward: the stage has 2^sh blocks
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       if (e & (1 << fb)) continue;
       const int e1 = e | (1 << fb);
-      const double2 u = x[e], v = x[e1];
-      if (beta == 0) {  // twiddle index 0: exactly 1
+      const int p = fft_point<LOGM, LO, NB>(q, e);
+      if (FWD) {
+        const double2 t = tw[(1 << sh) + (p >> (beta + 1))];
+        if (beta == 0) fwd_butterfly_last(x[e], x[e1], t);
+        else fwd_butterfly(x[e], x[e1], t);
+      } else if (beta == 0) {  // twiddle index 0: exactly 1
+        const double2 u = x[e], v = x[e1];
         x[e] = make_double2(u.x + v.x, u.y + v.y);
         x[e1] = make_double2(u.x - v.x, u.y - v.y);
       } else {
-        const int p = fft_point<LOGM, LO, NB>(q, e);
-        const double2 w = tw[(p & ((1 << beta) - 1)) << sh];
-        if (FWD) {
-          const double2 d = make_double2(u.x - v.x, u.y - v.y);
-          x[e] = make_double2(u.x + v.x, u.y + v.y);
-          x[e1] = cmul(d, w);
-        } else {
-          inv_butterfly(x[e], x[e1], w);
-        }
+        inv_butterfly(x[e], x[e1], tw[(p & ((1 << beta) - 1)) << sh]);
       }
     }
   }
@@ -187,8 +214,8 @@ __device__ __forceinline__ void fft_inverse(double2 (&x)[8], int q, double2 *buf
 // ------------------------------------------------------------------------------------------
 template <int LOGN>
 __global__ void bsk_to_fourier_kernel(const uint64_t *__restrict__ bsk, double2 *__restrict__ out,
-                                      const double2 *__restrict__ twist,
-                                      const double2 *__restrict__ tw) {
+                                      const double2 *__restrict__ psi,
+                                      const double2 *__restrict__ odd_fix) {
   constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double2 *buf = reinterpret_cast<double2 *>(smem_raw);
@@ -198,12 +225,13 @@ __global__ void bsk_to_fourier_kernel(const uint64_t *__restrict__ bsk, double2 
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);
-    const double2 a = make_double2(i64_to_f64(poly[p]), i64_to_f64(poly[p + M]));
-    x[e] = cmul(a, twist[p]);
+    x[e] = make_double2(i64_to_f64(poly[p]), i64_to_f64(poly[p + M]));
   }
-  fft_forward<LOGM, LOGM>(x, q, buf, tw);
+  fft_forward<LOGM, LOGM>(x, q, buf, psi);
+  // odd slots: times the square of the last-stage twiddle (see fwd_butterfly_last), so that the product
+  // of this spectrum with a digit spectrum in the same internal form is the true product
   double2 *dst = out + (size_t)blockIdx.x * M;
-  for (int p = q; p < M; p += blockDim.x) dst[p] = buf[p];
+  for (int p = q; p < M; p += blockDim.x) dst[p] = (p & 1) ? cmul(buf[p], odd_fix[p]) : buf[p];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -512,7 +540,8 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
                                        int n_small, const double2 *__restrict__ bsk_f,
                                        const uint64_t *__restrict__ lut_polys,
                                        const double2 *__restrict__ twist,
-                                       const double2 *__restrict__ tw) {
+                                       const double2 *__restrict__ tw,
+                                       const double2 *__restrict__ psi) {
   constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
   constexpr int NB0 = FftPlan<LOGM>::NB_LAST;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -551,16 +580,16 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
     const int a = (int)at[i];
     if (a == 0) continue;  // X^0*acc - acc == 0: exact no-op (uniform branch)
 
-    // ---- diff -> digit -> twist, in the layout of the first forward pass ----
+    // ---- diff -> digit, in the layout of the first forward pass (the twist lives in the twiddles) ----
     double2 x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);
       const uint64_t d0 = rot_read<N>(acc_r, a, p) - acc_r[p];
       const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - acc_r[p + M];
-      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twist[p]);
+      x[e] = make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1));
     }
-    fft_forward<LOGM, LOGM>(x, q, buf_r, tw);  // ends with a barrier: both spectra in fbuf
+    fft_forward<LOGM, LOGM>(x, q, buf_r, psi);  // ends with a barrier: both spectra in fbuf
 
     // ---- external product: O_r = D_0 * G[0][r] + D_1 * G[1][r] ----
     const double2 *G = bsk_f + (size_t)i * 4 * M;  // [row][col][M]
@@ -607,17 +636,13 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
 }
 
 // ------------------------------------------------------------------------------------------
-// K2+K3 (variant 2): latency-oriented blind rotate.  Same arithmetic as variant 1 (so the
-// same bits), different mapping:
-//   * twiddles / twists of every pass and the thread's own accumulator coefficients live
-//     in registers for the whole kernel (one workgroup per CU -> 512 VGPRs per lane);
-//   * the GGSW of iteration i is fetched into registers at the top of the iteration from a
-//     lane-coalesced "engine layout" [i][row][col][e][q] and is consumed after the forward FFT;
-//   * the last radix-2 stage (index bit 0 = lane bit 0) runs on DPP quad permutes, so a
-//     transform needs 2 LDS exchanges instead of 3 (N = 2048);
-//   * LDS exchange buffers are XOR-swizzled (conflict-free ds_read/write_b128 in all passes).
+// Shared pieces of the throughput kernels (variant 5, multi-bit): 128 threads x 8 points per
+// polynomial, three register passes of 3 index bits + one lane-pair stage on index bit 0 (DPP),
+// XOR-swizzled LDS exchange buffers (conflict-free ds_read/write_b128 in every pass layout).
 // Requires (log2(N) - 1) % 3 == 1  (N = 2048, N = 256).
-// LDS: acc u64[2][N] | fbuf double2[2][M] | dx double2[2][M] | a_tilde
+// (Round 1 / early round 2 carried three more builds of the classic kernel -- a register-resident
+// latency build and two earlier throughput builds, variants 2-4, with a phase-stamped diagnostic
+// build: all slower than variant 5 at every launch size; they went when the forward transform changed.)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int fswz(int p) { return p ^ (((p >> 4) & 7) << 1); }
 
@@ -628,7 +653,22 @@ __device__ __forceinline__ double dpp_swap1(double v) {  // value of lane ^ 1
   return __hiloint2double(hi, lo);
 }
 
-// radix-2 stage on index bit 0 across lane pairs (twiddle index 0: exactly 1), DIF == DIT
+// last FORWARD stage (index bit 0) across lane pairs: own + c * partner with the per-lane constant
+// c = t on even lanes (s = u + t v) and (-t.x, t.y) on odd lanes (h = v + t' u): the FMA sequence of
+// fwd_butterfly_last on both.
+__device__ __forceinline__ void fft_fwd_stage0_dpp(double2 (&x)[8], const double2 (&c)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const double px = dpp_swap1(x[e].x), py = dpp_swap1(x[e].y);
+    double re = __builtin_fma(c[e].x, px, x[e].x);
+    re = __builtin_fma(-c[e].y, py, re);
+    double im = __builtin_fma(c[e].x, py, x[e].y);
+    im = __builtin_fma(c[e].y, px, im);
+    x[e] = make_double2(re, im);
+  }
+}
+
+// first INVERSE stage on index bit 0 across lane pairs (twiddle index 0: exactly 1)
 // sgn = +1.0 on even lanes, -1.0 on odd lanes: fma(own, sgn, partner) is own + partner (u + v)
 // resp. partner - own (u - v), correctly rounded like the add / sub it replaces.
 __device__ __forceinline__ void fft_stage_bit0_dpp(double2 (&x)[8], double sgn) {
@@ -653,8 +693,11 @@ __device__ __forceinline__ double2 ext_mac(double2 D0, double2 D1, double2 g0, d
   return make_double2(re, im);
 }
 
-// butterflies of a 3-bit pass with the 7 twiddles held in registers:
-// w[0..3] for the top bit (by e & 3), w[4..5] for the middle bit (by e & 1), w[6] for the low bit
+// butterflies of a 3-bit pass with the 7 twiddles held in registers.
+// inverse: w[0..3] for the top bit (by e & 3), w[4..5] for the middle bit (by e & 1), w[6] for the low bit
+//          (a twiddle depends on the index bits BELOW the stage's bit);
+// forward: w[0] for the top bit, w[1..2] for the middle bit (by e >> 2), w[3..6] for the low bit (by e >> 1)
+//          (a twiddle depends on the block, i.e. the index bits ABOVE the stage's bit)
 template <bool FWD>
 __device__ __forceinline__ void fft_butterflies_reg(double2 (&x)[8], const double2 (&w)[7]) {
 #pragma unroll
@@ -664,17 +707,27 @@ __device__ __forceinline__ void fft_butterflies_reg(double2 (&x)[8], const doubl
     for (int e = 0; e < 8; ++e) {
       if (e & (1 << fb)) continue;
       const int e1 = e | (1 << fb);
-      const double2 tw = fb == 2 ? w[e & 3] : (fb == 1 ? w[4 + (e & 1)] : w[6]);
-      const double2 u = x[e], v = x[e1];
       if (FWD) {
-        const double2 d = make_double2(u.x - v.x, u.y - v.y);
-        x[e] = make_double2(u.x + v.x, u.y + v.y);
-        x[e1] = cmul(d, tw);
+        fwd_butterfly(x[e], x[e1], fb == 2 ? w[0] : (fb == 1 ? w[1 + (e >> 2)] : w[3 + (e >> 1)]));
       } else {
-        inv_butterfly(x[e], x[e1], tw);
+        inv_butterfly(x[e], x[e1], fb == 2 ? w[e & 3] : (fb == 1 ? w[4 + (e & 1)] : w[6]));
       }
     }
   }
+}
+
+// the 7 forward twiddles of the 3-bit pass that owns index bits [LO, LO+3) from a table laid out like psi
+// (T[2^l + b]); h = q >> LO are the index bits above the pass.  Pass A (LO = LOGM-3) has h = 0 for every
+// thread: uniform addresses.
+template <int LOGM, int LO>
+__device__ __forceinline__ void load_fwd_twiddles(double2 (&w)[7], int q, const double2 *T) {
+  constexpr int L0 = LOGM - 3 - LO;
+  const int h = q >> LO;
+  w[0] = T[(1 << L0) + h];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) w[1 + k] = T[(2 << L0) + 2 * h + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[3 + k] = T[(4 << L0) + 4 * h + k];
 }
 
 template <int LOGM, int LO>
@@ -690,403 +743,6 @@ __device__ __forceinline__ void load_pass_twiddles(double2 (&w)[7], int q, const
   }
 }
 
-template <int LOGN, int BL>
-__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 1) void blind_rotate_v2_kernel(
-    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
-    int ks_stride, int n_small, const double2 *__restrict__ bsk_e /* engine layout */,
-    const uint64_t *__restrict__ lut_polys, const double2 *__restrict__ twist,
-    const double2 *__restrict__ tw) {
-  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
-  constexpr int NP = (LOGM - 1) / 3;  // number of 3-bit passes (bit 0 is the DPP stage)
-  static_assert(LOGM % 3 == 1, "variant 2 needs log2(N/2) % 3 == 1");
-  static_assert(NP == 2 || NP == 3, "supported: N = 256, N = 2048");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                                      // [2][N]
-  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);                   // [2][M]
-  double2 *dx = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16);  // [2][8][TP]
-  uint32_t *at = reinterpret_cast<uint32_t *>(smem_raw + (size_t)2 * N * 8 + (size_t)4 * M * 16);
-
-  const int tid = threadIdx.x;
-  const int r = tid / TP;
-  const int q = tid % TP;
-  const double sgn = (q & 1) ? -1.0 : 1.0;
-  const int vidx = d.v0 + blockIdx.x;
-  const int inst = vidx / d.count, node = d.first + vidx % d.count;
-
-  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
-  for (int j = tid; j <= n_small; j += blockDim.x)
-    at[j] = (uint32_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
-  __syncthreads();
-
-  // pass layouts: pass k (k = 0 .. NP-1) owns index bits [LOGM-3-3k, LOGM-3k)
-  constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
-  double2 wA[7], wB[7], wC[7], twr[8];
-  load_pass_twiddles<LOGM, LO_A>(wA, q, tw);
-  load_pass_twiddles<LOGM, LO_B>(wB, q, tw);
-  if (NP == 3) load_pass_twiddles<LOGM, LO_C>(wC, q, tw);
-  double2 twi[8];  // conj-untwist factors pre-scaled by 1/M (power of two: exact, same bits)
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    twr[e] = twist[fft_point<LOGM, LO_A, 3>(q, e)];
-    twi[e] = make_double2(twr[e].x * (1.0 / (double)M), twr[e].y * (1.0 / (double)M));
-  }
-
-  // ---- acc = (0, X^{-b~} * LUT); own coefficients also kept in registers ----
-  uint64_t own_lo[8], own_hi[8];  // coefficients p and p + M of polynomial r
-  {
-    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
-    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      uint64_t v0 = 0, v1 = 0;
-      if (r == 1) {
-        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
-        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
-      }
-      own_lo[e] = v0;
-      own_hi[e] = v1;
-      acc[(size_t)r * N + p] = v0;
-      acc[(size_t)r * N + p + M] = v1;
-    }
-  }
-  __syncthreads();
-
-  const uint64_t *acc_r = acc + (size_t)r * N;
-  double2 *buf_r = fbuf + (size_t)r * M;
-
-  int a_next = (int)at[0];
-  for (int i = 0; i < n_small; ++i) {
-    const int a = a_next;
-    a_next = (int)at[i + 1];  // requested one iteration ahead: off the critical path (at has n+1 entries)
-    if (a == 0) continue;
-
-    // ---- prefetch this iteration's GGSW column r (consumed after the forward FFT) ----
-    double2 g0[8], g1[8];
-    {
-      const double2 *G = bsk_e + (size_t)i * 4 * M;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        g0[e] = G[((size_t)(0 * 2 + r) * 8 + e) * TP + q];
-        g1[e] = G[((size_t)(1 * 2 + r) * 8 + e) * TP + q];
-      }
-    }
-
-    // ---- diff -> digit -> twist ----
-    double2 x[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      const uint64_t d0 = rot_read<N>(acc_r, a, p) - own_lo[e];
-      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - own_hi[e];
-      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twr[e]);
-    }
-
-    // ---- forward FFT ----
-    fft_butterflies_reg<true>(x, wA);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
-    fft_butterflies_reg<true>(x, wB);
-    if (NP == 3) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
-      // B -> C never leaves a wave (q >> 6 is index bit LOGM-1 in both layouts): LDS operations of
-      // one wave execute in order, no workgroup barrier
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
-      fft_butterflies_reg<true>(x, wC);
-    }
-    fft_stage_bit0_dpp(x, sgn);
-
-    // ---- exchange spectra between the two halves, external product ----
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dx[((size_t)r * 8 + e) * TP + q] = x[e];
-    __syncthreads();
-    if (r == 0) {  // wave-uniform: D0 = own spectrum, D1 = the other half's
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], dx[((size_t)1 * 8 + e) * TP + q], g0[e], g1[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(dx[((size_t)0 * 8 + e) * TP + q], x[e], g0[e], g1[e]);
-    }
-
-    // ---- inverse FFT ----
-    fft_stage_bit0_dpp(x, sgn);
-    if (NP == 3) {
-      fft_butterflies_reg<false>(x, wC);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
-      __builtin_amdgcn_wave_barrier();  // C -> B stays inside the wave as well
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
-    }
-    fft_butterflies_reg<false>(x, wB);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
-    fft_butterflies_reg<false>(x, wA);
-
-    // ---- untwist, round to the torus, accumulate (registers + LDS copy for the rotations) ----
-    // every rotated read of this iteration completed before the barriers above
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      const double2 v = cmul_conj(x[e], twi[e]);
-      own_lo[e] += torus_from_f64_fast(v.x);
-      own_hi[e] += torus_from_f64_fast(v.y);
-      acc[(size_t)r * N + p] = own_lo[e];
-      acc[(size_t)r * N + p + M] = own_hi[e];
-    }
-    __syncthreads();
-  }
-
-  // ---- sample extract ----
-  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
-  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
-  if (tid == 0) out[N] = acc[N];
-}
-
-// ------------------------------------------------------------------------------------------
-// K2+K3 (variant 3): throughput-oriented sibling of variant 2 -- same arithmetic, same bits.
-// Two independent workgroups per CU (<= 256 registers, <= 80 KB LDS each) so that one
-// workgroup's barriers / LDS round trips are covered by the other's f64 work:
-//   * the thread's own accumulator coefficients are re-read from LDS (frees 32 registers);
-//   * the two halves exchange spectra through the FFT buffer (two extra barriers);
-//   * the 1/M scale is folded into a pre-scaled untwist table (exact: power of two).
-// (A first version kept the twiddle table in LDS: strided ds_read_b128 gave 1.1 G bank-conflict
-//  cycles per launch and the LDS pipe was 55 % busy -- twiddles stay in registers.)
-// LDS: acc u64[2][N] | fbuf double2[2][M] | stage twiddle tables double2[M/2] | a_tilde u16
-// ------------------------------------------------------------------------------------------
-// butterflies of a 3-bit pass with twiddles from the per-stage LDS tables
-//   T[2^beta + j] = tw[j << (LOGM-1-beta)],  j < 2^beta,  beta = 1 .. LOGM-2
-// (consecutive or broadcast addresses -> conflict-free); the top stage (beta = LOGM-1) of the
-// first pass takes its 4 twiddles from registers.
-template <int LOGM, bool FWD, int LO>
-__device__ __forceinline__ void fft_butterflies_tab(double2 (&x)[8], int q, const double2 *T, const double2 (&wtop)[4]) {
-#pragma unroll
-  for (int st = 0; st < 3; ++st) {
-    const int fb = FWD ? (2 - st) : st;
-    const int beta = LO + fb;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (e & (1 << fb)) continue;
-      const int e1 = e | (1 << fb);
-      double2 w;
-      if (beta == LOGM - 1) w = wtop[e & 3];
-      else w = T[(1 << beta) + (fft_point<LOGM, LO, 3>(q, e) & ((1 << beta) - 1))];
-      const double2 u = x[e], v = x[e1];
-      if (FWD) {
-        const double2 dd = make_double2(u.x - v.x, u.y - v.y);
-        x[e] = make_double2(u.x + v.x, u.y + v.y);
-        x[e1] = cmul(dd, w);
-      } else {
-        inv_butterfly(x[e], x[e1], w);
-      }
-    }
-  }
-}
-
-template <int LOGN, int BL, bool DIAG>
-__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v3_kernel(
-    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
-    int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
-    const double2 *__restrict__ twist, const double2 *__restrict__ twist_inv /* twist / M */,
-    const double2 *__restrict__ tw, unsigned long long *__restrict__ diag) {
-  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
-  constexpr int NP = (LOGM - 1) / 3;
-  static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N]
-  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][M]
-  double2 *T = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16);  // [M/2] stage tables
-  uint16_t *at = reinterpret_cast<uint16_t *>(smem_raw + (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)(M / 2) * 16);
-
-  const int tid = threadIdx.x;
-  const int r = tid / TP;
-  const int q = tid % TP;
-  const double sgn = (q & 1) ? -1.0 : 1.0;
-  const int vidx = d.v0 + blockIdx.x;
-  const int inst = vidx / d.count, node = d.first + vidx % d.count;
-
-  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
-  for (int j = tid; j <= n_small; j += blockDim.x)
-    at[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
-  for (int idx = 2 + tid; idx < M / 2; idx += blockDim.x) {
-    const int beta = 31 - __builtin_clz(idx);  // idx = 2^beta + j
-    T[idx] = tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
-  }
-  __syncthreads();
-
-  constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
-  double2 wtop[4];  // stage LOGM-1 of pass A: tw[q + TP * e], e = 0..3
-#pragma unroll
-  for (int e = 0; e < 4; ++e) wtop[e] = tw[fft_point<LOGM, LO_A, 3>(q, e) & (M / 2 - 1)];
-  const double2 *twist_q = twist + q;  // twist[fft_point<LOGM, LO_A, 3>(q, e)] = twist_q[e * TP]
-  const double2 *twist_inv_q = twist_inv + q;  // same factors times 1/M (power of two: exact)
-
-  {
-    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
-    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      uint64_t v0 = 0, v1 = 0;
-      if (r == 1) {
-        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
-        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
-      }
-      acc[(size_t)r * N + p] = v0;
-      acc[(size_t)r * N + p + M] = v1;
-    }
-  }
-  __syncthreads();
-
-  uint64_t *acc_r = acc + (size_t)r * N;
-  double2 *buf_r = fbuf + (size_t)r * M;
-  const double2 *buf_o = fbuf + (size_t)(1 - r) * M;
-
-  // diagnostic build only: cycles per phase, accumulated over the iterations
-  unsigned long long ph[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t_prev = 0;
-#define FHES_STAMP(K)                                                              \
-  if (DIAG) {                                                                      \
-    unsigned long long t_now;                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory"); \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    ph[K] += t_now - t_prev;                                                       \
-    t_prev = t_now;                                                                \
-  }
-  if (DIAG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory"); }
-
-  for (int i = 0; i < n_small; ++i) {
-    const int a = (int)at[i];
-    if (a == 0) continue;
-
-    // Global loads complete in issue order (vmcnt), so the twist factors are requested FIRST
-    // and the GGSW prefetch only after they have been consumed: waiting for the twist then
-    // never waits for the (HBM / Infinity-Cache latency) GGSW loads.
-    double2 twv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) twv[e] = twist_q[e * TP];
-    double2 x[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      const uint64_t d0 = rot_read<N>(acc_r, a, p) - acc_r[p];
-      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - acc_r[p + M];
-      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twv[e]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // GGSW column r of this iteration, consumed after the forward FFT
-    double2 g0[8], g1[8];
-    {
-      const double2 *G = bsk_e + (size_t)i * 4 * M;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        g0[e] = G[((size_t)(0 * 2 + r) * 8 + e) * TP + q];
-        g1[e] = G[((size_t)(1 * 2 + r) * 8 + e) * TP + q];
-      }
-    }
-    FHES_STAMP(0)  // prefetch issue + rotation reads + digits + twist
-    // ---- forward FFT ----
-    fft_butterflies_tab<LOGM, true, LO_A>(x, q, T, wtop);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
-    FHES_STAMP(1)  // pass A + LDS write
-    __syncthreads();
-    FHES_STAMP(2)  // barrier 1
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
-    fft_butterflies_tab<LOGM, true, LO_B>(x, q, T, wtop);
-    if (NP == 3) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
-      FHES_STAMP(3)  // read + pass B + write
-      __syncthreads();
-      FHES_STAMP(4)  // barrier 2
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
-    }
-    if (NP == 3) fft_butterflies_tab<LOGM, true, LO_C>(x, q, T, wtop);
-    fft_stage_bit0_dpp(x, sgn);
-
-    // ---- exchange spectra through fbuf ([e][q] order), external product ----
-    FHES_STAMP(5)  // read + pass C + DPP stage
-    FHES_STAMP(6)  // (barrier 3 removed)
-    // spectrum written IN PLACE (the slots this thread read its pass-C inputs from): no other
-    // thread reads or writes those slots before the barrier, so no barrier is needed here
-#pragma unroll
-    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
-    FHES_STAMP(7)  // spectrum write
-    __syncthreads();
-    FHES_STAMP(8)  // barrier 4
-    if (r == 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], buf_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], g0[e], g1[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(buf_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], x[e], g0[e], g1[e]);
-    }
-    // untwist factors (pre-scaled by 1/M): requested now, while the GGSW registers are dead,
-    // consumed after the inverse FFT
-    double2 twi[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) twi[e] = twist_inv_q[e * TP];
-    FHES_STAMP(9)  // read other spectrum + external product (waits for the GGSW prefetch)
-    __syncthreads();  // the other half has read my spectrum: buf_r may be overwritten
-    FHES_STAMP(10)  // barrier 5
-
-    // ---- inverse FFT ----
-    fft_stage_bit0_dpp(x, sgn);
-    if (NP == 3) {
-      fft_butterflies_tab<LOGM, false, LO_C>(x, q, T, wtop);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
-      FHES_STAMP(11)  // DPP stage + inverse pass C + write
-      __syncthreads();
-      FHES_STAMP(12)  // barrier 6
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
-    }
-    fft_butterflies_tab<LOGM, false, LO_B>(x, q, T, wtop);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) buf_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
-    FHES_STAMP(13)  // read + inverse pass B + write
-    __syncthreads();
-    FHES_STAMP(14)  // barrier 7
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = buf_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
-    fft_butterflies_tab<LOGM, false, LO_A>(x, q, T, wtop);
-
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      const double2 v = cmul_conj(x[e], twi[e]);
-      acc_r[p] += torus_from_f64_fast(v.x);
-      acc_r[p + M] += torus_from_f64_fast(v.y);
-    }
-    FHES_STAMP(15)  // read + inverse pass A + untwist + rounding + accumulator update
-    __syncthreads();
-    FHES_STAMP(16)  // barrier 8
-  }
-#undef FHES_STAMP
-  if (DIAG && diag && (tid & 63) == 0) {
-    unsigned long long *dst = diag + ((size_t)blockIdx.x * (blockDim.x / 64) + tid / 64) * 17;
-#pragma unroll
-    for (int kk = 0; kk < 17; ++kk) dst[kk] = ph[kk];
-  }
-
-  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
-  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
-  if (tid == 0) out[N] = acc[N];
-}
 
 // padded exchange-buffer layout: slot(p) = (p>>7)*142 + ((p>>4)&7)*18 + (p&15).  Every 3-bit pass
 // layout is then base(q) + e * const (one address register per layout, immediate offsets) and b128
@@ -1100,21 +756,9 @@ __device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t rs, unsign
   return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
 }
 
-// ------------------------------------------------------------------------------------------
-// K2+K3 (variant 4): variant 3 with one barrier fewer per iteration -- same arithmetic, same bits.
-// The thread's own accumulator coefficients stay in registers, so the accumulator image in LDS is
-// dead between the rotated reads and the write-back at the end of the iteration: it serves as a
-// SECOND exchange buffer.  The FFT exchanges alternate between the two buffers (X = fbuf, padded
-// layout; Y = the accumulator image, XOR-swizzled), so a buffer is never rewritten in the phase
-// that follows its reads and the barrier "the other half has read my spectrum" disappears:
-//   rot(Y) | A->X | B1 | B(X) ->Y | B2 | C(Y), spectrum ->X | B3 | other(X), MAC, inv C ->Y | B4 |
-//   B(Y) ->X | B5 | A(X), round, acc ->Y | B6
-// GGSW / twist factors through buffer loads with SGPR offsets.
-// LDS: Y = acc u64[2][N] | X = fbuf double2[2][SLOTS] | stage tables double2[M/2] | a_tilde u16
-// ------------------------------------------------------------------------------------------
-// the 7 twiddles of a 3-bit pass from the LDS stage tables (same values and order as
-// load_pass_twiddles): issued BEFORE the barrier that precedes the pass, so that only the data
-// reads remain on the critical path after it
+// the 7 twiddles of a 3-bit INVERSE pass from the LDS stage tables T[2^beta + j] = tw[j << (LOGM-1-beta)]
+// (same values and order as load_pass_twiddles): issued BEFORE the barrier that precedes the pass, so that
+// only the data reads remain on the critical path after it
 template <int LOGM, int LO>
 __device__ __forceinline__ void load_pass_twiddles_tab(double2 (&w)[7], int q, const double2 *T, const double2 (&wtop)[4]) {
 #pragma unroll
@@ -1125,192 +769,6 @@ __device__ __forceinline__ void load_pass_twiddles_tab(double2 (&w)[7], int q, c
     if (beta == LOGM - 1) w[k] = wtop[e & 3];
     else w[k] = T[(1 << beta) + (fft_point<LOGM, LO, 3>(q, e) & ((1 << beta) - 1))];
   }
-}
-
-template <int LOGN, int BL>
-__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v4_kernel(
-    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
-    int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
-    const double2 *__restrict__ twist, const double2 *__restrict__ twist_inv /* twist / M */,
-    const double2 *__restrict__ tw) {
-  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
-  constexpr int NP = (LOGM - 1) / 3;
-  static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
-  constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N]      } Y
-  double2 *ybuf = reinterpret_cast<double2 *>(smem_raw);                      // [2][M]      }
-  double2 *xbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][SLOTS]    X
-  double2 *T = xbuf + (size_t)2 * SLOTS;                                      // [M/2] stage tables
-  uint16_t *at = reinterpret_cast<uint16_t *>(T + M / 2);
-
-  const int tid = threadIdx.x;
-  const int r = tid / TP;
-  const int q = tid % TP;
-  const double sgn = (q & 1) ? -1.0 : 1.0;
-  const int vidx = d.v0 + blockIdx.x;
-  const int inst = vidx / d.count, node = d.first + vidx % d.count;
-
-  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
-  for (int j = tid; j <= n_small; j += blockDim.x)
-    at[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
-  for (int idx = 2 + tid; idx < M / 2; idx += blockDim.x) {
-    const int beta = 31 - __builtin_clz(idx);  // idx = 2^beta + j
-    T[idx] = tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
-  }
-  __syncthreads();
-
-  constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
-  constexpr int SA = fpad(1 << LO_A), SB = fpad(1 << LO_B), SC = fpad(1 << LO_C);
-  double2 wtop[4];  // stage LOGM-1 of pass A: tw[q + TP * e], e = 0..3
-#pragma unroll
-  for (int e = 0; e < 4; ++e) wtop[e] = tw[fft_point<LOGM, LO_A, 3>(q, e) & (M / 2 - 1)];
-  const __amdgpu_buffer_rsrc_t rs_g =
-      __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_small * 4 * M * 16), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc((void *)twist, 0, M * 16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ti = __builtin_amdgcn_make_buffer_rsrc((void *)twist_inv, 0, M * 16, 0x00020000);
-  const unsigned voff_q = (unsigned)q * 16u;                 // twist[q + e*TP]
-  const unsigned voff_g = (unsigned)(r * 8 * TP + q) * 16u;  // G[((row*2 + r)*8 + e)*TP + q]
-
-  uint64_t own_lo[8], own_hi[8];  // coefficients p and p + M of polynomial r
-  {
-    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
-    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      uint64_t v0 = 0, v1 = 0;
-      if (r == 1) {
-        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
-        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
-      }
-      own_lo[e] = v0;
-      own_hi[e] = v1;
-      acc[(size_t)r * N + p] = v0;
-      acc[(size_t)r * N + p + M] = v1;
-    }
-  }
-  __syncthreads();
-
-  const uint64_t *acc_r = acc + (size_t)r * N;
-  uint64_t *acc_w = acc + (size_t)r * N + q;  // own coefficient p = q + e*TP lives at acc_w[e * TP]
-  double2 *xA = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_A, 3>(q, 0));
-  double2 *xB = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_B, 3>(q, 0));
-  double2 *xC = xbuf + (size_t)r * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
-  const double2 *xCo = xbuf + (size_t)(1 - r) * SLOTS + fpad(fft_point<LOGM, LO_C, 3>(q, 0));
-  double2 *y_r = ybuf + (size_t)r * M;
-
-  int a_next = (int)at[0];
-  for (int i = 0; i < n_small; ++i) {
-    const int a = a_next;
-    a_next = (int)at[i + 1];  // requested one iteration ahead: off the critical path (at has n+1 entries)
-    if (a == 0) continue;
-
-    // twist factors first, GGSW prefetch after they have been consumed (vmcnt completes in order)
-    double2 twv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) twv[e] = buf_load_d2(rs_tw, voff_q, (unsigned)(e * TP * 16));
-    double2 x[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int p = fft_point<LOGM, LO_A, 3>(q, e);
-      const uint64_t d0 = rot_read<N>(acc_r, a, p) - own_lo[e];
-      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - own_hi[e];
-      x[e] = cmul(make_double2(digit1_f64<BL>(d0), digit1_f64<BL>(d1)), twv[e]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    double2 g0[8], g1[8];
-    {
-      const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        g0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
-        g1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
-      }
-    }
-    // ---- forward FFT: A -> X, B -> Y.  The twiddles of the NEXT pass are requested before each
-    // barrier: after it only the data reads are on the critical path ----
-    double2 w[7];
-    load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
-    fft_butterflies_reg<true>(x, w);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) xA[e * SA] = x[e];
-    load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
-    __syncthreads();  // B1 (also: every rotated read of Y is done)
-    __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = xB[e * SB];
-    fft_butterflies_reg<true>(x, w);
-    if (NP == 3) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
-      load_pass_twiddles_tab<LOGM, LO_C>(w, q, T, wtop);
-      // B -> C stays inside a wave (q >> 6 is index bit LOGM-1 in both layouts; the slots of X that
-      // the spectrum write below touches belong to the same wave as well): no workgroup barrier
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
-      fft_butterflies_reg<true>(x, w);
-    }
-    fft_stage_bit0_dpp(x, sgn);
-
-    // ---- spectra -> X (its B-layout reads ended before B2), external product ----
-#pragma unroll
-    for (int e = 0; e < 8; ++e) xC[e * SC] = x[e];
-    __syncthreads();  // B3
-    if (r == 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], xCo[e * SC], g0[e], g1[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(xCo[e * SC], x[e], g0[e], g1[e]);
-    }
-    double2 twi[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) twi[e] = buf_load_d2(rs_ti, voff_q, (unsigned)(e * TP * 16));
-
-    // ---- inverse FFT: C -> Y (no barrier: Y was last read before B3), B -> X ----
-    fft_stage_bit0_dpp(x, sgn);
-    if (NP == 3) {
-      fft_butterflies_reg<false>(x, w);  // w still holds the pass-C twiddles
-#pragma unroll
-      for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
-      load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
-      __builtin_amdgcn_wave_barrier();  // C -> B stays inside a wave
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
-      fft_butterflies_reg<false>(x, w);
-      __syncthreads();  // B4: every read of the spectra in X is done (X is written next)
-    } else {
-      fft_butterflies_reg<false>(x, w);  // w holds the pass-B twiddles
-      __syncthreads();  // B4
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) xB[e * SB] = x[e];
-    load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
-    __syncthreads();  // B5
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = xA[e * SA];
-    fft_butterflies_reg<false>(x, w);
-
-    // ---- untwist, round, accumulate; the image goes back into Y (last read before B5) ----
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const double2 v = cmul_conj(x[e], twi[e]);
-      own_lo[e] += torus_from_f64_fast(v.x);
-      own_hi[e] += torus_from_f64_fast(v.y);
-      acc_w[e * TP] = own_lo[e];
-      acc_w[e * TP + M] = own_hi[e];
-    }
-    __syncthreads();  // B6
-    // the long head of the next iteration (rotated reads, digits, twist, first pass) runs at high
-    // priority, the short latency-bound passes at normal priority: measured +1.8 %
-    __builtin_amdgcn_s_setprio(3);
-  }
-
-  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
-  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
-  if (tid == 0) out[N] = acc[N];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1358,8 +816,8 @@ template <int LOGN, int BL, int PRIO>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v5_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
     int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
-    const double2 *__restrict__ twist, const double2 *__restrict__ twist_inv /* twist / M */,
-    const double2 *__restrict__ tw) {
+    const double2 *__restrict__ twist_inv /* twist / M */, const double2 *__restrict__ tw,
+    const double2 *__restrict__ psi /* forward twiddles [M] */, const double2 *__restrict__ cdpp /* [8][M/8] */) {
   constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
   constexpr int NP = (LOGM - 1) / 3;
   static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
@@ -1372,8 +830,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N] image of -acc  } Y
   double2 *ybuf = reinterpret_cast<double2 *>(smem_raw);                      // [2][M]                }
   double2 *xbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][SLOTS]    X
-  double2 *T = xbuf + (size_t)2 * SLOTS;                                      // [M/2] stage tables
-  uint16_t *at = reinterpret_cast<uint16_t *>(T + M / 2);
+  double2 *T = xbuf + (size_t)2 * SLOTS;                                      // [M/2] inverse stage tables
+  double2 *TF = T + M / 2;                                                    // [M/2] forward twiddles psi[0, M/2)
+  // (no room for anything else: 2 x 80 KB fill the CU's LDS; the switched mask a~_i is read from the
+  // keyswitch output through the scalar cache, one iteration ahead)
 
   const int tid = threadIdx.x;
   const int r = tid / TP;
@@ -1383,21 +843,26 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   const int inst = vidx / d.count, node = d.first + vidx % d.count;
 
   const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
-  for (int j = tid; j <= n_small; j += blockDim.x)
-    at[j] = (uint16_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  auto modswitch = [&](int j) __attribute__((always_inline)) {  // uniform: scalar load + scalar ALU
+    return (int)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  };
   for (int idx = 2 + tid; idx < M / 2; idx += blockDim.x) {
     const int beta = 31 - __builtin_clz(idx);  // idx = 2^beta + j
     T[idx] = tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
   }
+  for (int idx = tid; idx < M / 2; idx += blockDim.x) TF[idx] = psi[idx];
   __syncthreads();
 
   constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
-  double2 wtop[4];  // stage LOGM-1 of pass A: tw[q + TP * e], e = 0..3
+  double2 wfa[7];   // forward pass A: the same 7 twiddles for every thread (blocks 0 of the three top stages)
 #pragma unroll
-  for (int e = 0; e < 4; ++e) wtop[e] = tw[fft_point<LOGM, LO_A, 3>(q, e) & (M / 2 - 1)];
+  for (int kk = 0; kk < 7; ++kk) wfa[kk] = psi[1 + kk];
+  const double2 wnone[4] = {};  // passes B / C take every twiddle from the LDS tables
+  // inverse, stage LOGM-1 of pass A: tw[q + TP * e], e = 0..3, fetched from global memory when the pass is near
+  const __amdgpu_buffer_rsrc_t rs_twg = __builtin_amdgcn_make_buffer_rsrc((void *)tw, 0, (M / 2) * 16, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_g =
       __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_small * 4 * M * 16), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc((void *)twist, 0, M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_cd = __builtin_amdgcn_make_buffer_rsrc((void *)cdpp, 0, M * 16, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_ti = __builtin_amdgcn_make_buffer_rsrc((void *)twist_inv, 0, M * 16, 0x00020000);
   const unsigned voff_q = (unsigned)q * 16u;                 // twist[q + e*TP]
   const unsigned voff_g = (unsigned)(r * 8 * TP + q) * 16u;  // G[((row*2 + r)*8 + e)*TP + q]
@@ -1406,7 +871,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   uint64_t nlo[8], nhi[8];
   {
     const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
-    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
+    const int t = (2 * N - modswitch(n_small)) & (2 * N - 1);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int p = fft_point<LOGM, LO_A, 3>(q, e);
@@ -1438,16 +903,12 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_REG_HW_ID.WAVE_ID: slot inside the SIMD
     if (slot & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
   }
-  int a_next = (int)at[0];
+  int a_next = modswitch(0);
   for (int i = 0; i < n_small; ++i) {
     const int a = a_next;
-    a_next = (int)at[i + 1];  // requested one iteration ahead: off the critical path (at has n+1 entries)
+    a_next = modswitch(i + 1);  // requested one iteration ahead: off the critical path (the row has n+1 words)
     if (a == 0) continue;
 
-    // twist factors first, GGSW prefetch after they have been consumed (vmcnt completes in order)
-    double2 twv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) twv[e] = buf_load_d2(rs_tw, voff_q, (unsigned)(e * TP * 16));
     double2 x[8];
     {
       // byte offset of the rotated coefficient (q - a) mod 2N, with the wrap bit (bit LOGN+3 of the byte
@@ -1469,7 +930,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
         }
         const double d0 = (double)((int)(uint32_t)(dd[0] >> 32) >> (32 - BL));
         const double d1 = (double)((int)(uint32_t)(dd[1] >> 32) >> (32 - BL));
-        x[e] = cmul(make_double2(d0, d1), twv[e]);
+        x[e] = make_double2(d0, d1);  // no twist: it lives in the forward twiddles
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1483,26 +944,31 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       }
     }
     double2 w[7];
-    load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
-    fft_butterflies_reg<true>(x, w);
+    fft_butterflies_reg<true>(x, wfa);
 #pragma unroll
     for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
-    load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
+    load_fwd_twiddles<LOGM, LO_B>(w, q, TF);
     __syncthreads();  // B1 (also: every rotated read of Y is done)
     if (PRIO == 0) __builtin_amdgcn_s_setprio(0);
+    // constants of the lane-pair stage: requested here, consumed after the remaining register passes
+    // (measured: requested at the top of the iteration instead, 140.5 against 134.8 ms per 16 384 PBS)
+    double2 cd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cd[e] = buf_load_d2(rs_cd, voff_q, (unsigned)(e * TP * 16));
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = x_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
     fft_butterflies_reg<true>(x, w);
     if (NP == 3) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
-      load_pass_twiddles_tab<LOGM, LO_C>(w, q, T, wtop);
+      load_fwd_twiddles<LOGM, LO_C>(w, q, TF);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
       fft_butterflies_reg<true>(x, w);
     }
-    fft_stage_bit0_dpp(x, sgn);
+    fft_fwd_stage0_dpp(x, cd);
+    load_pass_twiddles_tab<LOGM, LO_C>(w, q, T, wnone);  // first inverse pass (LO_C == LO_B when there are two)
 
 #pragma unroll
     for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
@@ -1517,20 +983,23 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     double2 twi[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) twi[e] = buf_load_d2(rs_ti, voff_q, (unsigned)(e * TP * 16));
+    double2 wtop[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wtop[e] = buf_load_d2(rs_twg, voff_q, (unsigned)(e * TP * 16));
 
     fft_stage_bit0_dpp(x, sgn);
     if (NP == 3) {
-      fft_butterflies_reg<false>(x, w);  // w still holds the pass-C twiddles
+      fft_butterflies_reg<false>(x, w);  // the pass-C twiddles requested before B3
 #pragma unroll
       for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
-      load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wtop);
+      load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wnone);
       __builtin_amdgcn_wave_barrier();  // C -> B stays inside a wave
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
       fft_butterflies_reg<false>(x, w);
       __syncthreads();  // B4
     } else {
-      fft_butterflies_reg<false>(x, w);
+      fft_butterflies_reg<false>(x, w);  // LO_C == LO_B: requested before B3
       __syncthreads();  // B4
     }
 #pragma unroll
@@ -1584,28 +1053,28 @@ __device__ __forceinline__ double2 cfma(double2 g, double2 w, double2 acc) {
   return make_double2(re, im);
 }
 
-// butterflies of a 3-bit pass, every stage's twiddles from the LDS stage tables (T[M] entries)
+// INVERSE butterflies of a 3-bit pass, every stage's twiddles from the LDS stage tables (T[M] entries)
 template <int LOGM, bool FWD, int LO>
 __device__ __forceinline__ void fft_butterflies_tab_all(double2 (&x)[8], int q, const double2 *T) {
+  static_assert(!FWD, "forward passes: fft_fwd_butterflies_tab");
 #pragma unroll
   for (int st = 0; st < 3; ++st) {
-    const int fb = FWD ? (2 - st) : st;
+    const int fb = st;
     const int beta = LO + fb;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       if (e & (1 << fb)) continue;
       const int e1 = e | (1 << fb);
-      const double2 w = T[(1 << beta) + (fft_point<LOGM, LO, 3>(q, e) & ((1 << beta) - 1))];
-      const double2 u = x[e], v = x[e1];
-      if (FWD) {
-        const double2 dd = make_double2(u.x - v.x, u.y - v.y);
-        x[e] = make_double2(u.x + v.x, u.y + v.y);
-        x[e1] = cmul(dd, w);
-      } else {
-        inv_butterfly(x[e], x[e1], w);
-      }
+      inv_butterfly(x[e], x[e1], T[(1 << beta) + (fft_point<LOGM, LO, 3>(q, e) & ((1 << beta) - 1))]);
     }
   }
+}
+// FORWARD butterflies of a 3-bit pass, twiddles from the LDS copy of psi
+template <int LOGM, int LO>
+__device__ __forceinline__ void fft_fwd_butterflies_tab(double2 (&x)[8], int q, const double2 *TF) {
+  double2 w[7];
+  load_fwd_twiddles<LOGM, LO>(w, q, TF);
+  fft_butterflies_reg<true>(x, w);
 }
 
 // LAT = true: the latency build -- one workgroup per CU (512 registers per lane), pass twiddles and
@@ -1614,16 +1083,19 @@ template <int LOGN, int BL, int G, bool PIPE, bool LAT>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LAT ? 1 : 2) void blind_rotate_mb_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
     int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
-    const double2 *__restrict__ twist, const double2 *__restrict__ twist_inv /* twist / M */,
-    const double2 *__restrict__ tw, const double2 *__restrict__ root /* [2N] */) {
+    const double2 *__restrict__ twist_inv /* twist / M */, const double2 *__restrict__ tw,
+    const double2 *__restrict__ root /* [2N] */, const double2 *__restrict__ psi /* forward twiddles [M] */,
+    const double2 *__restrict__ cdpp /* [8][M/8] */) {
   constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
   constexpr int NP = (LOGM - 1) / 3, NC = 1 << G;
   static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
   constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;  // padded slots per polynomial (fpad)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double2 *fbuf = reinterpret_cast<double2 *>(smem_raw);                                 // [2][SLOTS]
-  double2 *T = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * SLOTS * 16);           // [M] stage tables
-  uint16_t *degs = reinterpret_cast<uint16_t *>(smem_raw + (size_t)2 * SLOTS * 16 + (size_t)M * 16);
+  double2 *T = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * SLOTS * 16);           // [M] inverse stage tables
+  double2 *TF = T + M;                                                                   // [M/2] forward twiddles psi[0, M/2)
+  double2 *CDL = TF + M / 2;                                                             // [8][M/8] constants of the lane-pair stage
+  uint16_t *degs = reinterpret_cast<uint16_t *>(CDL + M);
 
   const int tid = threadIdx.x;
   const int r = tid / TP;
@@ -1646,19 +1118,28 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
     const int beta = 31 - __builtin_clz(idx);  // idx = 2^beta + j
     T[idx] = tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
   }
+  for (int idx = tid; idx < M / 2; idx += blockDim.x) TF[idx] = psi[idx];
+  for (int idx = tid; idx < M; idx += blockDim.x) CDL[idx] = cdpp[idx];
   __syncthreads();
 
   constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = NP == 3 ? LOGM - 9 : LOGM - 6;
-  const double2 *twist_q = twist + q;
+  const double2 *cdpp_q = cdpp + q;
   const double2 *twist_inv_q = twist_inv + q;
-  double2 wA[7], wB[7], wC[7], twr[8], twir[8];  // latency build only (dead otherwise)
+  double2 wfa[7];  // forward pass A: the same 7 twiddles for every thread
+#pragma unroll
+  for (int kk = 0; kk < 7; ++kk) wfa[kk] = psi[1 + kk];
+  double2 wA[7], wB[7], wC[7], wfB[7], wfC[7], cdr[8], twir[8];  // latency build only (dead otherwise)
   if (LAT) {
     load_pass_twiddles<LOGM, LO_A>(wA, q, tw);
     load_pass_twiddles<LOGM, LO_B>(wB, q, tw);
-    if (NP == 3) load_pass_twiddles<LOGM, LO_C>(wC, q, tw);
+    load_fwd_twiddles<LOGM, LO_B>(wfB, q, psi);
+    if (NP == 3) {
+      load_pass_twiddles<LOGM, LO_C>(wC, q, tw);
+      load_fwd_twiddles<LOGM, LO_C>(wfC, q, psi);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      twr[e] = twist_q[e * TP];
+      cdr[e] = cdpp_q[e * TP];
       twir[e] = twist_inv_q[e * TP];
     }
   }
@@ -1790,29 +1271,33 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // ---- digits of the accumulator -> twist ----
+    // ---- digits of the accumulator (no twist: it lives in the forward twiddles) ----
     double2 x[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      x[e] = cmul(make_double2(digit1_f64<BL>(own_lo[e]), digit1_f64<BL>(own_hi[e])), LAT ? twr[e] : twist_q[e * TP]);
+    for (int e = 0; e < 8; ++e) x[e] = make_double2(digit1_f64<BL>(own_lo[e]), digit1_f64<BL>(own_hi[e]));
 
     // ---- forward FFT ----
-    if (LAT) fft_butterflies_reg<true>(x, wA); else fft_butterflies_tab_all<LOGM, true, LO_A>(x, q, T);
+    fft_butterflies_reg<true>(x, wfa);
 #pragma unroll
     for (int e = 0; e < 8; ++e) bufA[e * SA] = x[e];
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = bufB[e * SB];
-    if (LAT) fft_butterflies_reg<true>(x, wB); else fft_butterflies_tab_all<LOGM, true, LO_B>(x, q, T);
+    if (LAT) fft_butterflies_reg<true>(x, wfB); else fft_fwd_butterflies_tab<LOGM, LO_B>(x, q, TF);
     if (NP == 3) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) bufB[e * SB] = x[e];
       __builtin_amdgcn_wave_barrier();  // B -> C stays inside a wave (q >> 6 is index bit LOGM-1 in both layouts)
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = bufC[e * SC];
-      if (LAT) fft_butterflies_reg<true>(x, wC); else fft_butterflies_tab_all<LOGM, true, LO_C>(x, q, T);
+      if (LAT) fft_butterflies_reg<true>(x, wfC); else fft_fwd_butterflies_tab<LOGM, LO_C>(x, q, TF);
     }
-    fft_stage_bit0_dpp(x, sgn);
+    {
+      double2 cd[8];  // constants of the lane-pair stage (latency build: registers; otherwise the LDS copy)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cd[e] = LAT ? cdr[e] : CDL[e * TP + q];
+      fft_fwd_stage0_dpp(x, cd);
+    }
 
     // ---- spectra exchanged in place, external product with the bundle ----
 #pragma unroll

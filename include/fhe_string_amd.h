@@ -152,16 +152,17 @@ int fhes_get_stats(fhes_ctx *ctx, fhes_stats *out);
 int fhes_reset_stats(fhes_ctx *ctx);
 /* enable per-launch HIP-event timing (used by bench.py for the roofline object) */
 int fhes_set_timing(fhes_ctx *ctx, int32_t enabled);
-/* blind-rotate kernel selection for A/B benchmarking: 0 = auto (variant 5), 1..7 = force (all produce
- * the same bits; multi-bit sets: 2 = latency build, 3 = throughput build) */
+/* blind-rotate kernel selection for A/B benchmarking: 0 = auto (variant 5), 1 = simple kernel, 5 = throughput
+ * kernel, 6 / 7 = 5 with other wave-priority policies (all produce the same bits; multi-bit sets: 2 = latency
+ * build, 3 = throughput build) */
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t br_variant);
 /* test hooks: Fourier BSK in the oracle's canonical order [n][L][k+1][k+1][N/2][2];
  * FFT tables twist[N/2][2], twiddle[N/4][2]. */
 int fhes_debug_bsk_fourier(fhes_ctx *ctx, double *out);
+/* forward-transform tables: psi[N/2][2] (psi[2^l + b]: twiddle of block b of the stage with 2^l blocks),
+ * odd_fix[N/2][2] (odd slots: the factor the Fourier key carries) */
+int fhes_debug_fwd_tables(const fhes_params *p, double *psi, double *odd_fix);
 int fhes_debug_fft_tables(const fhes_params *p, double *twist, double *twiddle);
-/* developer hook: average shader cycles per CMUX iteration in each of the 17 phases of the
- * throughput blind-rotate kernel (diagnostic build with s_memtime stamps), out[17] */
-int fhes_debug_phase_profile(fhes_ctx *ctx, int32_t count, int32_t in_handle, double *out);
 /* test hook: keyswitch+modswitch only; a_tilde out is [count][n+1] u32 */
 int fhes_debug_keyswitch(fhes_ctx *ctx, int32_t count, const int32_t *in_handles,
                          uint32_t *a_tilde);

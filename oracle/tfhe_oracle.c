@@ -21,8 +21,10 @@ struct oracle_ctx {
   oracle_params p;
   int N, M, k, n, L;  /* M = N/2 complex points */
   int big;            /* k*N */
-  cplx *twist;        /* [M]   exp(+i*pi*j/N)          */
-  cplx *tw;           /* [M/2] exp(-2*pi*i*t/M)        */
+  cplx *twist;        /* [M]   exp(+i*pi*j/N)   (untwist after the inverse transform) */
+  cplx *tw;           /* [M/2] exp(-2*pi*i*t/M) (inverse transform)                   */
+  cplx *psi;          /* [M]   forward transform: psi[2^l + b] = twiddle of block b at the stage with 2^l blocks */
+  cplx *odd_fix;      /* [M]   odd slots: square of the last-stage twiddle (Fourier key material only) */
   cplx *bsk_f;        /* [n_ggsw][L][k+1][k+1][M]      */
   uint64_t *ksk;      /* [big][ks_level][n+1]          */
   int g;              /* grouping factor (1 = classic) */
@@ -45,17 +47,39 @@ static inline cplx cmul_conj(cplx a, cplx w) { /* a * conj(w) */
   return r;
 }
 
-/* DIF radix-2, natural order in, bit-reversed order out. */
+/* Forward transform: the twist is merged into the twiddles.  With b_j = a_j + i a_{j+M} the
+ * spectrum is the evaluation of b(Y) at y_f = exp(i pi (1 - 4 f) / N), roots of Y^M = i, slot m <-> f =
+ * bitrev(m).  Cooley-Tukey stages from stride M/2 down to 1 on natural-order input: block b of the stage
+ * with 2^l blocks reduces modulo (Y^half -+ t), t = psi[2^l + b] = y^half of the block's first root, by the
+ * fused butterfly  s = u + t v (4 FMAs),  d = 2u - s (2 FMAs).
+ * LAST stage (adjacent slots): the even slot gets s = u + t v; the odd slot holds  h = v + t' u  with
+ * t' = -conj(t), i.e. the true value u - t v divided by -t (|t| = 1).  A lane pair of the device kernels
+ * computes both with ONE instruction sequence (own + c * partner).  Products of two such spectra are put
+ * right by multiplying ONE factor's odd slots by t^2 (odd_fix) -- done once, on the Fourier key material. */
 static void fft_fwd(const oracle_ctx *c, cplx *x) {
   const int M = c->M;
-  for (int half = M / 2, stride = 1; half >= 1; half >>= 1, stride <<= 1) {
-    for (int b = 0; b < M; b += 2 * half) {
+  for (int half = M / 2, nb = 1; half >= 1; half >>= 1, nb <<= 1) {
+    for (int b = 0; b < nb; b++) {
+      const cplx t = c->psi[nb + b];
+      cplx *blk = x + (size_t)b * 2 * half;
       for (int j = 0; j < half; j++) {
-        cplx u = x[b + j], v = x[b + j + half];
-        cplx s = {u.re + v.re, u.im + v.im};
-        cplx d = {u.re - v.re, u.im - v.im};
-        x[b + j] = s;
-        x[b + j + half] = cmul(d, c->tw[j * stride]);
+        const cplx u = blk[j], v = blk[j + half];
+        cplx s, d;
+        s.re = fma(t.re, v.re, u.re);
+        s.re = fma(-t.im, v.im, s.re);
+        s.im = fma(t.re, v.im, u.im);
+        s.im = fma(t.im, v.re, s.im);
+        if (half > 1) {
+          d.re = fma(2.0, u.re, -s.re);
+          d.im = fma(2.0, u.im, -s.im);
+        } else { /* h = v + t' u, t' = (-t.re, t.im) */
+          d.re = fma(-t.re, u.re, v.re);
+          d.re = fma(-t.im, u.im, d.re);
+          d.im = fma(-t.re, u.im, v.im);
+          d.im = fma(t.im, u.re, d.im);
+        }
+        blk[j] = s;
+        blk[j + half] = d;
       }
     }
   }
@@ -104,8 +128,8 @@ static inline uint64_t torus_from_f64(double y) {
 static void poly_fwd(const oracle_ctx *c, const int64_t *p, cplx *out) {
   const int M = c->M;
   for (int j = 0; j < M; j++) {
-    cplx a = {(double)p[j], (double)p[j + M]};
-    out[j] = cmul(a, c->twist[j]);
+    out[j].re = (double)p[j];
+    out[j].im = (double)p[j + M];
   }
   fft_fwd(c, out);
 }
@@ -153,6 +177,8 @@ oracle_ctx *oracle_ctx_create(const oracle_params *p) {
   if (c->M >= 4) { c->tw[c->M / 4].re = 0.0; c->tw[c->M / 4].im = -1.0; }
   c->g = p->grouping_factor > 1 ? p->grouping_factor : 1;
   if (c->g > 3 || c->n % c->g) { oracle_ctx_destroy(c); return NULL; }
+  c->psi = (cplx *)calloc(c->M, sizeof(cplx));
+  c->odd_fix = (cplx *)calloc(c->M, sizeof(cplx));
   c->n_ggsw = c->g > 1 ? (long)(c->n / c->g) << c->g : c->n;
   /* multi-bit tables.  The forward transform evaluates a polynomial at
    *   x_f = twist * exp(-2 pi i f / M) = exp(i pi (1 - 4 f) / N),  f = 0 .. M-1,
@@ -176,6 +202,19 @@ oracle_ctx *oracle_ctx_create(const oracle_params *p) {
     for (int b = 0; b < logm; b++) f |= ((m >> b) & 1) << (logm - 1 - b);
     c->slot_exp[m] = (int32_t)(((1 - 4 * f) % (2 * c->N) + 2 * c->N) % (2 * c->N));
   }
+  /* forward twiddles: the stage with 2^l blocks has half = M >> (l+1); the first slot of block b is
+   * m0 = b * 2 * half, its root y = root[slot_exp[m0]], t = y^half = root[(slot_exp[m0] * half) mod 2N] */
+  for (int l = 0; l < logm; l++) {
+    const int nb = 1 << l, half = c->M >> (l + 1);
+    for (int b = 0; b < nb; b++) {
+      const long e = ((long)c->slot_exp[(size_t)b * 2 * half] * half) % (2 * c->N);
+      c->psi[nb + b] = c->root[e];
+      if (half == 1) {
+        c->odd_fix[2 * b].re = 1.0;
+        c->odd_fix[2 * b + 1] = c->root[(2 * e) % (2 * c->N)];
+      }
+    }
+  }
   return c;
 }
 
@@ -187,6 +226,8 @@ void oracle_ctx_destroy(oracle_ctx *c) {
   free(c->ksk);
   free(c->root);
   free(c->slot_exp);
+  free(c->psi);
+  free(c->odd_fix);
   free(c);
 }
 
@@ -203,7 +244,9 @@ int oracle_set_keys(oracle_ctx *c, const uint64_t *bsk, const uint64_t *ksk) {
 #pragma omp parallel for schedule(static)
   for (long q = 0; q < (long)npoly; q++) {
     /* BSK coefficients enter the FFT as signed 64-bit integers. */
-    poly_fwd(c, (const int64_t *)(bsk + (size_t)q * c->N), c->bsk_f + (size_t)q * c->M);
+    cplx *sp = c->bsk_f + (size_t)q * c->M;
+    poly_fwd(c, (const int64_t *)(bsk + (size_t)q * c->N), sp);
+    for (int m = 1; m < c->M; m += 2) sp[m] = cmul(sp[m], c->odd_fix[m]); /* see fft_fwd */
   }
   return 0;
 }
@@ -214,9 +257,22 @@ const double *oracle_twiddle_table(const oracle_ctx *c) { return (const double *
 const double *oracle_root_table(const oracle_ctx *c) { return (const double *)c->root; }
 const int32_t *oracle_slot_exp_table(const oracle_ctx *c) { return c->slot_exp; }
 
+/* the TRUE spectrum (evaluations at root^slot_exp[m]): odd slots of the internal form times -t */
 void oracle_fft_forward_i64(const oracle_ctx *c, const int64_t *poly, double *spec) {
+  cplx *sp = (cplx *)spec;
+  poly_fwd(c, poly, sp);
+  for (int m = 1; m < c->M; m += 2) {
+    const cplx t = c->psi[c->M / 2 + m / 2];
+    const cplx mt = {-t.re, -t.im};
+    sp[m] = cmul(sp[m], mt);
+  }
+}
+/* the internal form: what the blind rotate multiplies with the Fourier key (odd slots: see fft_fwd) */
+void oracle_fft_forward_internal(const oracle_ctx *c, const int64_t *poly, double *spec) {
   poly_fwd(c, poly, (cplx *)spec);
 }
+const double *oracle_psi_table(const oracle_ctx *c) { return (const double *)c->psi; }
+const double *oracle_odd_fix_table(const oracle_ctx *c) { return (const double *)c->odd_fix; }
 void oracle_fft_inverse_torus(const oracle_ctx *c, const double *spec, uint64_t *poly) {
   cplx *tmp = (cplx *)malloc(sizeof(cplx) * c->M);
   memcpy(tmp, spec, sizeof(cplx) * c->M);

@@ -68,15 +68,20 @@ void oracle_ctx_destroy(oracle_ctx *c);
  * The BSK is transformed to the Fourier domain here (canonical forward FFT). */
 int oracle_set_keys(oracle_ctx *c, const uint64_t *bsk, const uint64_t *ksk);
 
-/* Fourier BSK, canonical (bit-reversed) order:
- * double [n][pbs_level][k+1][k+1][N/2][2 (re,im)] */
+/* Fourier BSK, canonical (bit-reversed) order, odd slots carrying the factor of the forward transform's
+ * last stage (tfhe_oracle.c: fft_fwd):  double [n][pbs_level][k+1][k+1][N/2][2 (re,im)] */
 const double *oracle_bsk_fourier(const oracle_ctx *c);
-/* FFT tables: twist[N/2][2], twiddle[N/4][2] */
+/* FFT tables: untwist[N/2][2] and inverse twiddles[N/4][2]; forward twiddles psi[N/2][2] (psi[2^l + b]:
+ * block b of the stage with 2^l blocks); odd_fix[N/2][2] (odd slots: the factor applied to the Fourier key) */
 const double *oracle_twist_table(const oracle_ctx *c);
 const double *oracle_twiddle_table(const oracle_ctx *c);
+const double *oracle_psi_table(const oracle_ctx *c);
+const double *oracle_odd_fix_table(const oracle_ctx *c);
 
-/* Canonical transforms (exposed for unit tests). */
+/* Canonical transforms (exposed for unit tests).  _i64: the true spectrum (slot m = evaluation at
+ * root^slot_exp[m]); _internal: the form the blind rotate works on (odd slots divided by -t, see fft_fwd). */
 void oracle_fft_forward_i64(const oracle_ctx *c, const int64_t *poly, double *spec /*[N/2][2]*/);
+void oracle_fft_forward_internal(const oracle_ctx *c, const int64_t *poly, double *spec /*[N/2][2]*/);
 void oracle_fft_inverse_torus(const oracle_ctx *c, const double *spec, uint64_t *poly);
 /* Exact negacyclic product (schoolbook, __int128): out = a (small signed) * b (torus) */
 void oracle_negacyclic_mul_exact(const oracle_ctx *c, const int64_t *a, const uint64_t *b,

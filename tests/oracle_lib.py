@@ -21,6 +21,9 @@ def load():
         "oracle_twist_table": (_P, [_P]),
         "oracle_twiddle_table": (_P, [_P]),
         "oracle_fft_forward_i64": (None, [_P, _P, _P]),
+        "oracle_fft_forward_internal": (None, [_P, _P, _P]),
+        "oracle_psi_table": (_P, [_P]),
+        "oracle_odd_fix_table": (_P, [_P]),
         "oracle_fft_inverse_torus": (None, [_P, _P, _P]),
         "oracle_negacyclic_mul_exact": (None, [_P, _P, _P, _P]),
         "oracle_make_lut_poly": (None, [_P, _P, _P]),
