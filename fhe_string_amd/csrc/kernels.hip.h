@@ -772,12 +772,27 @@ __device__ __forceinline__ void load_pass_twiddles_tab(double2 (&w)[7], int q, c
 }
 
 // ------------------------------------------------------------------------------------------
-// K2+K3 (variant 5): variant 4 with the INTEGER side of an iteration rewritten -- same transforms,
-// same roundings, same bits.  Measured on gfx950 (scripts/micro/f64_rate.hip): every VALU slot
-// costs ~4.4 cycles next to f64 work, a VALU write of VCC followed by a VALU read of it costs two
-// extra wait states (the compiler pads `v_sub_co / v_subb` and `v_cmp / v_cndmask` with s_nop), and
-// variant 4 spends 16 issue slots per coefficient on the rotated read -> signed digit path and 8 on
-// the accumulator update.  Here:
+// K2+K3 (variant 5): the throughput blind rotate (every launch size).  256 threads = two halves (output
+// polynomial r) x 128 threads x 8 points, two workgroups per CU (<= 256 registers, exactly 80 KB LDS each).
+// Structure of an iteration (4 workgroup barriers):
+//   rotated reads of the image (Y), digits | pass A -> X | B1 | pass B (X) -> Y, wave-local | pass C (Y),
+//   lane-pair stage, spectra -> X | B3 | other half's spectrum (X), multiply-accumulate with the GGSW rows,
+//   inverse lane-pair stage, inverse pass C -> Y, wave-local | inverse pass B (Y) -> Y in place | B5 |
+//   inverse pass A (Y), untwist, round, accumulate, image -> Y in place | B6
+//   * the thread's own accumulator coefficients stay in registers, so the image in Y is dead between the
+//     rotated reads and the write-back and Y doubles as an exchange buffer; the image lives in the slots of
+//     the pass-A layout (image_word below), so the write-back and the exchange before it are written by the
+//     thread that read the slots: no barrier between them, and X keeps the spectra until the next iteration
+//     (no barrier "the other half has read my spectrum");
+//   * the exchanges between passes B and C stay inside a wave (q >> 6 is index bit LOGM-1 in both layouts and
+//     the LDS operations of one wave execute in order);
+//   * the twiddles of the next pass are requested from LDS tables BEFORE each barrier; pass A of the forward
+//     transform takes the same 7 twiddles on every thread (SGPRs); GGSW rows are prefetched one transform
+//     ahead, the lane-pair constants after B1, the untwist factors after the multiply-accumulate;
+//   * X and Y are XOR-swizzled (fswz): conflict-free ds_read/write_b128 in every pass layout.
+// The INTEGER side avoids VCC (measured, scripts/micro/f64_rate.hip: every VALU slot costs ~4.4 cycles next
+// to f64 work, a VALU write of VCC followed by a VALU read of it costs two extra wait states, v_cndmask with
+// VCC 23 cycles):
 //   * registers and the LDS image hold the NEGATED accumulator  nacc = -acc  (mod 2^64), so the
 //     decomposed difference  (+-)acc[s] - acc[p]  is  nacc[p] + ((-+)nacc[s])  -- additions only;
 //   * the conditional negation of the rotated operand is  (v ^ M) + c  with the wrap mask M taken
@@ -788,7 +803,8 @@ __device__ __forceinline__ void load_pass_twiddles_tab(double2 (&w)[7], int q, c
 //   * the accumulator update adds rint(-y) = -rint(y) (round-half-even is symmetric; the untwist
 //     factors enter negated through the free f64 source modifiers), the two dwords of the rounded
 //     value are assembled in place and added with one v_lshl_add_u64.
-// LDS layout, barriers, FFT passes: exactly variant 4.
+// LDS: Y = double2[2][M] (exchange + image of -acc) | X = double2[2][M] | inverse stage tables double2[M/2] |
+// forward twiddles double2[M/2]; the switched mask a~_i comes through the scalar cache, one iteration ahead.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b) {  // one instruction, no VCC
   uint64_t r;
@@ -809,6 +825,19 @@ __device__ __forceinline__ uint64_t torus_from_f64_pair(double y) {
   return ((uint64_t)hi << 32) | (uint64_t)(uint32_t)__double2loint(t2);
 }
 
+// image of -acc inside the exchange buffer Y (variant 5): coefficient j of a polynomial lives in the complex
+// slot fswz(j mod M) -- the slot of the pass-A layout -- in the 8-byte word j / M, so that a thread writes its
+// pair (coefficient p, coefficient p + M) with ONE ds_write_b128 into the slot it has just read.  Price: the
+// rotated 8-byte reads of 32 consecutive lanes stride 16 bytes and hit every bank twice (76 conflict cycles per
+// wave and iteration, SQ_LDS_BANK_CONFLICT).  XORing index bit 4 into the word number makes those reads
+// conflict-free but turns the write-back into 16 ds_write_b64 at a 16-byte stride (2-way on the 32-bank store
+// path): measured 2.7 % slower in the same run, so the plain order stays.
+template <int LOGM>
+__device__ __forceinline__ int image_word(int j) {
+  const int low = j & ((1 << LOGM) - 1);
+  return 2 * fswz(low) + ((j >> LOGM) & 1);
+}
+
 // PRIO: 0 = head of an iteration at high wave priority (as variant 4), 1 = static priority by the
 // wave slot the workgroup occupies (one of the two workgroups of a CU always wins arbitration and runs
 // at its solo speed, the other fills its gaps), 2 = no priority hints
@@ -827,8 +856,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
                             // {0-3,12-15,20-27}.., not 16 consecutive lanes) -- measured 96 conflict cycles per
                             // wave and iteration (SQ_LDS_BANK_CONFLICT), predicted exactly by the bank model
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint64_t *acc = reinterpret_cast<uint64_t *>(smem_raw);                     // [2][N] image of -acc  } Y
-  double2 *ybuf = reinterpret_cast<double2 *>(smem_raw);                      // [2][M]                }
+  // Y: exchange buffer AND image of -acc.  Coefficient j of polynomial r lives in the complex slot of half r's
+  // pass-A layout: slot fswz(j mod M), component j / M -- a thread writes its accumulator to the slots it has
+  // just read in the last inverse pass (in place: no barrier before the write-back)
+  double2 *ybuf = reinterpret_cast<double2 *>(smem_raw);                      // [2][M]
   double2 *xbuf = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);  // [2][SLOTS]    X
   double2 *T = xbuf + (size_t)2 * SLOTS;                                      // [M/2] inverse stage tables
   double2 *TF = T + M / 2;                                                    // [M/2] forward twiddles psi[0, M/2)
@@ -882,18 +913,16 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       }
       nlo[e] = (uint64_t)0 - v0;
       nhi[e] = (uint64_t)0 - v1;
-      acc[(size_t)r * N + p] = nlo[e];
-      acc[(size_t)r * N + p + M] = nhi[e];
+      reinterpret_cast<uint64_t *>(ybuf + (size_t)r * M)[image_word<LOGM>(p)] = nlo[e];
+      reinterpret_cast<uint64_t *>(ybuf + (size_t)r * M)[image_word<LOGM>(p + M)] = nhi[e];
     }
   }
   __syncthreads();
 
-  const unsigned ybase = (unsigned)(r * N * 8);              // byte offset of polynomial r inside Y (bits >= LOGN+3)
-  uint64_t *acc_w = acc + (size_t)r * N + q;  // own coefficient p = q + e*TP lives at acc_w[e * TP]
   double2 *x_r = xbuf + (size_t)r * SLOTS;
   const double2 *x_o = xbuf + (size_t)(1 - r) * SLOTS;
   double2 *y_r = ybuf + (size_t)r * M;
-  const unsigned char *ybytes = smem_raw;
+  const unsigned char *ybytes = smem_raw + (size_t)r * M * 16;  // image of polynomial r
 
   // closest-representable digit of x with the rounding bit already added to x:
   // (int)hi >> (32 - BL)
@@ -911,22 +940,33 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 
     double2 x[8];
     {
-      // byte offset of the rotated coefficient (q - a) mod 2N, with the wrap bit (bit LOGN+3 of the byte
-      // offset) INVERTED: the image holds -acc, the operand wanted is +acc[s] when the rotation wrapped
-      // (X^N = -1) and -acc[s] = image[s] when it did not.
-      const unsigned t0 = ((unsigned)(q - a) << 3) ^ (1u << (LOGN + 3));
+      // rotated coefficient s = (p - a) mod 2N of the own point p = q + e*TP (h = 0) and of p + M (h = 1): both
+      // live in ONE slot (index s mod M), the component is bit LOGM of s.  The wrap bit (bit LOGN) is taken
+      // INVERTED: the image holds -acc, the operand wanted is +acc[s] when the rotation wrapped (X^N = -1) and
+      // -acc[s] = image[s] when it did not.
+      // everything in byte offsets: bits [4, LOGM+4) = slot index, bit LOGM+4 = component, bit LOGM+5 = wrap
+      const unsigned sb = ((unsigned)(q - a) << 4) ^ (1u << (LOGM + 5));
+      // fswz XORs index bits 4..6 into bits 1..3: byte-offset bits 8..10 into 5..7.  With TP >= 128 the points of
+      // a thread differ in index bits >= 7 only, so the term is the same for all of them
+      const unsigned swz_all = (sb >> 3) & 0xE0u;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
+        const unsigned se = sb + (unsigned)(e * TP * 16);
+        const unsigned swz = TP >= 128 ? swz_all : ((se >> 3) & 0xE0u);
+        const int hm = __builtin_amdgcn_sbfe(se, LOGM + 4, 1);       // -1 when h = 0 reads the upper component
+        const unsigned off0 = ((se & (unsigned)((M - 1) << 4)) ^ swz) | ((unsigned)hm & 8u);
+        const uint64_t va = *reinterpret_cast<const uint64_t *>(ybytes + off0);
+        const uint64_t vb = *reinterpret_cast<const uint64_t *>(ybytes + (off0 ^ 8u));
+        const int m0 = __builtin_amdgcn_sbfe(se, LOGM + 5, 1);       // h = 0: 0 take image, -1 take -image
+        const int m1 = m0 ^ hm;                                      // h = 1: adding M carries into the wrap bit iff hm
         uint64_t dd[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const unsigned se = t0 + (unsigned)((e * TP + h * M) * 8);
-          const unsigned off = (se & (unsigned)((N - 1) * 8)) | ybase;
-          const uint64_t v = *reinterpret_cast<const uint64_t *>(ybytes + off);
-          const int m32 = __builtin_amdgcn_sbfe(se, LOGN + 3, 1);       // 0: take image (= -acc[s]); -1: take -image
+          const int m32 = h == 0 ? m0 : m1;
+          const uint64_t v = h == 0 ? va : vb;
           const uint64_t mm = ((uint64_t)(uint32_t)m32 << 32) | (uint64_t)(uint32_t)m32;  // both dwords: m32 is 0 or -1
-          const uint64_t k = ROUND | (uint64_t)(uint32_t)(m32 & 1);     // carry of the negation + rounding bit of the digit
-          dd[h] = add64(add64(v ^ mm, h == 0 ? nlo[e] : nhi[e]), k);
+          const uint64_t kk = ROUND | (uint64_t)(uint32_t)(m32 & 1);   // carry of the negation + rounding bit of the digit
+          dd[h] = add64(add64(v ^ mm, h == 0 ? nlo[e] : nhi[e]), kk);
         }
         const double d0 = (double)((int)(uint32_t)(dd[0] >> 32) >> (32 - BL));
         const double d1 = (double)((int)(uint32_t)(dd[1] >> 32) >> (32 - BL));
@@ -997,17 +1037,18 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
       fft_butterflies_reg<false>(x, w);
-      __syncthreads();  // B4
     } else {
       fft_butterflies_reg<false>(x, w);  // LO_C == LO_B: requested before B3
-      __syncthreads();  // B4
     }
+    // B -> A through Y as well (three passes: in place, the thread wrote/read these slots itself; two passes:
+    // Y is free since B1).  X keeps the spectra until the next iteration: no barrier "the other half has read
+    // my spectrum" (variant 4's B4) -- every thread's reads of X lie before B5.
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+    for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
     load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
     __syncthreads();  // B5
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = x_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
+    for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
     fft_butterflies_reg<false>(x, w);
 
     // ---- untwist (negated factors: -y), round, nacc += rint(-y); the image goes back into Y ----
@@ -1016,8 +1057,8 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       const double2 v = cmul_conj(x[e], make_double2(-twi[e].x, -twi[e].y));
       nlo[e] = add64(torus_from_f64_pair(v.x), nlo[e]);
       nhi[e] = add64(torus_from_f64_pair(v.y), nhi[e]);
-      acc_w[e * TP] = nlo[e];
-      acc_w[e * TP + M] = nhi[e];
+      // in place: both words lie in the slot this thread has just read
+      reinterpret_cast<ulonglong2 *>(y_r)[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = make_ulonglong2(nlo[e], nhi[e]);
     }
     __syncthreads();  // B6
     if (PRIO == 0) __builtin_amdgcn_s_setprio(3);
@@ -1025,8 +1066,13 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 
   // ---- sample extract from the image of -acc: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
   uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
-  for (int j = tid; j < N; j += blockDim.x) out[j] = (j == 0) ? (uint64_t)0 - acc[0] : acc[N - j];
-  if (tid == 0) out[N] = (uint64_t)0 - acc[N];
+  const uint64_t *img = reinterpret_cast<const uint64_t *>(smem_raw);  // polynomial 0 (polynomial 1 follows at word 2M)
+  for (int j = tid; j < N; j += blockDim.x) {
+    const int jj = (j == 0) ? 0 : N - j;
+    const uint64_t v = img[image_word<LOGM>(jj)];
+    out[j] = (j == 0) ? (uint64_t)0 - v : v;
+  }
+  if (tid == 0) out[N] = (uint64_t)0 - img[(size_t)2 * M + image_word<LOGM>(0)];
 }
 
 // ------------------------------------------------------------------------------------------
