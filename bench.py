@@ -280,6 +280,16 @@ def main():
     check(lib.fhes_arena_download(ctx, int(out_handles[0]), B * n_out, res_host.ctypes.data))
     dt_pcie = time.perf_counter() - t1
     pcie_bytes = cts_host.nbytes + res_host.nbytes
+    # untimed extra pass: the same step with the VALU keyswitch (the matrix-core keyswitch is the default; both
+    # compute the same integers -- DESIGN.md 7, "On north_star's no MFMA")
+    free_outputs(B)
+    sync()
+    check(lib.fhes_set_keyswitch_mfma_min(ctx, 0))
+    t2 = time.perf_counter()
+    run_batch(B)
+    sync()
+    dt_valu_ks = time.perf_counter() - t2
+    check(lib.fhes_set_keyswitch_mfma_min(ctx, 1))
     text, pat = pairs[0]
 
     def measure_sharded():
@@ -417,6 +427,9 @@ def main():
                                       f"position-sharded single-string operations over the same ranks: see `sharded`"},
             "result_ok": bool(ok),
             "finds_per_s": round(B * world_size * args.steps / dt_max, 2),
+            "keyswitch": {"path": "i8 matrix product on the matrix cores (v_mfma_i32_16x16x64_i8), exact",
+                          "pbs_per_s_rank0_with_valu_keyswitch": round(B * pbs_per_find / dt_valu_ks, 2),
+                          "note": "one untimed step of the same batch with the VALU keyswitch kernel (fhes_set_keyswitch_mfma_min(ctx, 0)): same bits"},
             "pcie_inclusive": {"pbs_per_s_rank0": round(B * pbs_per_find / dt_pcie, 2), "step_ms": round(dt_pcie * 1e3, 1),
                                "host_bytes_moved": int(pcie_bytes),
                                "note": "one extra untimed-for-`value` step on rank 0 with the upload of its input ciphertexts and the download of its results inside the clock"},
