@@ -255,3 +255,36 @@ def test_one_level_decomposition_noise_scales_with_the_base(libs):
     assert 47.5 < rms["default"] < 50.0, rms
     assert 52.5 < rms["default_b18"] < 54.8, rms
     assert 4.0 < rms["default_b18"] - rms["default"] < 5.6, rms     # 2^5 from the 5 dropped bits
+
+
+def test_forward_transform_internal_form_and_tables(w):
+    """the forward transform works on an internal form -- even slots are the true evaluations,
+    odd slots hold the true value divided by -t (t = last-stage twiddle of the pair); the Fourier key carries
+    t^2 on its odd slots.  psi / odd_fix are consistent with the root table and the slot exponents."""
+    N, M = w.N, w.N // 2
+    rng = np.random.default_rng(5)
+    a = rng.integers(-(1 << 22), 1 << 22, size=N).astype(np.int64)
+    true_s, held = np.zeros(2 * M), np.zeros(2 * M)
+    w.orc.oracle_fft_forward_i64(w.oc, ptr(a), ptr(true_s))
+    w.orc.oracle_fft_forward_internal(w.oc, ptr(a), ptr(held))
+    ct, ch = true_s.view(np.complex128), held.view(np.complex128)
+    root = np.ctypeslib.as_array(C.cast(w.orc.oracle_root_table(w.oc), C.POINTER(C.c_double)), (4 * N,)).view(np.complex128)
+    sexp = np.ctypeslib.as_array(C.cast(w.orc.oracle_slot_exp_table(w.oc), C.POINTER(C.c_int32)), (M,))
+    psi = np.ctypeslib.as_array(C.cast(w.orc.oracle_psi_table(w.oc), C.POINTER(C.c_double)), (2 * M,)).view(np.complex128)
+    fix = np.ctypeslib.as_array(C.cast(w.orc.oracle_odd_fix_table(w.oc), C.POINTER(C.c_double)), (2 * M,)).view(np.complex128)
+    # true spectrum = direct evaluation of b(Y) = sum (a_j + i a_{j+M}) Y^j at root^slot_exp[m]
+    b = a[:M] + 1j * a[M:]
+    y = root[sexp]
+    direct = np.array([np.sum(b * y[m] ** np.arange(M)) for m in range(M)])
+    assert np.allclose(ct, direct, rtol=0, atol=1e-6 * np.abs(direct).max())
+    assert np.array_equal(ct[0::2], ch[0::2])                       # even slots: identical bits
+    t = psi[M // 2:]                                               # last stage: one twiddle per slot pair
+    assert np.array_equal(t, root[sexp[0::2]])                     # = the root of the pair's even slot
+    assert np.allclose(ch[1::2] * (-t), ct[1::2], rtol=0, atol=1e-6 * np.abs(direct).max())
+    assert np.array_equal(fix[1::2], root[(2 * sexp[0::2].astype(np.int64)) % (2 * N)])   # t^2, from the table
+    # every stage's twiddle is (root of the block's first slot)^half
+    logm = M.bit_length() - 1
+    for l in range(logm):
+        nb, half = 1 << l, M >> (l + 1)
+        e = (sexp[np.arange(nb) * 2 * half].astype(np.int64) * half) % (2 * N)
+        assert np.array_equal(psi[nb:2 * nb], root[e]), l
