@@ -1174,15 +1174,14 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
   double2 wfa[7];  // forward pass A: the same 7 twiddles for every thread
 #pragma unroll
   for (int kk = 0; kk < 7; ++kk) wfa[kk] = psi[1 + kk];
-  double2 wA[7], wB[7], wC[7], wfB[7], wfC[7], cdr[8], twir[8];  // latency build only (dead otherwise)
+  // latency build only (dead otherwise): the inverse twiddles, the lane-pair constants and the untwist factors
+  // stay in registers; the forward twiddles come from LDS in both builds (resident they pushed the latency
+  // build to 502 registers, of which only 256 are VALU-addressable: 266 v_accvgpr_read per kernel)
+  double2 wA[7], wB[7], wC[7], cdr[8], twir[8];
   if (LAT) {
     load_pass_twiddles<LOGM, LO_A>(wA, q, tw);
     load_pass_twiddles<LOGM, LO_B>(wB, q, tw);
-    load_fwd_twiddles<LOGM, LO_B>(wfB, q, psi);
-    if (NP == 3) {
-      load_pass_twiddles<LOGM, LO_C>(wC, q, tw);
-      load_fwd_twiddles<LOGM, LO_C>(wfC, q, psi);
-    }
+    if (NP == 3) load_pass_twiddles<LOGM, LO_C>(wC, q, tw);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       cdr[e] = cdpp_q[e * TP];
@@ -1329,14 +1328,14 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = bufB[e * SB];
-    if (LAT) fft_butterflies_reg<true>(x, wfB); else fft_fwd_butterflies_tab<LOGM, LO_B>(x, q, TF);
+    fft_fwd_butterflies_tab<LOGM, LO_B>(x, q, TF);
     if (NP == 3) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) bufB[e * SB] = x[e];
       __builtin_amdgcn_wave_barrier();  // B -> C stays inside a wave (q >> 6 is index bit LOGM-1 in both layouts)
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = bufC[e * SC];
-      if (LAT) fft_butterflies_reg<true>(x, wfC); else fft_fwd_butterflies_tab<LOGM, LO_C>(x, q, TF);
+      fft_fwd_butterflies_tab<LOGM, LO_C>(x, q, TF);
     }
     {
       double2 cd[8];  // constants of the lane-pair stage (latency build: registers; otherwise the LDS copy)
