@@ -388,11 +388,21 @@ static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
   }
   int variant = ctx->br_variant;
   if (variant == 0) variant = 5;  // every launch size
-  if (variant != 1 && (variant < 5 || variant > 7)) return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d does not exist (1, 5, 6, 7)", variant);
+  if (variant != 1 && (variant < 5 || variant > 10 || variant == 8))
+    return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d does not exist (1, 5, 6, 7; 9 and 10 are timing-only ablations)", variant);
   if (ctx->dims.pbs_base_log != 23 && variant == 1)
     return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant 1 is instantiated for pbs_base_log 23 only");
-  if (ctx->dims.N == 2048)
-    return variant == 1 ? launch_br_v1<11>(ctx, d) : variant == 5 ? launch_br_v5<11>(ctx, d) : variant == 6 ? launch_br_v5<11, 1>(ctx, d) : launch_br_v5<11, 2>(ctx, d);
+  if (ctx->dims.N == 2048) {
+    switch (variant) {
+      case 1: return launch_br_v1<11>(ctx, d);
+      case 5: return launch_br_v5<11, 0>(ctx, d);
+      case 6: return launch_br_v5<11, 1>(ctx, d);
+      case 7: return launch_br_v5<11, 2>(ctx, d);
+      case 9: return launch_br_v5<11, 4>(ctx, d);   // timing-only ablation: no LDS exchanges (WRONG results)
+      default: return launch_br_v5<11, 5>(ctx, d);  // timing-only ablation: no butterflies (WRONG results)
+    }
+  }
+  if (variant > 7) return fail(FHES_ERR_UNSUPPORTED, "the ablation builds exist for N = 2048 only");
   return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 5 ? launch_br_v5<8>(ctx, d) : variant == 6 ? launch_br_v5<8, 1>(ctx, d) : launch_br_v5<8, 2>(ctx, d);
 }
 
@@ -791,7 +801,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  if (v < 0 || v > 7) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
+  if (v < 0 || v > 10) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
   ctx->br_variant = v;
   return FHES_OK;
 }

@@ -841,6 +841,10 @@ __device__ __forceinline__ int image_word(int j) {
 // PRIO: 0 = head of an iteration at high wave priority (as variant 4), 1 = static priority by the
 // wave slot the workgroup occupies (one of the two workgroups of a CU always wins arbitration and runs
 // at its solo speed, the other fills its gaps), 2 = no priority hints
+// PRIO 4 / 5: timing-only ablations (WRONG results; scripts/bench_pbs.py variants 9 / 10, round 3):
+// 4 = without the LDS exchanges between the passes (rotated reads, table reads and the image write-back stay),
+// 5 = without the butterfly passes and lane-pair stages (every LDS operation stays).
+#define FHES_PASS(FWD, x, w) do { if (PRIO != 5) fft_butterflies_reg<FWD>(x, w); } while (0)
 template <int LOGN, int BL, int PRIO>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v5_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
@@ -984,9 +988,11 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       }
     }
     double2 w[7];
-    fft_butterflies_reg<true>(x, wfa);
+    FHES_PASS(true, x, wfa);
+    if (PRIO != 4) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
+      for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
+    }
     load_fwd_twiddles<LOGM, LO_B>(w, q, TF);
     __syncthreads();  // B1 (also: every rotated read of Y is done)
     if (PRIO == 0) __builtin_amdgcn_s_setprio(0);
@@ -995,25 +1001,40 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     double2 cd[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cd[e] = buf_load_d2(rs_cd, voff_q, (unsigned)(e * TP * 16));
+    if (PRIO != 4) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = x_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
-    fft_butterflies_reg<true>(x, w);
+      for (int e = 0; e < 8; ++e) x[e] = x_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+    }
+    FHES_PASS(true, x, w);
     if (NP == 3) {
+      if (PRIO != 4) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+        for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+      }
       load_fwd_twiddles<LOGM, LO_C>(w, q, TF);
       __builtin_amdgcn_wave_barrier();
+      if (PRIO != 4) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
-      fft_butterflies_reg<true>(x, w);
+        for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
+      }
+      FHES_PASS(true, x, w);
     }
-    fft_fwd_stage0_dpp(x, cd);
+    if (PRIO != 5) fft_fwd_stage0_dpp(x, cd);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e].x += cd[e].x + cd[e].y;  // keeps the loads of the constants alive
+    }
     load_pass_twiddles_tab<LOGM, LO_C>(w, q, T, wnone);  // first inverse pass (LO_C == LO_B when there are two)
 
+    if (PRIO != 4) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+      for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+    }
     __syncthreads();  // B3
-    if (r == 0) {
+    if (PRIO == 4) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], x[e], g0[e], g1[e]);
+    } else if (r == 0) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], x_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], g0[e], g1[e]);
     } else {
@@ -1027,29 +1048,37 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 #pragma unroll
     for (int e = 0; e < 4; ++e) wtop[e] = buf_load_d2(rs_twg, voff_q, (unsigned)(e * TP * 16));
 
-    fft_stage_bit0_dpp(x, sgn);
+    if (PRIO != 5) fft_stage_bit0_dpp(x, sgn);
     if (NP == 3) {
-      fft_butterflies_reg<false>(x, w);  // the pass-C twiddles requested before B3
+      FHES_PASS(false, x, w);  // the pass-C twiddles requested before B3
+      if (PRIO != 4) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+        for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))] = x[e];
+      }
       load_pass_twiddles_tab<LOGM, LO_B>(w, q, T, wnone);
       __builtin_amdgcn_wave_barrier();  // C -> B stays inside a wave
+      if (PRIO != 4) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
-      fft_butterflies_reg<false>(x, w);
+        for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+      }
+      FHES_PASS(false, x, w);
     } else {
-      fft_butterflies_reg<false>(x, w);  // LO_C == LO_B: requested before B3
+      FHES_PASS(false, x, w);  // LO_C == LO_B: requested before B3
     }
     // B -> A through Y as well (three passes: in place, the thread wrote/read these slots itself; two passes:
     // Y is free since B1).  X keeps the spectra until the next iteration: no barrier "the other half has read
     // my spectrum" (variant 4's B4) -- every thread's reads of X lie before B5.
+    if (PRIO != 4) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+      for (int e = 0; e < 8; ++e) y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))] = x[e];
+    }
     load_pass_twiddles_tab<LOGM, LO_A>(w, q, T, wtop);
     __syncthreads();  // B5
+    if (PRIO != 4) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
-    fft_butterflies_reg<false>(x, w);
+      for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
+    }
+    FHES_PASS(false, x, w);
 
     // ---- untwist (negated factors: -y), round, nacc += rint(-y); the image goes back into Y ----
 #pragma unroll
