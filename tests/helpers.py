@@ -13,6 +13,31 @@ def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def effective_cores():
+    """host cores this process may really use: min(cpu_count, affinity mask, cgroup CPU quota) -- the GPU box
+    shows 256 logical CPUs and grants 16; an OpenMP team of 256 threads on a 16-core quota only gets throttled"""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 class World:
     """One key set (client key + standard-domain server keys) plus an oracle context."""
 

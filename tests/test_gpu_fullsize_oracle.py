@@ -1,0 +1,95 @@
+"""Oracle-bit parity at FULL size for BASELINE configs 3, 4 and 5: the compiled program
+runs on the device through the C ABI and on the CPU oracle (`Prog.run_oracle`) on the same seeded input
+ciphertexts; every word of every output ciphertext must agree, and the decrypted result must be the
+`std::str` answer.  Reference: `search.rs:17-41` (contains / find_all), `split.rs:238-341` (split_opt),
+`search.rs:23-28` + `mod.rs:315-355` (find).  The oracle needs about 40 ms per bootstrap and core, so the
+three cases together take a few minutes of host time on the GPU box's 16 cores."""
+import os
+
+import numpy as np
+import pytest
+
+from fhe_string_amd._lib import check
+from tests.helpers import effective_cores, ptr, world
+from tests.progs import Prog, decode_result, num_blocks_usize, string_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+def run_on_device(w, p, cts):
+    """one program run through the Level-1 ABI; returns the output ciphertexts"""
+    ctx = w.ctx()
+    h = check(w.lib.fhes_arena_alloc(ctx, len(cts)))
+    check(w.lib.fhes_arena_upload(ctx, h, len(cts), ptr(cts)))
+    in_h = np.arange(h, h + len(cts), dtype=np.int32)
+    out_h = np.zeros(p.n_outputs, dtype=np.int32)
+    check(w.lib.fhes_program_run(ctx, p.h, ptr(in_h), ptr(out_h)))
+    assert np.array_equal(out_h, out_h[0] + np.arange(p.n_outputs))
+    dev = np.zeros((p.n_outputs, w.W), dtype=np.uint64)
+    check(w.lib.fhes_arena_download(ctx, int(out_h[0]), p.n_outputs, ptr(dev)))
+    check(w.lib.fhes_arena_free(ctx, h, len(cts)))
+    check(w.lib.fhes_arena_free(ctx, int(out_h[0]), p.n_outputs))
+    return dev
+
+
+def assert_same_words(dev, ref, what):
+    bad = np.nonzero(np.any(ref != dev, axis=1))[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {len(ref)} output ciphertexts differ from the oracle, first {bad[:8]}"
+
+
+def test_config4_contains_1024_every_output_word_against_oracle(libs):
+    """config 4: 1000 characters padded to 1024, 8-character pattern, l = 1024 (6 usize blocks):
+    37.8 k bootstraps in 7 levels."""
+    w = world("default", l=1024)
+    bu = num_blocks_usize(1024)
+    rng = np.random.default_rng(0xF4E50004)
+    s = "".join(chr(c) for c in rng.integers(0x20, 0x7F, size=1000))
+    pat = s[700:708]
+    p = Prog(w.p, "contains", [1025, 9], bu)
+    cts = w.encrypt(np.concatenate([string_blocks(s, 1024), string_blocks(pat)]))
+    dev = run_on_device(w, p, cts)
+    assert bool(w.decrypt(dev)[0] & 1) is True
+    ref, _ = p.run_oracle(w, cts, threads=effective_cores())
+    assert_same_words(dev, ref, f"contains 1024/8 ({p.n_pbs} PBS, {p.n_levels} levels)")
+
+
+def config3_input():
+    rng = np.random.default_rng(0xF4E50003)
+    chars = [chr(c) for c in rng.integers(0x61, 0x7B, size=256)]
+    for i in range(7, 256, 8):
+        chars[i] = ","
+    return "".join(chars)
+
+
+def test_config3_split_256_logdepth_every_output_word_against_oracle(libs):
+    """config 3: split of a 256-character input on a 1-character encrypted separator, l = 256 (5 usize
+    blocks), the log-depth form (14.3 k bootstraps; the faithful circuit's 152 k would take the oracle
+    seven minutes -- its outputs are compared with this form's block by block on the plaintext model in
+    tests/test_circuits_plain.py and decrypted on the device in test_config3_split_256)."""
+    w = world("default", l=256)
+    bu = num_blocks_usize(256)
+    assert bu == 5
+    s = config3_input()
+    p = Prog(w.p, "split_logdepth", [257, 2], bu)
+    cts = w.encrypt(np.concatenate([string_blocks(s), string_blocks(",")]))
+    dev = run_on_device(w, p, cts)
+    assert decode_result("split", w.decrypt(dev), bu, s) == s.split(",")
+    ref, _ = p.run_oracle(w, cts, threads=effective_cores())
+    assert_same_words(dev, ref, f"split_logdepth 256/1 ({p.n_pbs} PBS, {p.n_levels} levels)")
+
+
+def test_config5_find_512_multibit2_every_output_word_against_oracle(libs):
+    """config 5: find on 500 characters padded to 512, 3-character pattern, l = 1023, multi-bit g = 2
+    parameters, log-depth form (11.5 k multi-bit bootstraps)."""
+    w = world("multibit2", l=1023, seed=0xF4E50005)
+    bu = num_blocks_usize(1023)
+    rng = np.random.default_rng(0xF4E50005)
+    body = "".join(chr(c) for c in rng.integers(0x21, 0x7F, size=494))
+    text = "  " + body[:200] + " " + body[200:] + "   "
+    pat = text[301:304]
+    p = Prog(w.p, "find_logdepth", [513, 4], bu)
+    cts = w.encrypt(np.concatenate([string_blocks(text, 512), string_blocks(pat)]))
+    dev = run_on_device(w, p, cts)
+    assert decode_result("find", w.decrypt(dev), bu) == text.find(pat)
+    ref, _ = p.run_oracle(w, cts, threads=effective_cores())
+    assert_same_words(dev, ref, f"find_logdepth 512/3 multibit2 ({p.n_pbs} PBS, {p.n_levels} levels)")

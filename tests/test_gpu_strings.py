@@ -13,7 +13,7 @@ import pytest
 
 from fhe_string_amd import api
 from fhe_string_amd._lib import check
-from tests.helpers import ptr, world
+from tests.helpers import effective_cores, ptr, world
 from tests.progs import Prog, decode_result, num_blocks_usize, string_blocks
 
 pytestmark = pytest.mark.gpu
@@ -70,7 +70,7 @@ def test_find_config2_bit_exact_against_oracle(libs):
     assert np.array_equal(out_handles, out_handles[0] + np.arange(p.n_outputs))
     check(w.lib.fhes_arena_download(ctx, int(out_handles[0]), p.n_outputs, ptr(dev)))
     assert decode_result("find", w.decrypt(dev), bu) == s.find(pat) == 37
-    ref, _ = p.run_oracle(w, cts, threads=os.cpu_count() or 8)
+    ref, _ = p.run_oracle(w, cts, threads=effective_cores())
     nbad = int(np.count_nonzero(ref != dev))
     assert nbad == 0, f"{nbad} output words differ between the HIP path and the oracle"
     check(w.lib.fhes_arena_free(ctx, h, len(cts)))
