@@ -3,13 +3,40 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <shared_mutex>
+#include <thread>
 #include <vector>
 
 #include "common.h"
 
 struct fhes_program;
+
+namespace fhes {
+// An execution lane: a HIP stream with the per-launch scratch its launches use.  The context's own stream is
+// the MAIN lane (asynchronous, what a single caller sees); a program run that finds the main lane occupied by
+// another caller's work takes a SIDE lane -- own stream, own keyswitch scratch, own slot map -- so that the
+// reference's concurrent callers (rayon workers, /root/reference/src/ciphertext/search.rs:34-40, mod.rs:292
+// `T: Sync`) overlap on the device instead of queueing behind one mutex.
+struct Lane {
+  hipStream_t stream = nullptr;
+  uint64_t *ks_out = nullptr;   // [nodes][ks_stride]
+  int64_t ks_out_nodes = 0;
+  int8_t *ks_dig = nullptr;     // digits of a wide launch, A-fragment order: [ceil(nodes / 128) * 8][ksteps][64][16]
+  uint64_t *ks_body = nullptr;  // [nodes]
+  int32_t *slot_map = nullptr;  // slot map of the program run this lane carries
+  size_t slot_map_cap = 0;
+  bool is_main = false;
+  bool busy = false;            // side lanes: taken by a running call (guarded by fhes_ctx::mu)
+};
+struct RunCounters {            // what one call adds to fhes_stats (merged under fhes_ctx::mu)
+  uint64_t pbs = 0, launches = 0, linear = 0;
+};
+}  // namespace fhes
 
 struct fhes_ctx {
   fhes_params p;
@@ -17,9 +44,24 @@ struct fhes_ctx {
   int device = 0;
   int n_cus = 256;
   uint64_t uid = 0;          // unique per context (program images are keyed by it, not by address)
-  unsigned attr_done = 0;    // bit v: max-dynamic-LDS attribute set for blind-rotate variant v on this device
-  hipStream_t stream = nullptr;
+  std::atomic<unsigned> attr_done{0};  // bit v: max-dynamic-LDS attribute set for blind-rotate variant v on this device
+  hipStream_t stream = nullptr;   // the main lane's stream (== main.stream)
+  // Locking: `mu` guards the host-side state (arena free list, LUT registry, lanes, stats).  A program run
+  // holds it while it sets up and while it cleans up, NOT while it queues its launches; `arena_rw` is held
+  // shared while launches are queued (they read `arena`) and exclusively by an arena growth, which replaces
+  // the allocation.  Order: mu before arena_rw; nobody waits for mu while holding arena_rw.
   std::mutex mu;
+  std::shared_mutex arena_rw;
+  std::condition_variable lane_cv;
+  fhes::Lane main;                                 // wraps `stream` and the scratch pointers below
+  std::vector<std::unique_ptr<fhes::Lane>> side;   // created on demand, at most kMaxSideLanes
+  static constexpr int kMaxSideLanes = 15;         // main + 15 = the 16 hardware queues the library asks for (engine.hip, runtime_defaults)
+  hipEvent_t main_done_ev = nullptr;               // recorded on the main stream whenever a call hands the main lane back: "every
+                                                   // COMPLETED call's work" -- what a side lane has to wait for, since only a returned
+                                                   // call can have given anybody a handle (a call still queueing on the main lane is not
+                                                   // waited for: that would put the side lanes behind it)
+  bool main_held = false;                          // a call is queueing launches on the main lane
+  std::thread::id main_user{};                     // the thread whose work the main stream last received
 
   // ciphertext arena: u64 [capacity][ct_stride]
   uint64_t *arena = nullptr;
@@ -50,11 +92,7 @@ struct fhes_ctx {
   int lut_capacity = 0;
   std::vector<std::vector<uint64_t>> lut_tables;
 
-  // per-launch scratch
-  uint64_t *ks_out = nullptr;
-  int64_t ks_out_nodes = 0;
-  int8_t *ks_dig = nullptr;    // digits of a wide launch, A-fragment order: [ceil(nodes / 128) * 8][ksteps][64][16]
-  uint64_t *ks_body = nullptr; // [nodes]
+  // per-launch scratch: in the lanes (`main`, `side`)
   unsigned char *desc_buf = nullptr;  // staging for fhes_pbs_batch descriptors
   size_t desc_cap = 0;
 
@@ -89,9 +127,24 @@ int hip_fail(hipError_t e, const char *what);
     if (_e != hipSuccess) return fhes::hip_fail(_e, #call);   \
   } while (0)
 
-// launches keyswitch + blind rotate for nodes [first, first+count) of n_inst instances
-int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst = 1);
-int launch_linear(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst = 1);
+// launches keyswitch + blind rotate for nodes [first, first+count) of n_inst instances on `lane`
+// (the caller owns the lane; counters are merged into the context's stats by merge_counters_locked)
+int launch_pbs(fhes_ctx *ctx, Lane &lane, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst, RunCounters *rc);
+int launch_linear(fhes_ctx *ctx, Lane &lane, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst, RunCounters *rc);
+void merge_counters_locked(fhes_ctx *ctx, const RunCounters &rc);
+// Lane hand-out.  acquire_main_locked waits (on lane_cv, releasing mu) until no call is queueing on the main
+// lane and takes it; acquire_lane_locked gives the main lane to a caller who finds it free and idle (or whose
+// own work is the last it received) and a side lane to everybody else.
+void acquire_main_locked(fhes_ctx *ctx, std::unique_lock<std::mutex> &lk);
+int acquire_lane_locked(fhes_ctx *ctx, std::unique_lock<std::mutex> &lk, Lane **out);
+void release_lane_locked(fhes_ctx *ctx, Lane *lane);
+int ensure_slot_map(Lane &lane, size_t entries);
+struct MainLaneHold {  // Level-0 entry points: hold mu for the whole call AND the main lane
+  fhes_ctx *ctx;
+  std::unique_lock<std::mutex> lk;
+  explicit MainLaneHold(fhes_ctx *c) : ctx(c), lk(c->mu) { acquire_main_locked(c, lk); }
+  ~MainLaneHold() { release_lane_locked(ctx, &ctx->main); }
+};
 int32_t arena_alloc_locked(fhes_ctx *ctx, int32_t count);
 int arena_free_locked(fhes_ctx *ctx, int32_t first, int32_t count);
 int32_t lut_register_locked(fhes_ctx *ctx, const uint64_t *table, int32_t n);

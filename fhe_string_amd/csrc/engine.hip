@@ -15,6 +15,14 @@
 
 namespace fhes {
 
+// HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share one run their kernels
+// one after the other, so with the default at most ~2-4 of a context's lanes make progress at a time (measured:
+// 4 concurrent finds 463 ms with 4 queues, 265 ms with 16; one find 221 ms).  The ROCm runtime reads the variable
+// when it initialises, i.e. at the process's first HIP call: this constructor runs when the library is loaded
+// and only supplies a default -- a value the host application has set wins, and an application that has touched
+// HIP before it loads this library has to set it itself.
+__attribute__((constructor)) static void runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 // registry of live contexts: ciphertext objects may outlive their server key
 static std::mutex g_live_mu;
 static std::set<fhes_ctx *> g_live;
@@ -127,7 +135,10 @@ static int arena_grow_locked(fhes_ctx *ctx, int64_t min_capacity) {
   const size_t row = (size_t)ctx->ct_stride * 8;
   size_t free_b = 0, total_b = 0;
   FHES_HIP(hipSetDevice(ctx->device));
-  FHES_HIP(hipStreamSynchronize(ctx->stream));
+  // no launch may be queued while the allocation is replaced (runs hold arena_rw shared while they queue), and
+  // everything queued on any lane must have finished with the old one
+  std::unique_lock<std::shared_mutex> grow_lk(ctx->arena_rw);
+  FHES_HIP(hipDeviceSynchronize());
   FHES_HIP(hipMemGetInfo(&free_b, &total_b));
   const int64_t fit = (int64_t)((free_b - std::min<size_t>(free_b, (size_t)1 << 30)) / row);  // keep 1 GiB for keys / staging
   if (cap > fit) cap = fit;
@@ -243,44 +254,111 @@ static dev::NodeDesc make_desc(const DevNodeArrays &a, int32_t first, int32_t co
   return d;
 }
 
-static int ensure_ks_out(fhes_ctx *ctx, int64_t nodes) {
-  if (nodes <= ctx->ks_out_nodes) return FHES_OK;
-  if (ctx->ks_out) FHES_HIP(hipFree(ctx->ks_out));
-  if (ctx->ks_dig) FHES_HIP(hipFree(ctx->ks_dig));
-  if (ctx->ks_body) FHES_HIP(hipFree(ctx->ks_body));
-  ctx->ks_out = nullptr; ctx->ks_dig = nullptr; ctx->ks_body = nullptr;
-  ctx->ks_out_nodes = 0;
-  const int64_t cap = ((std::max<int64_t>(nodes, 1024) + 127) / 128) * 128;  // whole 128-row tiles of the MFMA keyswitch
-  FHES_HIP(hipMalloc(&ctx->ks_out, (size_t)cap * ctx->ks_stride * sizeof(uint64_t)));
-  FHES_HIP(hipMalloc(&ctx->ks_dig, (size_t)cap * ctx->dims.big * ctx->dims.ks_level));
-  FHES_HIP(hipMalloc(&ctx->ks_body, (size_t)cap * sizeof(uint64_t)));
-  ctx->ks_out_nodes = cap;
+// keyswitch scratch of a lane (its owner calls this; a lane's earlier launches have been queued on its own
+// stream, and hipFree waits for the device)
+static int ensure_ks_out(fhes_ctx *ctx, Lane &lane, int64_t nodes) {
+  if (nodes <= lane.ks_out_nodes) return FHES_OK;
+  if (lane.ks_out) FHES_HIP(hipFree(lane.ks_out));
+  if (lane.ks_dig) FHES_HIP(hipFree(lane.ks_dig));
+  if (lane.ks_body) FHES_HIP(hipFree(lane.ks_body));
+  lane.ks_out = nullptr; lane.ks_dig = nullptr; lane.ks_body = nullptr;
+  lane.ks_out_nodes = 0;
+  // side lanes carry single operations (levels of a few to a few thousand bootstraps): start small
+  const int64_t floor_nodes = lane.is_main ? 1024 : 128;
+  const int64_t cap = ((std::max<int64_t>(nodes, floor_nodes) + 127) / 128) * 128;  // whole 128-row tiles of the MFMA keyswitch
+  FHES_HIP(hipMalloc(&lane.ks_out, (size_t)cap * ctx->ks_stride * sizeof(uint64_t)));
+  FHES_HIP(hipMalloc(&lane.ks_dig, (size_t)cap * ctx->dims.big * ctx->dims.ks_level));
+  FHES_HIP(hipMalloc(&lane.ks_body, (size_t)cap * sizeof(uint64_t)));
+  lane.ks_out_nodes = cap;
   return FHES_OK;
 }
 
+int ensure_slot_map(Lane &lane, size_t entries) {
+  if (entries <= lane.slot_map_cap) return FHES_OK;
+  FHES_HIP(hipStreamSynchronize(lane.stream));
+  if (lane.slot_map) FHES_HIP(hipFree(lane.slot_map));
+  lane.slot_map = nullptr;
+  lane.slot_map_cap = 0;
+  FHES_HIP(hipMalloc(&lane.slot_map, 4 * entries));
+  lane.slot_map_cap = entries;
+  return FHES_OK;
+}
+
+// ---- lanes ---------------------------------------------------------------------------------
+void acquire_main_locked(fhes_ctx *ctx, std::unique_lock<std::mutex> &lk) {
+  ctx->lane_cv.wait(lk, [&] { return !ctx->main_held; });
+  ctx->main_held = true;
+  ctx->main_user = std::this_thread::get_id();
+}
+
+int acquire_lane_locked(fhes_ctx *ctx, std::unique_lock<std::mutex> &lk, Lane **out) {
+  const auto me = std::this_thread::get_id();
+  for (;;) {
+    // the main lane: nobody is queueing on it, and either this thread's own work is the last it received (a
+    // single caller keeps its asynchronous pipeline) or the stream has drained
+    if (!ctx->main_held && (ctx->main_user == me || ctx->main_user == std::thread::id() ||
+                            hipStreamQuery(ctx->stream) == hipSuccess)) {
+      (void)hipGetLastError();  // hipStreamQuery reports "not ready" as an error value
+      ctx->main_held = true;
+      ctx->main_user = me;
+      *out = &ctx->main;
+      return FHES_OK;
+    }
+    (void)hipGetLastError();
+    for (auto &l : ctx->side)
+      if (!l->busy) { l->busy = true; *out = l.get(); return FHES_OK; }
+    if ((int)ctx->side.size() < fhes_ctx::kMaxSideLanes) {
+      auto l = std::make_unique<Lane>();
+      FHES_HIP(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+      l->busy = true;
+      *out = l.get();
+      ctx->side.push_back(std::move(l));
+      return FHES_OK;
+    }
+    ctx->lane_cv.wait(lk);  // every lane is taken: wait for one to come back
+  }
+}
+
+void release_lane_locked(fhes_ctx *ctx, Lane *lane) {
+  if (!lane) return;
+  if (lane == &ctx->main) {
+    if (ctx->main_held && ctx->main_done_ev) (void)hipEventRecord(ctx->main_done_ev, ctx->stream);
+    ctx->main_held = false;
+  } else {
+    lane->busy = false;
+  }
+  ctx->lane_cv.notify_all();
+}
+
+void merge_counters_locked(fhes_ctx *ctx, const RunCounters &rc) {
+  ctx->stats.pbs_count += rc.pbs;
+  ctx->stats.pbs_launches += rc.launches;
+  ctx->stats.linear_count += rc.linear;
+}
+
 // wide launches: digits -> i8 matrix product on the matrix cores (kernels.hip.h K1b); same integers, same bits
-static int launch_keyswitch_mfma(fhes_ctx *ctx, const dev::NodeDesc &d) {
+static int launch_keyswitch_mfma(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   const Dims &dm = ctx->dims;
   const int ksteps = dm.big * dm.ks_level / 64;
-  hipLaunchKernelGGL(dev::keyswitch_digits_kernel, dim3(d.v_count), dim3(128), 0, ctx->stream, d, ctx->arena,
-                     ctx->ct_stride, dm.big, dm.ks_level, dm.ks_base_log, ksteps, ctx->ks_dig, ctx->ks_body);
+  hipLaunchKernelGGL(dev::keyswitch_digits_kernel, dim3(d.v_count), dim3(128), 0, lane.stream, d, ctx->arena,
+                     ctx->ct_stride, dm.big, dm.ks_level, dm.ks_base_log, ksteps, lane.ks_dig, lane.ks_body);
   FHES_HIP(hipGetLastError());
   const int row_blocks = (d.v_count + 127) / 128, col_blocks = (ctx->ks_n_wb + 1) / 2;
   // few row blocks: split the digit range so that the launch still covers the chip (u64 atomics: exact)
   int splits = 1;
   while (splits < 16 && row_blocks * col_blocks * splits < 512 && ksteps % (splits * 2) == 0) splits *= 2;
-  if (splits > 1) FHES_HIP(hipMemsetAsync(ctx->ks_out, 0, (size_t)d.v_count * ctx->ks_stride * sizeof(uint64_t), ctx->stream));
-  hipLaunchKernelGGL(dev::keyswitch_mfma_kernel, dim3(row_blocks, col_blocks, splits), dim3(256), 0, ctx->stream,
-                     ctx->ks_dig, ctx->ksk_pk, ctx->ks_body, ctx->ks_out, ctx->ks_stride, ksteps, ctx->ks_n_wb, dm.n,
+  if (splits > 1) FHES_HIP(hipMemsetAsync(lane.ks_out, 0, (size_t)d.v_count * ctx->ks_stride * sizeof(uint64_t), lane.stream));
+  hipLaunchKernelGGL(dev::keyswitch_mfma_kernel, dim3(row_blocks, col_blocks, splits), dim3(256), 0, lane.stream,
+                     lane.ks_dig, ctx->ksk_pk, lane.ks_body, lane.ks_out, ctx->ks_stride, ksteps, ctx->ks_n_wb, dm.n,
                      d.v_count, ksteps / splits, splits > 1 ? 1 : 0);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
 
-static int launch_keyswitch(fhes_ctx *ctx, const dev::NodeDesc &d) {
+static int launch_keyswitch(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   const Dims &dm = ctx->dims;
-  if (ctx->ks_mfma_min > 0 && d.v_count >= ctx->ks_mfma_min && ctx->ksk_pk) return launch_keyswitch_mfma(ctx, d);
-  FHES_HIP(hipMemsetAsync(ctx->ks_out, 0, (size_t)d.v_count * ctx->ks_stride * sizeof(uint64_t), ctx->stream));
+  if (ctx->ks_mfma_min > 0 && d.v_count >= ctx->ks_mfma_min && ctx->ksk_pk) return launch_keyswitch_mfma(ctx, lane, d);
+  FHES_HIP(hipMemsetAsync(lane.ks_out, 0, (size_t)d.v_count * ctx->ks_stride * sizeof(uint64_t), lane.stream));
   // 8 ciphertexts per block; FHES_KS_TB=16 forces 16 (measured no faster: kernels.hip.h)
   const bool wide = ctx->ks_tb == dev::KS_TB_WIDE;
   const int tb = wide ? dev::KS_TB_WIDE : dev::KS_TB;
@@ -297,13 +375,13 @@ static int launch_keyswitch(fhes_ctx *ctx, const dev::NodeDesc &d) {
   const int jpt = ctx->ks_stride / 256;
 #define KS_LAUNCH(J)                                                                                        \
   if (wide)                                                                                                 \
-    hipLaunchKernelGGL((dev::keyswitch_kernel<J, dev::KS_TB_WIDE>), grid, block, 0, ctx->stream, d, ctx->arena, \
+    hipLaunchKernelGGL((dev::keyswitch_kernel<J, dev::KS_TB_WIDE>), grid, block, 0, lane.stream, d, ctx->arena, \
                        ctx->ct_stride, dm.big, ctx->ksk, ctx->ksk_bias, dm.ks_level, dm.ks_base_log,       \
-                       ctx->ks_stride, dm.n, cps, ctx->ks_out);                                             \
+                       ctx->ks_stride, dm.n, cps, lane.ks_out);                                             \
   else                                                                                                      \
-    hipLaunchKernelGGL((dev::keyswitch_kernel<J, dev::KS_TB>), grid, block, 0, ctx->stream, d, ctx->arena, \
+    hipLaunchKernelGGL((dev::keyswitch_kernel<J, dev::KS_TB>), grid, block, 0, lane.stream, d, ctx->arena, \
                        ctx->ct_stride, dm.big, ctx->ksk, ctx->ksk_bias, dm.ks_level, dm.ks_base_log,       \
-                       ctx->ks_stride, dm.n, cps, ctx->ks_out)
+                       ctx->ks_stride, dm.n, cps, lane.ks_out)
   switch (jpt) {
     case 1: KS_LAUNCH(1); break;
     case 2: KS_LAUNCH(2); break;
@@ -317,7 +395,7 @@ static int launch_keyswitch(fhes_ctx *ctx, const dev::NodeDesc &d) {
 }
 
 template <int LOGN>
-static int launch_br_v1(fhes_ctx *ctx, const dev::NodeDesc &d) {
+static int launch_br_v1(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)((ctx->dims.n + 1 + 3) & ~3) * 4;
   auto kern = dev::blind_rotate_v1_kernel<LOGN, 23>;
@@ -326,16 +404,16 @@ static int launch_br_v1(fhes_ctx *ctx, const dev::NodeDesc &d) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ctx->attr_done |= 1u << 1;
   }
-  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
-                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_f,
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena,
+                     ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_f,
                      ctx->lut_polys, ctx->twist, ctx->tw, ctx->psi);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
 
 template <int LOGN, int G, bool PIPE, bool LAT = false, int BL = 23>
-static int launch_br_mb(fhes_ctx *ctx, const dev::NodeDesc &d) {
-  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_mb<LOGN, G, PIPE, LAT, 18>(ctx, d);
+static int launch_br_mb(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_mb<LOGN, G, PIPE, LAT, 18>(ctx, lane, d);
   constexpr int N = 1 << LOGN, M = N / 2;
   const int n_deg = (ctx->dims.n / G) * ((1 << G) - 1);
   constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
@@ -347,16 +425,16 @@ static int launch_br_mb(fhes_ctx *ctx, const dev::NodeDesc &d) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ctx->attr_done |= 1u << bit;
   }
-  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
-                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena,
+                     ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
                      ctx->lut_polys, ctx->twist_inv, ctx->tw, ctx->root, ctx->psi, ctx->cdpp);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
 
 template <int LOGN, int PRIO = 0, int BL = 23>
-static int launch_br_v5(fhes_ctx *ctx, const dev::NodeDesc &d) {
-  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_v5<LOGN, PRIO, 18>(ctx, d);
+static int launch_br_v5(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_v5<LOGN, PRIO, 18>(ctx, lane, d);
   constexpr int N = 1 << LOGN, M = N / 2;
   constexpr int SLOTS = M;
   const size_t lds = (size_t)2 * N * 8 + (size_t)2 * SLOTS * 16 + (size_t)2 * (M / 2) * 16;  // N = 2048: exactly 80 KB, two per CU
@@ -366,8 +444,8 @@ static int launch_br_v5(fhes_ctx *ctx, const dev::NodeDesc &d) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ctx->attr_done |= 1u << (20 + PRIO);
   }
-  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, ctx->stream, d, ctx->arena,
-                     ctx->ct_stride, ctx->ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena,
+                     ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
                      ctx->lut_polys, ctx->twist_inv, ctx->tw, ctx->psi, ctx->cdpp);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
@@ -375,16 +453,16 @@ static int launch_br_v5(fhes_ctx *ctx, const dev::NodeDesc &d) {
 
 // variant: 0 = auto (variant 5), 1 = the simple kernel, 5 = the throughput kernel, 6 / 7 = 5 with other
 // wave-priority policies; all produce the same bits.  (Variants 2-4 of earlier rounds are gone.)
-static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
+static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   if (ctx->dims.g > 1) {
     // multi-bit parameter sets: one kernel in three builds -- latency (launches of at most one
     // workgroup per CU: everything in registers, bundle pipeline), throughput with the pipeline
     // (g = 3) and without (g = 2).  br_variant 2 forces the latency build, 3 the throughput build.
     const bool lat = ctx->br_variant == 2 || (ctx->br_variant == 0 && d.v_count <= ctx->n_cus);
     if (ctx->dims.g == 3)  // measured: the latency build gains nothing for g = 3 (3.21 vs 3.16 ms)
-      return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true>(ctx, d) : launch_br_mb<8, 3, true>(ctx, d);
-    if (ctx->dims.N == 2048) return lat ? launch_br_mb<11, 2, true, true>(ctx, d) : launch_br_mb<11, 2, false>(ctx, d);
-    return lat ? launch_br_mb<8, 2, true, true>(ctx, d) : launch_br_mb<8, 2, false>(ctx, d);
+      return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true>(ctx, lane, d) : launch_br_mb<8, 3, true>(ctx, lane, d);
+    if (ctx->dims.N == 2048) return lat ? launch_br_mb<11, 2, true, true>(ctx, lane, d) : launch_br_mb<11, 2, false>(ctx, lane, d);
+    return lat ? launch_br_mb<8, 2, true, true>(ctx, lane, d) : launch_br_mb<8, 2, false>(ctx, lane, d);
   }
   int variant = ctx->br_variant;
   if (variant == 0) variant = 5;  // every launch size
@@ -394,16 +472,16 @@ static int launch_blind_rotate(fhes_ctx *ctx, const dev::NodeDesc &d) {
     return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant 1 is instantiated for pbs_base_log 23 only");
   if (ctx->dims.N == 2048) {
     switch (variant) {
-      case 1: return launch_br_v1<11>(ctx, d);
-      case 5: return launch_br_v5<11, 0>(ctx, d);
-      case 6: return launch_br_v5<11, 1>(ctx, d);
-      case 7: return launch_br_v5<11, 2>(ctx, d);
-      case 9: return launch_br_v5<11, 4>(ctx, d);   // timing-only ablation: no LDS exchanges (WRONG results)
-      default: return launch_br_v5<11, 5>(ctx, d);  // timing-only ablation: no butterflies (WRONG results)
+      case 1: return launch_br_v1<11>(ctx, lane, d);
+      case 5: return launch_br_v5<11, 0>(ctx, lane, d);
+      case 6: return launch_br_v5<11, 1>(ctx, lane, d);
+      case 7: return launch_br_v5<11, 2>(ctx, lane, d);
+      case 9: return launch_br_v5<11, 4>(ctx, lane, d);   // timing-only ablation: no LDS exchanges (WRONG results)
+      default: return launch_br_v5<11, 5>(ctx, lane, d);  // timing-only ablation: no butterflies (WRONG results)
     }
   }
   if (variant > 7) return fail(FHES_ERR_UNSUPPORTED, "the ablation builds exist for N = 2048 only");
-  return variant == 1 ? launch_br_v1<8>(ctx, d) : variant == 5 ? launch_br_v5<8>(ctx, d) : variant == 6 ? launch_br_v5<8, 1>(ctx, d) : launch_br_v5<8, 2>(ctx, d);
+  return variant == 1 ? launch_br_v1<8>(ctx, lane, d) : variant == 5 ? launch_br_v5<8>(ctx, lane, d) : variant == 6 ? launch_br_v5<8, 1>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
 }
 
 static int take_event(fhes_ctx *ctx, hipEvent_t *e) {
@@ -432,7 +510,7 @@ int collect_timing_locked(fhes_ctx *ctx) {
   return FHES_OK;
 }
 
-int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst) {
+int launch_pbs(fhes_ctx *ctx, Lane &lane, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst, RunCounters *cnt) {
   if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
   if (count <= 0 || n_inst <= 0) return FHES_OK;
   const int64_t total = (int64_t)count * n_inst;
@@ -440,36 +518,37 @@ int launch_pbs(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t cou
   const int32_t kMaxChunk = 16384;
   for (int32_t off = 0; off < (int32_t)total; off += kMaxChunk) {
     const int32_t c = std::min<int32_t>(kMaxChunk, (int32_t)total - off);
-    int rc = ensure_ks_out(ctx, c);
+    int rc = ensure_ks_out(ctx, lane, c);
     if (rc) return rc;
     dev::NodeDesc d = make_desc(a, first, count, off, c);
     fhes_ctx::Timed t{};
-    if (ctx->timing) {
+    const bool timed = ctx->timing && lane.is_main;  // the event lists belong to the main lane's holder
+    if (timed) {
       if ((rc = take_event(ctx, &t.e0)) || (rc = take_event(ctx, &t.e1)) || (rc = take_event(ctx, &t.e2))) return rc;
-      FHES_HIP(hipEventRecord(t.e0, ctx->stream));
+      FHES_HIP(hipEventRecord(t.e0, lane.stream));
     }
-    rc = launch_keyswitch(ctx, d);
+    rc = launch_keyswitch(ctx, lane, d);
     if (rc) return rc;
-    if (ctx->timing) FHES_HIP(hipEventRecord(t.e1, ctx->stream));
-    rc = launch_blind_rotate(ctx, d);
+    if (timed) FHES_HIP(hipEventRecord(t.e1, lane.stream));
+    rc = launch_blind_rotate(ctx, lane, d);
     if (rc) return rc;
-    if (ctx->timing) {
-      FHES_HIP(hipEventRecord(t.e2, ctx->stream));
+    if (timed) {
+      FHES_HIP(hipEventRecord(t.e2, lane.stream));
       ctx->pending.push_back(t);
     }
-    ctx->stats.pbs_count += (uint64_t)c;
-    ctx->stats.pbs_launches += 1;
+    cnt->pbs += (uint64_t)c;
+    cnt->launches += 1;
   }
   return FHES_OK;
 }
 
-int launch_linear(fhes_ctx *ctx, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst) {
+int launch_linear(fhes_ctx *ctx, Lane &lane, const DevNodeArrays &a, int32_t first, int32_t count, int32_t n_inst, RunCounters *cnt) {
   if (count <= 0 || n_inst <= 0) return FHES_OK;
   dev::NodeDesc d = make_desc(a, first, count, 0, count * n_inst);
-  hipLaunchKernelGGL(dev::linear_kernel, dim3(count * n_inst), dim3(256), 0, ctx->stream, d, ctx->arena,
+  hipLaunchKernelGGL(dev::linear_kernel, dim3(count * n_inst), dim3(256), 0, lane.stream, d, ctx->arena,
                      ctx->ct_stride, ctx->dims.big);
   FHES_HIP(hipGetLastError());
-  ctx->stats.linear_count += (uint64_t)count * n_inst;
+  cnt->linear += (uint64_t)count * n_inst;
   return FHES_OK;
 }
 
@@ -549,6 +628,9 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   };
   if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  ctx->main.stream = ctx->stream;
+  ctx->main.is_main = true;
+  if ((e = hipEventCreateWithFlags(&ctx->main_done_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
 
   {
     hipDeviceProp_t prop;
@@ -616,7 +698,15 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->root); (void)hipFree(ctx->psi); (void)hipFree(ctx->odd_fix); (void)hipFree(ctx->cdpp); (void)hipFree(ctx->lut_polys);
-  (void)hipFree(ctx->ks_out); (void)hipFree(ctx->ks_dig); (void)hipFree(ctx->ks_body); (void)hipFree(ctx->ksk_pk); (void)hipFree(ctx->desc_buf);
+  (void)hipDeviceSynchronize();
+  auto drop_lane = [](Lane &l) { (void)hipFree(l.ks_out); (void)hipFree(l.ks_dig); (void)hipFree(l.ks_body); (void)hipFree(l.slot_map); };
+  drop_lane(ctx->main);
+  for (auto &l : ctx->side) {
+    drop_lane(*l);
+    if (l->stream) (void)hipStreamDestroy(l->stream);
+  }
+  if (ctx->main_done_ev) (void)hipEventDestroy(ctx->main_done_ev);
+  (void)hipFree(ctx->ksk_pk); (void)hipFree(ctx->desc_buf);
   for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
   for (auto &ev : ctx->ev_free) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -625,8 +715,9 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
 
 int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
   if (!ctx || !bsk || !ksk) return fail(FHES_ERR_INVALID, "null argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  MainLaneHold hold(ctx);
   FHES_HIP(hipSetDevice(ctx->device));
+  FHES_HIP(hipDeviceSynchronize());  // no lane may still read the keys that are replaced
   const Dims &d = ctx->dims;
   // keyswitch key, rows padded to ks_stride words
   {
@@ -745,23 +836,29 @@ int fhes_pbs_batch(fhes_ctx *ctx, int32_t count, const int32_t *term_ptr, const 
                    const int64_t *term_coef, const uint64_t *consts, const int32_t *lut_ids,
                    const int32_t *out_handles) {
   if (!ctx || !lut_ids) return fail(FHES_ERR_INVALID, "null argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  MainLaneHold hold(ctx);
   FHES_HIP(hipSetDevice(ctx->device));
   DevNodeArrays a;
   int rc = stage_desc(ctx, count, term_ptr, term_idx, term_coef, consts, lut_ids, out_handles, &a);
   if (rc) return rc;
-  return launch_pbs(ctx, a, 0, count);
+  RunCounters cnt;
+  rc = launch_pbs(ctx, ctx->main, a, 0, count, 1, &cnt);
+  merge_counters_locked(ctx, cnt);
+  return rc;
 }
 
 int fhes_linear_batch(fhes_ctx *ctx, int32_t count, const int32_t *term_ptr, const int32_t *term_idx,
                       const int64_t *term_coef, const uint64_t *consts, const int32_t *out_handles) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  MainLaneHold hold(ctx);
   FHES_HIP(hipSetDevice(ctx->device));
   DevNodeArrays a;
   int rc = stage_desc(ctx, count, term_ptr, term_idx, term_coef, consts, nullptr, out_handles, &a);
   if (rc) return rc;
-  return launch_linear(ctx, a, 0, count);
+  RunCounters cnt;
+  rc = launch_linear(ctx, ctx->main, a, 0, count, 1, &cnt);
+  merge_counters_locked(ctx, cnt);
+  return rc;
 }
 
 int fhes_sync(fhes_ctx *ctx) {
@@ -773,7 +870,7 @@ int fhes_sync(fhes_ctx *ctx) {
 
 int fhes_get_stats(fhes_ctx *ctx, fhes_stats *out) {
   if (!ctx || !out) return fail(FHES_ERR_INVALID, "null argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  MainLaneHold hold(ctx);  // the timing event lists belong to whoever holds the main lane
   FHES_HIP(hipSetDevice(ctx->device));
   int rc = collect_timing_locked(ctx);
   if (rc) return rc;
@@ -785,7 +882,7 @@ int fhes_get_stats(fhes_ctx *ctx, fhes_stats *out) {
 
 int fhes_reset_stats(fhes_ctx *ctx) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  MainLaneHold hold(ctx);
   FHES_HIP(hipSetDevice(ctx->device));
   int rc = collect_timing_locked(ctx);
   if (rc) return rc;
@@ -853,7 +950,7 @@ int fhes_debug_keyswitch_words(fhes_ctx *ctx, int32_t count, const int32_t *in_h
 
 static int debug_keyswitch_impl(fhes_ctx *ctx, int32_t count, const int32_t *in_handles, uint32_t *a_tilde, uint64_t *words) {
   if (!ctx || !in_handles || count <= 0) return fail(FHES_ERR_INVALID, "bad argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  MainLaneHold hold(ctx);
   FHES_HIP(hipSetDevice(ctx->device));
   if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
   std::vector<int32_t> tp(count + 1), ti(count), lut(count, 0), out(in_handles, in_handles + count);
@@ -864,14 +961,14 @@ static int debug_keyswitch_impl(fhes_ctx *ctx, int32_t count, const int32_t *in_
   DevNodeArrays a;
   int rc = stage_desc(ctx, count, tp.data(), ti.data(), tc.data(), cs.data(), nullptr, out.data(), &a);
   if (rc) return rc;
-  rc = ensure_ks_out(ctx, count);
+  rc = ensure_ks_out(ctx, ctx->main, count);
   if (rc) return rc;
   dev::NodeDesc d = make_desc(a, 0, count, 0, count);
-  rc = launch_keyswitch(ctx, d);
+  rc = launch_keyswitch(ctx, ctx->main, d);
   if (rc) return rc;
   std::vector<uint64_t> h((size_t)count * ctx->ks_stride);
   FHES_HIP(hipStreamSynchronize(ctx->stream));
-  FHES_HIP(hipMemcpy(h.data(), ctx->ks_out, h.size() * 8, hipMemcpyDeviceToHost));
+  FHES_HIP(hipMemcpy(h.data(), ctx->main.ks_out, h.size() * 8, hipMemcpyDeviceToHost));
   int lg = 0;
   while ((1 << lg) < 2 * ctx->dims.N) lg++;
   if (words)

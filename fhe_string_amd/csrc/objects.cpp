@@ -361,6 +361,12 @@ fhes_ct *fhes_ct_deserialize(const uint8_t *buf, int64_t len) {
   ct->degree.resize((size_t)ct->n_blocks);
   ct->noise.resize((size_t)ct->n_blocks);
   for (int32_t i = 0; i < ct->n_blocks; i++) { ct->degree[i] = *r++; ct->noise[i] = *r++; }
+  for (int32_t i = 0; i < ct->n_blocks; i++)
+    if (ct->degree[i] > 15 || ct->noise[i] > 1) {  // a block entering an operation is clean: value < 16, at most one bootstrap's noise
+      delete ct;
+      fail(FHES_ERR_INVALID, "corrupt blob: block %d carries degree / noise metadata out of range", i);
+      return nullptr;
+    }
   ct->host.resize((size_t)ct->n_blocks * ct->ct_words);
   memcpy(ct->host.data(), r, ct->host.size() * 8);
   return ct;
@@ -435,7 +441,9 @@ int fhes_string_op(fhes_server_key *sk, const char *op_in, fhes_ct *const *args,
   if (!sk || !op_in || !args || n_args < 1 || !outs || !n_outs) return fail(FHES_ERR_INVALID, "bad argument");
   const char *sig = fhes_op_signature(op_in);
   if (!sig) return fail(FHES_ERR_INVALID, "unknown operation '%s'", op_in);
-  std::lock_guard<std::mutex> lk(sk->mu);
+  // the key's mutex covers the program cache and the residency of the operands, not the run: concurrent callers
+  // (the reference's rayon workers) overlap on the device (engine.h, `Lane`)
+  std::unique_lock<std::mutex> lk(sk->mu);
   std::string op_name = op_in;
   {
     static const std::string suffix = "_logdepth";
@@ -540,6 +548,10 @@ int fhes_string_op(fhes_server_key *sk, const char *op_in, fhes_ct *const *args,
   if (n_parts < 1 || n_parts > 16) return fail(FHES_ERR_STATE, "internal: bad result layout");
   if (n_parts > max_outs) return fail(FHES_ERR_INVALID, "need room for %d results", n_parts);
   std::vector<int32_t> out((size_t)std::max<int64_t>(info[1], 1));
+  std::vector<int32_t> out_deg((size_t)std::max<int64_t>(info[1], 1), -1);
+  std::vector<double> out_noise((size_t)std::max<int64_t>(info[1], 1), -1.0);
+  fhes_program_out_meta(prog, out_deg.data(), out_noise.data());
+  lk.unlock();
   int rc = fhes_program_run(sk->ctx, prog, in.data(), out.data());
   if (rc) return rc;
   int32_t off = 0;
@@ -550,10 +562,16 @@ int fhes_string_op(fhes_server_key *sk, const char *op_in, fhes_ct *const *args,
     c->ct_words = d.ct_words();
     c->ctx = sk->ctx;
     c->handle = out[0] + off;  // program outputs are one contiguous handle range
-    // results cross the program boundary clean (Builder::finish): degree below the message modulus, one
-    // bootstrap's noise at most
-    c->degree.assign((size_t)c->n_blocks, (uint8_t)(sk->msg_mod - 1));
-    c->noise.assign((size_t)c->n_blocks, 1);
+    // results cross the program boundary clean (Builder::finish): what the builder tracked per output block
+    // (a BooleanBlock has degree 1), degree below the message modulus and one bootstrap's noise at most
+    c->degree.resize((size_t)c->n_blocks);
+    c->noise.resize((size_t)c->n_blocks);
+    for (int32_t b = 0; b < c->n_blocks; b++) {
+      const int32_t dg = out_deg[(size_t)off + b];
+      const double nz = out_noise[(size_t)off + b];
+      c->degree[b] = (uint8_t)(dg >= 0 && dg < sk->msg_mod ? dg : sk->msg_mod - 1);
+      c->noise[b] = (uint8_t)(nz >= 0 && nz <= 1.0 ? (nz > 0 ? 1 : 0) : 1);
+    }
     off += parts[k];
     outs[k] = c;
   }

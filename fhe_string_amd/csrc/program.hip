@@ -12,9 +12,7 @@ using namespace fhes;
 
 struct DeviceImage {
   int device = 0;
-  unsigned char *buf = nullptr;  // all descriptor arrays
-  int32_t *slot_map = nullptr;
-  size_t slot_map_cap = 0;
+  unsigned char *buf = nullptr;  // all descriptor arrays (immutable after creation; the slot map of a run lives in its lane)
   DevNodeArrays arrays{};
 };
 
@@ -110,7 +108,6 @@ void fhes_program_destroy(fhes_program *fp) {
   for (auto &kv : fp->images) {
     (void)hipSetDevice(kv.second.device);
     (void)hipFree(kv.second.buf);
-    (void)hipFree(kv.second.slot_map);
   }
   delete fp;
 }
@@ -182,8 +179,11 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
     return fail(FHES_ERR_INVALID, "program_run: bad argument");
   if (memcmp(&ctx->p, &fp->prog.params, sizeof(fhes_params)) != 0)
     return fail(FHES_ERR_INVALID, "program_run: program was compiled for different parameters");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  std::lock_guard<std::mutex> lk2(fp->mu);
+  // Concurrency (round 3): the context mutex is held while the run is set up (arena ranges, program image, a
+  // lane) and while it is cleaned up, NOT while its launches are queued; a caller that finds the main lane
+  // carrying another caller's work gets a side lane (own stream and scratch) and returns when its results are
+  // complete, so N threads calling into one context overlap on the device (engine.h, `Lane`).
+  std::unique_lock<std::mutex> lk(ctx->mu);
   FHES_HIP(hipSetDevice(ctx->device));
   if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
   const circ::Program &p = fp->prog;
@@ -194,6 +194,7 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
     if (in_handles[i] < 0 || in_handles[i] >= ctx->capacity) return fail(FHES_ERR_INVALID, "program_run: bad input handle");
 
   // ---- device image (once per ctx) ----
+  std::unique_lock<std::mutex> plk(fp->mu);
   auto it = fp->images.find(ctx->uid);
   if (it == fp->images.end()) {
     DeviceImage img;
@@ -234,16 +235,25 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
     img.arrays.n_slots = n_slots;
     it = fp->images.emplace(ctx->uid, img).first;
   }
-  DeviceImage &img = it->second;
-  if (img.slot_map_cap < (size_t)n_inst * n_slots) {
-    FHES_HIP(hipStreamSynchronize(ctx->stream));
-    if (img.slot_map) FHES_HIP(hipFree(img.slot_map));
-    img.slot_map = nullptr;
-    img.slot_map_cap = 0;
-    FHES_HIP(hipMalloc(&img.slot_map, 4 * (size_t)n_inst * n_slots));
-    img.slot_map_cap = (size_t)n_inst * n_slots;
+  DevNodeArrays arrays = it->second.arrays;  // by value: the slot map is this run's
+  plk.unlock();
+
+  // ---- lane ----
+  struct LaneGuard {  // destroyed AFTER the arena guard below (declared first): both run with ctx->mu held
+    fhes_ctx *ctx;
+    Lane *lane = nullptr;
+    ~LaneGuard() { release_lane_locked(ctx, lane); }
+  } lane_guard{ctx};
+  {
+    const int lrc = acquire_lane_locked(ctx, lk, &lane_guard.lane);
+    if (lrc) return lrc;
   }
-  img.arrays.slot_map = img.slot_map;
+  Lane &lane = *lane_guard.lane;
+  {
+    const int mrc = ensure_slot_map(lane, (size_t)n_inst * n_slots);
+    if (mrc) return mrc;
+  }
+  arrays.slot_map = lane.slot_map;
 
   // ---- slot maps for this run ----
   // Everything this call takes from the arena is handed back on EVERY failing exit (the outputs too:
@@ -292,26 +302,46 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
       }
     }
   }
-  FHES_HIP(hipMemcpyAsync(img.slot_map, map.data(), 4 * map.size(), hipMemcpyHostToDevice, ctx->stream));
-  FHES_HIP(hipStreamSynchronize(ctx->stream));  // `map` is a stack object
-
-  // ---- execute level by level ----
+  // ---- queue the launches: without the context mutex, with the arena pinned (arena_rw shared) ----
+  RunCounters cnt;
   int rc = FHES_OK;
-  for (int lv = 0; lv < fp->n_pbs_levels && rc == FHES_OK; lv++)
-    rc = launch_pbs(ctx, img.arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv], n_inst);
-  if (rc == FHES_OK && fp->has_linear_level) {
-    const int lv = fp->n_pbs_levels;
-    rc = launch_linear(ctx, img.arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv], n_inst);
+  {
+    std::shared_lock<std::shared_mutex> pin(ctx->arena_rw);
+    lk.unlock();
+    auto queue = [&]() -> int {
+      if (!lane.is_main) {
+        // inputs may be results of a RETURNED call whose work is still queued on the main stream: order this
+        // lane behind every completed call (main_done_ev), not behind a call that is still queueing there
+        FHES_HIP(hipStreamWaitEvent(lane.stream, ctx->main_done_ev, 0));
+      }
+      FHES_HIP(hipMemcpyAsync(lane.slot_map, map.data(), 4 * map.size(), hipMemcpyHostToDevice, lane.stream));
+      FHES_HIP(hipStreamSynchronize(lane.stream));  // `map` is a stack object
+      int r = FHES_OK;
+      for (int lv = 0; lv < fp->n_pbs_levels && r == FHES_OK; lv++)
+        r = launch_pbs(ctx, lane, arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv], n_inst, &cnt);
+      if (r == FHES_OK && fp->has_linear_level) {
+        const int lv = fp->n_pbs_levels;
+        r = launch_linear(ctx, lane, arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv], n_inst, &cnt);
+      }
+      if (r == FHES_OK) {
+        const size_t bytes = (size_t)ctx->dims.ct_words() * 8;
+        for (auto &c : copies)
+          FHES_HIP(hipMemcpyAsync(ctx->arena + (size_t)c.first * ctx->ct_stride,
+                                  ctx->arena + (size_t)map[c.second] * ctx->ct_stride, bytes,
+                                  hipMemcpyDeviceToDevice, lane.stream));
+      }
+      return r;
+    };
+    rc = queue();
   }
-  if (rc == FHES_OK) {
-    const size_t bytes = (size_t)ctx->dims.ct_words() * 8;
-    for (auto &c : copies) {
-      hipError_t e = hipMemcpyAsync(ctx->arena + (size_t)c.first * ctx->ct_stride,
-                                    ctx->arena + (size_t)map[c.second] * ctx->ct_stride, bytes,
-                                    hipMemcpyDeviceToDevice, ctx->stream);
-      if (e != hipSuccess) { rc = hip_fail(e, "output copy"); break; }
-    }
+  // a side lane's results must be complete before anybody can hold their handles: the main stream does not
+  // know about this lane (making it wait would serialise the lanes behind each other)
+  if (!lane.is_main) {
+    hipError_t e = hipStreamSynchronize(lane.stream);
+    if (e != hipSuccess && rc == FHES_OK) rc = hip_fail(e, "side lane");
   }
+  lk.lock();  // the guards below free arena ranges and hand the lane back under the mutex
+  merge_counters_locked(ctx, cnt);
   guard.keep_outputs = rc == FHES_OK;
   return rc;
 }
