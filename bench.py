@@ -12,14 +12,18 @@ per GPU) every rank runs the same workload on its own B strings: independent str
 data-path collective, so scaling is "weak" and `value` is the PBS all ranks executed per second.
 
 The JSON line also carries
-  roofline          the dominant kernel (blind rotate) against the 8 TB/s HBM peak, in the contract's form:
-                    ALGORITHMIC bytes per launch / HIP-event launch duration; `traffic` and `physical_gbs`
-                    are the PMC-measured fabric bytes (profiles/) -- the launch re-uses the key from
-                    L2 / Infinity Cache, so HBM is NOT what binds this kernel,
-  roofline_compute  what does bind it: f64 + integer VALU issue.  Instructions per wave and CMUX iteration
-                    from the SQ counters of the same command (profiles/compute_roofline.json), issue
-                    cost per instruction and the clock held under load from scripts/micro/f64_rate
-                    (profiles/*_issue_rates.jsonl), achieved rate live from HIP events,
+  roofline      the dominant kernel (blind rotate) against the bound that binds it: f64 + integer VALU issue
+                (`bound: "valu_issue"`, unit PBS/s).  Instructions per wave and CMUX iteration from the SQ
+                counters of the same command (profiles/compute_roofline.json), issue cost per instruction and
+                the clock held under load from scripts/micro/f64_rate (profiles/*_issue_rates.jsonl), `achieved`
+                live from HIP events of this run.  Side figures, labelled: `co_bound_lds_pipe` (the CU's LDS pipe
+                needs as many cycles per CMUX as the VALU; a barrier-separated phase pays their sum),
+                `hbm_algorithmic` (the contract's bytes: SURVEY 8d charges KSK + BSK to every PBS, 109 559 824 B --
+                a figure that exceeds the HBM peak as soon as a launch shares the key, as 8d itself warns) and
+                `hbm_physical` / `traffic` (PMC FETCH_SIZE x2 + WRITE_SIZE per BATCHED launch, the basis of
+                `launch_ms`): 1-2 % of the HBM peak -- HBM does not bind this kernel,
+  callers       one find from 1 and from 8 host threads on one context (execution lanes, csrc/engine.h), and the
+                same 8 finds as one batched run,
   cpu_baseline  the CPU oracle (a port of the same algorithm, NOT tfhe-rs) timed on this box's
                 host cores on the same `find` program (rank 0, N = 1 only).
 """
@@ -32,6 +36,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# concurrent callers need more than the runtime's 4 hardware queues; must be set before the first HIP call
+# (torch initialises HIP before the library's own default can apply)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 # algorithmic bytes per PBS (SURVEY.md 8d / BASELINE.md section 2), split per kernel:
 KS_BYTES = 60_866_560 + 16_392                 # keyswitch key + LWE in
@@ -250,6 +257,58 @@ def main():
         single_ok = single_ok and decode(1)[0] == pairs[0][0].find(pairs[0][1])
         free_outputs(1)
     lib.fhes_program_destroy(prog_log)
+
+    # ---- untimed: N host threads, one find each, on this one context ----
+    def concurrent_callers(n):
+        import threading
+        outs = [np.zeros(n_out, dtype=np.int32) for _ in range(n)]
+        errs = []
+        gate = threading.Barrier(n + 1)
+
+        def worker(k):
+            try:
+                gate.wait()
+                check(lib.fhes_program_run(ctx, prog, in_handles[k * n_in:(k + 1) * n_in].ctypes.data, outs[k].ctypes.data))
+            except Exception as e:
+                errs.append(repr(e))
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(n)]
+        for t in th:
+            t.start()
+        sync()
+        gate.wait()
+        t_c = time.perf_counter()
+        for t in th:
+            t.join()
+        sync()
+        d_c = (time.perf_counter() - t_c) * 1e3
+        good = not errs
+        for k in range(n):
+            res = np.zeros((n_out, W), dtype=np.uint64)
+            check(lib.fhes_arena_download(ctx, int(outs[k][0]), n_out, res.ctypes.data))
+            v = np.zeros(n_out, dtype=np.uint8)
+            check(lib.fhes_client_decrypt_blocks(ck, res.ctypes.data, n_out, v.ctypes.data))
+            got_k = sum(int(v[1 + j] & 3) << (2 * j) for j in range(4)) if v[0] & 1 else -1
+            good = good and got_k == pairs[k][0].find(pairs[k][1])
+            check(lib.fhes_arena_free(ctx, int(outs[k][0]), n_out))
+        return d_c, good
+
+    callers = None
+    if B >= 8:
+        concurrent_callers(8)                       # creates the lanes
+        c1, ok1 = concurrent_callers(1)
+        c8, ok8 = concurrent_callers(8)
+        t_b = time.perf_counter()
+        run_batch(8)
+        sync()
+        b8 = (time.perf_counter() - t_b) * 1e3
+        free_outputs(8)
+        callers = {"find_wall_ms_1_caller": round(c1, 3), "find_wall_ms_8_callers": round(c8, 3),
+                   "ratio_8_over_1": round(c8 / c1, 3), "same_8_finds_batched_ms": round(b8, 3), "result_ok": bool(ok1 and ok8),
+                   "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "note": "8 host threads, one fhes_program_run each on ONE context, started together: each gets an execution lane "
+                           "(own stream and scratch); the batched run merges the same 8 finds level by level and is the floor -- the "
+                           "four wide levels of a find (1319 of 1664 bootstraps) are throughput-bound and do not shrink by overlapping"}
     for _ in range(max(args.warmup, 0)):
         run_batch(B)
         sync()
@@ -377,7 +436,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.params == "classic" else f"pmc_traffic_{args.params}.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("blind_rotate_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                # per BATCHED launch (>= 512 workgroups): the launches `launch_ms` is measured on
+                traffic = tj.get("blind_rotate_hbm_bytes_per_batched_launch", tj.get("blind_rotate_hbm_bytes_per_launch"))
             except Exception:
                 traffic = None
         # compute roofline: VALU issue bound of the blind rotate
@@ -389,8 +450,19 @@ def main():
                 bound = cr.get("bound_pbs_per_s")
                 br_rate = units / (br_ms * 1e-3) if br_ms > 0 else 0.0
                 if bound:
+                    lp = cr.get("lds_pipe")
                     comp = {"bound": "valu_issue", "kernel": cr.get("kernel"), "unit": "PBS/s",
                             "achieved": round(br_rate, 1), "peak": round(bound, 1), "frac": round(br_rate / bound, 4),
+                            "co_bound_lds_pipe": ({"peak": round(lp["bound_pbs_per_s"], 1), "frac": round(br_rate / lp["bound_pbs_per_s"], 4),
+                                                   "lds_pipe_cycles_per_wave_cmux": round(lp["lds_pipe_cycles_per_wave_iter"], 1),
+                                                   "valu_issue_cycles_per_wave_cmux": round(cr["issue_cycles_per_pbs_iteration_per_cu"], 1),
+                                                   "serial_sum_pbs_per_s": round(cr["serial_sum_pbs_per_s"], 1),
+                                                   "frac_of_serial_sum": round(br_rate / cr["serial_sum_pbs_per_s"], 4),
+                                                   "note": "48 ds_write_b128 (13 LDS-pipe cycles each: the VGPR -> LDS transfer), 75 ds_read_b128 (4), 16 "
+                                                           "ds_read_b64 (2) per wave and CMUX + measured conflict cycles; the four waves of a PBS share the "
+                                                           "CU's one LDS pipe.  The two pipes need about the same cycles per CMUX; phases separated by "
+                                                           "barriers pay their SUM (scripts/micro/lds_valu_overlap.hip, profiles/r03_lds_valu_overlap.jsonl), "
+                                                           "two co-resident workgroups recover part of it: `frac_of_serial_sum` > 1"} if lp else None),
                             "achieved_whole_job": round(total_pbs / world_size / dt_max, 1),
                             "frac_whole_job": round(total_pbs / world_size / dt_max / bound, 4),
                             "valu_per_wave_cmux": round(cr["valu_per_wave_iter"], 1), "f64_per_wave_cmux": round(cr["f64_per_wave_iter"], 1),
@@ -438,21 +510,37 @@ def main():
             "pbs_per_s_single_find": round(pbs_per_find / (single_ms * 1e-3), 1),
             "find_wall_ms_single_logdepth": round(log_ms, 3),
             "logdepth_variant": {"pbs": log_pbs, "levels": log_levels, "note": "opt-in FheString.find(..., logdepth=True): parallel-prefix first-match scan, identical decrypted result"},
-            "roofline": {"bound": "hbm", "kernel": "blind_rotate", "achieved": round(br_achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(br_achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic,
-                         "physical_gbs": round(traffic / (br_ms * 1e-3) / 1e9, 1) if (traffic and br_ms > 0) else None,
-                         "physical_frac": round(traffic / (br_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and br_ms > 0) else None,
-                         "bytes_per_pbs": BR_BYTES, "pbs_per_launch": round(units, 2),
-                         "launch_ms": round(br_ms, 4), "launches": int(st.timed_launches),
-                         "keyswitch_launch_ms": round(ks_ms, 4),
-                         "note": "`achieved` / `frac` are the contract's ALGORITHMIC bytes (the whole Fourier key charged to every PBS); a launch "
-                                 "streams the key once per resident ciphertext pair from L2 / Infinity Cache, so the physical fabric traffic "
-                                 "(`traffic`, `physical_gbs`: PMC FETCH_SIZE x2 + WRITE_SIZE) is a few percent of the HBM peak: HBM does not bind "
-                                 "this kernel, see roofline_compute"},
-            "roofline_compute": comp,
+            "callers": callers,
+            "roofline": None,
             "sharded": None,
         }
+        # ---- roofline: the binding bound first, the contract's HBM forms as labelled side figures ----
+        whole_job = total_pbs / world_size / dt_max
+        side = {"traffic": traffic,
+                "pbs_per_launch": round(units, 2), "launch_ms": round(br_ms, 4), "launches": int(st.timed_launches),
+                "keyswitch_launch_ms": round(ks_ms, 4),
+                "hbm_algorithmic": {"bytes_per_pbs_contract_8d": PBS_BYTES, "bytes_per_pbs_blind_rotate": BR_BYTES,
+                                    "blind_rotate_gbs": round(br_achieved, 1), "blind_rotate_frac_of_hbm_peak": round(br_achieved / HBM_PEAK_GBS, 4),
+                                    "whole_job_gbs_at_8d_unit": round(whole_job * PBS_BYTES / 1e9, 1),
+                                    "whole_job_frac_of_hbm_peak_at_8d_unit": round(whole_job * PBS_BYTES / 1e9 / HBM_PEAK_GBS, 4),
+                                    "hbm_peak_gbs": HBM_PEAK_GBS,
+                                    "note": "SURVEY 8d's unit charges the whole keyswitch key and Fourier bootstrapping key to EVERY bootstrap; a launch "
+                                            "of thousands of bootstraps streams each key once per resident workgroup pair from L2 / Infinity Cache, so this "
+                                            "figure exceeds the HBM peak (frac > 1) and is not a bound -- 8d says so itself"},
+                "hbm_physical": {"bytes_per_batched_launch": traffic,
+                                 "gbs": round(traffic / (br_ms * 1e-3) / 1e9, 1) if (traffic and br_ms > 0) else None,
+                                 "frac_of_hbm_peak": round(traffic / (br_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and br_ms > 0) else None,
+                                 "ratio_to_algorithmic": round(traffic / (BR_BYTES * units), 4) if (traffic and units > 0) else None,
+                                 "note": "PMC FETCH_SIZE x2 (gfx950) + WRITE_SIZE of the blind-rotate kernel per BATCHED launch (profiles/, separate --pmc "
+                                         "passes of this command), divided by this run's HIP-event launch duration: no wasted traffic, HBM idles"}}
+        if comp and "error" not in comp:
+            line["roofline"] = {**comp, **side}
+        else:
+            # no compute profile for this parameter set: the contract's HBM form, labelled as what it is
+            line["roofline"] = {"bound": "hbm", "kernel": "blind_rotate", "achieved": round(br_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(br_achieved / HBM_PEAK_GBS, 4), **side,
+                                "note": "ALGORITHMIC bytes (whole Fourier key charged to every PBS) -- not a bound, see hbm_algorithmic.note"
+                                        + (f"; compute profile: {comp['error']}" if comp else "; no compute profile tracked for this parameter set")}
         if world_size == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline("default" if args.params == "classic" else args.params, pairs)
     else:
@@ -468,7 +556,11 @@ def main():
             if rank == 0:
                 line["sharded"] = {"error": "timed out: the position-sharded section did not return"}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            # a collective that never returns is a failure of the run: every rank leaves with a distinct non-zero
+            # code (the headline numbers are on stdout already), so the driver records the hang
+            sys.stderr.write(f"[bench rank {rank}] sharded section timed out: exit 3\n")
+            sys.stderr.flush()
+            os._exit(3)
 
     threading.Thread(target=watchdog, daemon=True).start()
     sharded = measure_sharded()

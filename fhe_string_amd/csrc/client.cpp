@@ -38,11 +38,14 @@ bool params_valid(const fhes_params &p, std::string *why) {
     if (why) *why = m;
     return false;
   };
-  if (p.poly_size < 16 || (p.poly_size & (p.poly_size - 1))) return bad("poly_size must be a power of two >= 16");
-  if (p.glwe_dim < 1 || p.lwe_dim < 1) return bad("dimensions must be positive");
-  if (p.pbs_level < 1 || p.pbs_base_log < 1 || p.pbs_level * p.pbs_base_log > 63) return bad("bad PBS decomposition");
-  if (p.ks_level < 1 || p.ks_base_log < 1 || p.ks_level * p.ks_base_log > 63) return bad("bad KS decomposition");
-  if (p.message_bits < 1 || p.carry_bits < 0 || p.message_bits + p.carry_bits > 6) return bad("bad message/carry bits");
+  // upper bounds too: a parameter block may come out of a caller-supplied blob (fhes_*_deserialize), and every
+  // size below is derived from it in 32-bit arithmetic (tests/asan: a corrupt glwe_dim overflowed k * N)
+  if (p.poly_size < 16 || p.poly_size > (1 << 16) || (p.poly_size & (p.poly_size - 1))) return bad("poly_size must be a power of two in [16, 65536]");
+  if (p.glwe_dim < 1 || p.glwe_dim > 8 || p.lwe_dim < 1 || p.lwe_dim > (1 << 16)) return bad("dimensions out of range (glwe_dim 1..8, lwe_dim 1..65536)");
+  if (!(p.lwe_noise_std >= 0.0) || !(p.lwe_noise_std < 1.0) || !(p.glwe_noise_std >= 0.0) || !(p.glwe_noise_std < 1.0)) return bad("noise standard deviations must lie in [0, 1)");
+  if (p.pbs_level < 1 || p.pbs_level > 63 || p.pbs_base_log < 1 || p.pbs_base_log > 63 || p.pbs_level * p.pbs_base_log > 63) return bad("bad PBS decomposition");
+  if (p.ks_level < 1 || p.ks_level > 63 || p.ks_base_log < 1 || p.ks_base_log > 63 || p.ks_level * p.ks_base_log > 63) return bad("bad KS decomposition");
+  if (p.message_bits < 1 || p.message_bits > 6 || p.carry_bits < 0 || p.carry_bits > 6 || p.message_bits + p.carry_bits > 6) return bad("bad message/carry bits");
   if ((1 << (p.message_bits + p.carry_bits)) > p.poly_size) return bad("plaintext space larger than polynomial");
   if (p.grouping_factor < 0 || p.grouping_factor > 3) return bad("grouping_factor must be 0/1 (classic), 2 or 3");
   if (p.grouping_factor > 1 && p.lwe_dim % p.grouping_factor) return bad("lwe_dim must be a multiple of grouping_factor");
@@ -277,6 +280,7 @@ fhes_client_key *fhes_client_key_generate(const fhes_params *p, uint64_t l, uint
     fail(FHES_ERR_INVALID, "invalid parameters: %s", why.c_str());
     return nullptr;
   }
+  if (l < 1 || l > 0xFFFFFFFFull) { fail(FHES_ERR_INVALID, "maximum string length l must lie in [1, 2^32)"); return nullptr; }
   auto *ck = new fhes_client_key;
   ck->deterministic = seed != 0;
   Key256 sk_key{};
@@ -434,8 +438,17 @@ fhes_client_key *fhes_client_key_deserialize(const uint8_t *buf, int64_t len) {
   std::string why;
   if (!params_valid(ck->p, &why)) { delete ck; fail(FHES_ERR_INVALID, "invalid parameters: %s", why.c_str()); return nullptr; }
   get(&ck->l, 8); get(&ck->nb_char, 4); get(&ck->nb_usize, 4);
+  {  // the block counts are functions of (message modulus, l) (lib.rs:51-62): a blob that says otherwise is corrupt
+    const uint64_t msg_mod = 1ull << ck->p.message_bits;
+    if (ck->l < 1 || ck->l > 0xFFFFFFFFull || ck->nb_char != ceil_ilog(128, msg_mod) || ck->nb_usize != ceil_ilog(ck->l + 1, msg_mod)) {
+      delete ck;
+      fail(FHES_ERR_INVALID, "corrupt blob: block counts do not match the parameters");
+      return nullptr;
+    }
+  }
   uint32_t mode;
   get(&mode, 4);
+  if (mode > 1) { delete ck; fail(FHES_ERR_INVALID, "corrupt blob: unknown randomness mode"); return nullptr; }
   ck->deterministic = mode == 1;
   if (ck->deterministic) { get(&ck->seed, 8); get(&ck->enc_counter, 8); }
   else {

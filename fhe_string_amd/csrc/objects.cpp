@@ -46,6 +46,8 @@ static int ensure_device(fhes_server_key *sk, fhes_ct *c) {
     return FHES_OK;
   }
   if (c->host.empty()) return fail(FHES_ERR_INVALID, "ciphertext has no data");
+  if (c->ct_words != fhes_ct_words(&sk->p) || (int64_t)c->host.size() != (int64_t)c->n_blocks * c->ct_words)
+    return fail(FHES_ERR_INVALID, "ciphertext of %lld words per block under a server key of %lld", (long long)c->ct_words, (long long)fhes_ct_words(&sk->p));
   const int32_t h = fhes_arena_alloc(sk->ctx, c->n_blocks);
   if (h < 0) return h;
   int rc = fhes_arena_upload(sk->ctx, h, c->n_blocks, c->host.data());
@@ -259,8 +261,14 @@ fhes_ct *fhes_ct_concat(fhes_server_key *sk, fhes_ct *const *parts, int32_t n_pa
 }
 
 static int decrypt_values(const fhes_client_key *ck, fhes_ct *c, std::vector<uint8_t> *vals) {
+  // a ciphertext object may come out of a blob (fhes_ct_deserialize): its width must be this key's
+  fhes_params kp;
+  fhes_client_key_params(ck, &kp);
+  if (c->ct_words != fhes_ct_words(&kp))
+    return fail(FHES_ERR_INVALID, "ciphertext of %lld words per block under a key of %lld", (long long)c->ct_words, (long long)fhes_ct_words(&kp));
   int rc = ensure_host(c);
   if (rc) return rc;
+  if ((int64_t)c->host.size() != (int64_t)c->n_blocks * c->ct_words) return fail(FHES_ERR_INVALID, "ciphertext object is inconsistent");
   vals->resize(c->n_blocks);
   return fhes_client_decrypt_blocks(ck, c->host.data(), c->n_blocks, vals->data());
 }
@@ -351,7 +359,7 @@ fhes_ct *fhes_ct_deserialize(const uint8_t *buf, int64_t len) {
   auto *ct = new fhes_ct;
   memcpy(&ct->n_blocks, buf + 12, 4);
   memcpy(&ct->ct_words, buf + 16, 8);
-  if (ct->n_blocks < 0 || ct->ct_words < 2 || ct->ct_words > (1 << 20) ||
+  if (ct->n_blocks < 1 || ct->n_blocks > (1 << 24) || ct->ct_words < 2 || ct->ct_words > (1 << 20) ||
       len < 24 + 2 * (int64_t)ct->n_blocks + (int64_t)ct->n_blocks * ct->ct_words * 8) {
     delete ct;
     fail(FHES_ERR_INVALID, "truncated or corrupt blob");
@@ -411,7 +419,9 @@ fhes_server_key *fhes_server_key_deserialize(const uint8_t *buf, int64_t len, in
   int64_t bw, kw;
   get(&sk->p, sizeof sk->p); get(&l, 8); get(&sk->nb_char, 4); get(&sk->nb_usize, 4); get(&bw, 8); get(&kw, 8);
   std::string why;
-  if (!params_valid(sk->p, &why) || bw != fhes_bsk_words(&sk->p) || kw != fhes_ksk_words(&sk->p) || len < head + (bw + kw) * 8) {
+  auto ilog = [](uint64_t a, uint64_t b) { int n = 0; for (uint64_t v = 1; v < a; v *= b) n++; return n; };  // lib.rs:51-57
+  if (!params_valid(sk->p, &why) || bw != fhes_bsk_words(&sk->p) || kw != fhes_ksk_words(&sk->p) || len < head + (bw + kw) * 8 ||
+      l < 1 || l > 0xFFFFFFFFull || sk->nb_char != ilog(128, 1ull << sk->p.message_bits) || sk->nb_usize != ilog(l + 1, 1ull << sk->p.message_bits)) {
     delete sk;
     fail(FHES_ERR_INVALID, "corrupt or truncated server-key blob %s", why.c_str());
     return nullptr;

@@ -112,7 +112,19 @@ int fhes_client_encrypt_blocks(fhes_client_key *ck, const uint8_t *values, int64
 int fhes_client_decrypt_blocks(const fhes_client_key *ck, const uint64_t *cts, int64_t count,
                                uint8_t *values);
 
-/* ============================ Level 0: device engine ==================================== */
+/* ============================ Level 0: device engine ====================================
+ * Threading (the reference calls its key from nested rayon workers and requires `ServerKey: Sync`,
+ * search.rs:34-40, compare.rs:27-42, mod.rs:292): every entry point may be called from any thread.
+ *   - fhes_program_run / fhes_program_run_batch / fhes_string_op from SEVERAL threads on one context
+ *     overlap on the device: a call that finds the context's own stream carrying another caller's work
+ *     gets an execution lane of its own (stream, keyswitch scratch, slot map) and returns when its results
+ *     are complete.  A single caller keeps the asynchronous behaviour: its runs queue on the context's
+ *     stream and return at once; fhes_sync / fhes_arena_download wait.
+ *   - the Level-0 batch calls (fhes_pbs_batch, fhes_linear_batch), key upload and statistics take the
+ *     context's own stream exclusively and serialise with each other.
+ *   - HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: at most about four lanes make
+ *     progress at once).  The library sets the variable to 16 when it is loaded unless the application has
+ *     set it; an application that initialises HIP before loading the library sets it itself. */
 typedef struct fhes_ctx fhes_ctx;
 
 typedef struct fhes_stats {

@@ -42,11 +42,18 @@ for r in csv.DictReader(open(stats_csv)):
                               "avg_ms": float(r["AverageNs"]) / 1e6, "pct": float(r["Percentage"])}
 
 
-def pmc(sub, counter):
+BATCHED_WGS = 512     # bench.py's timed launches are >= 512 workgroups; the untimed single-find launches are 2-7
+
+
+def pmc(sub, counter, min_wgs=0):
+    """(launches, sum) per kernel; min_wgs > 0 keeps the dispatches of the batched steps only -- the basis of
+    bench.py's `launch_ms` (HIP events around the batched launches)"""
     f = newest(os.path.join(src, sub, "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
+            continue
+        if min_wgs and float(r.get("Grid_Size", 0)) / max(float(r.get("Workgroup_Size", 1)), 1) < min_wgs:
             continue
         k = short(r["Kernel_Name"])
         agg[k][0] += 1
@@ -55,6 +62,7 @@ def pmc(sub, counter):
 
 
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+fetch_b, write_b = pmc("fetch", "FETCH_SIZE", BATCHED_WGS), pmc("write", "WRITE_SIZE", BATCHED_WGS)
 for k in kern:
     if k in fetch:
         n, v = fetch[k]
@@ -63,6 +71,13 @@ for k in kern:
     if k in write:
         n, v = write[k]
         kern[k]["write_bytes_per_launch"] = v / n * 1024
+    if k in fetch_b:
+        n, v = fetch_b[k]
+        kern[k]["batched_launches"] = n
+        kern[k]["fetch_bytes_per_batched_launch"] = v / n * 1024 * 2
+    if k in write_b:
+        n, v = write_b[k]
+        kern[k]["write_bytes_per_batched_launch"] = v / n * 1024
 
 
 def pmc_all(sub):
@@ -132,8 +147,12 @@ br = sorted((k for k in kern if "blind_rotate" in k), key=lambda k: -kern[k]["to
 if br:
     k = kern[br[0]]
     traffic = {"source": f"profiles/{tag}_summary.json", "kernel": br[0],
-               "blind_rotate_hbm_bytes_per_launch": round(k.get("fetch_bytes_per_launch", 0) + k.get("write_bytes_per_launch", 0)),
-               "note": "FETCH_SIZE x2 (gfx950) + WRITE_SIZE, KiB -> bytes, averaged over the launches of one bench run"}
+               "blind_rotate_hbm_bytes_per_batched_launch": round(k.get("fetch_bytes_per_batched_launch", 0) + k.get("write_bytes_per_batched_launch", 0)),
+               "batched_launches": k.get("batched_launches"),
+               "blind_rotate_hbm_bytes_per_launch_all": round(k.get("fetch_bytes_per_launch", 0) + k.get("write_bytes_per_launch", 0)),
+               "note": "FETCH_SIZE x2 (gfx950) + WRITE_SIZE, KiB -> bytes; `per_batched_launch` averages the dispatches of >= 512 workgroups "
+                       "(the batched steps bench.py times: same basis as its launch_ms), `per_launch_all` every dispatch of the run "
+                       "(incl. the untimed single-find launches of 2-7 workgroups)"}
     params = extra.split()[-1] if "--params" in extra else "classic"
     name = "pmc_traffic.json" if params == "classic" else f"pmc_traffic_{params}.json"
     json.dump(traffic, open(os.path.join(dst, name), "w"), indent=1)
@@ -145,7 +164,8 @@ if os.path.exists(rates_src) and os.path.getsize(rates_src):
     rates = [json.loads(l) for l in open(rates_src) if l.strip().startswith("{")]
 if br and br[0] in sq:
     c = sq[br[0]]
-    n_iter = 742 if "multibit" not in extra else None     # CMUX iterations per PBS (classic 2_2 set)
+    # CMUX iterations (classic 2_2 set) / group steps (multi-bit: n / g = 764 / 2, 765 / 3) per PBS
+    n_iter = 742 if "multibit" not in extra else (382 if extra.split()[-1] == "multibit2" else 255)
     wgs = c.get("sqa_workgroups", 0)                      # one workgroup = one PBS, 4 waves
     wave_iters = wgs * 4 * (n_iter or 1)
     f64 = sum(c.get(x, 0) for x in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
@@ -183,6 +203,23 @@ if br and br[0] in sq:
         cyc = comp["f64_per_wave_iter"] * c_f64 + other * c_other
         comp["issue_cycles_per_pbs_iteration_per_cu"] = cyc
         comp["bound_pbs_per_s"] = 256 * clock / (n_iter * cyc)
+    # second pipe (round 3): the LDS.  Static instruction mix of the kernel's loop body (llvm-objdump of the
+    # shipped code object) priced with the LDS-pipe cycles per wave-instruction of
+    # MI355X_MICROARCH.md (ds_write_b128 13 -- the VGPR -> LDS transfer, not the array --, ds_read_b128 4,
+    # ds_read_b64 2), plus the measured bank-conflict cycles; 4 waves per PBS share the CU's one LDS pipe.
+    # scripts/micro/lds_valu_overlap.hip confirms the prices on this chip (8 stores + 8 loads by 8 waves:
+    # 1021 cycles against 1088 predicted) and that a barrier-separated phase pays VALU + LDS, not max.
+    if "multibit" not in extra and clock and wave_iters:
+        mix = {"ds_write_b128": 48, "ds_read_b128": 75, "ds_read_b64": 16}
+        conflicts = c.get("SQ_LDS_BANK_CONFLICT", 0) / wave_iters
+        lds_cyc = mix["ds_write_b128"] * 13 + mix["ds_read_b128"] * 4 + mix["ds_read_b64"] * 2 + conflicts
+        comp["lds_pipe"] = {"instr_per_wave_iter_static": mix, "instr_per_wave_iter_measured": comp["lds_instr_per_wave_iter"],
+                            "bank_conflict_cycles_per_wave_iter": conflicts,
+                            "lds_pipe_cycles_per_wave_iter": lds_cyc,
+                            "lds_pipe_cycles_per_pbs_iteration_per_cu": 4 * lds_cyc,
+                            "bound_pbs_per_s": 256 * clock / (n_iter * 4 * lds_cyc)}
+        if comp.get("issue_cycles_per_pbs_iteration_per_cu"):
+            comp["serial_sum_pbs_per_s"] = 256 * clock / (n_iter * (comp["issue_cycles_per_pbs_iteration_per_cu"] + 4 * lds_cyc))
     json.dump(comp, open(os.path.join(dst, "compute_roofline.json" if "multibit" not in extra else f"compute_roofline_{extra.split()[-1]}.json"), "w"), indent=1)
     out["compute_roofline"] = comp
     json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
