@@ -427,3 +427,47 @@ def test_find_pred_scans(libs):
                 hits = [i for i, x in enumerate(v) if x]
                 want = (hits[-1] if op.startswith("r") else hits[0]) if hits else None
                 assert run_ext(op, [{"l": v}])[0] == want, (op, v)
+
+
+def _staged_split_plain(op, a, a_pad, p, p_pad, cut, suffix=""):
+    """the position-sharded form of split / rsplit (csrc/comm.hip: fhes_sharded_op) run stage by stage on the
+    plaintext model: find_all over two position ranges, head, is_some over two index ranges, tail"""
+    import numpy as np
+    bu = num_blocks_usize(255)
+    A, P = string_blocks(a, a_pad), string_blocks(p, p_pad)
+    sa, sp = len(A) // 4, len(P) // 4
+    n_pos, n = sa - 1, sa + 1
+    ap = np.concatenate([A, P]).astype("int64")
+    c1 = min(cut, n_pos)
+    found = np.concatenate([prog("find_all_range", [sa, sp, lo, hi], bu).run_plain(ap) if hi > lo else np.zeros(0, dtype="int64")
+                            for lo, hi in ((0, c1), (c1, n_pos))])
+    head = prog(op + "_head" + suffix, [sa, sp], bu).run_plain(np.concatenate([ap, found]))
+    matches, p_len, s_len, p_empty = head[:n], head[n:n + bu], head[n + bu:n + 2 * bu], head[n + 2 * bu:]
+    c2 = min(cut + 1, n)
+    is_some = np.concatenate([prog("split_is_some_range" + suffix, [n, lo, hi], bu).run_plain(np.concatenate([matches, p_len, s_len]))
+                              for lo, hi in ((0, c2), (c2, n))])
+    return prog(op + "_tail" + suffix, [n], bu).run_plain(np.concatenate([matches, is_some, p_len, s_len, p_empty])), bu
+
+
+def test_staged_split_equals_the_monolithic_program(libs):
+    """every output block of the staged (shardable) split / rsplit equals the monolithic program's, faithful and
+    log-depth forms, on the reference's split cases and on random inputs; decoded: the std::str answer"""
+    rnd = random.Random(5)
+    cases = [("xxx", None, "x", None), ("axbxc", None, "x", None), ("xxx", None, "xx", None), ("abc", None, "", None),
+             ("axbxc", 8, "x", 3), ("xxx", 8, "xx", None), ("", None, "x", None), ("a", 3, "", 2)]
+    for _ in range(10):
+        a = "".join(rnd.choice("ab,") for _ in range(rnd.randint(0, 9)))
+        p = "".join(rnd.choice("ab,") for _ in range(rnd.randint(0, 2)))
+        cases.append((a, rnd.choice([None, len(a) + 2]), p, rnd.choice([None, len(p) + 1])))
+    for a, a_pad, p, p_pad in cases:
+        for op in ("split", "rsplit"):
+            for suffix in ("", "_logdepth"):
+                mono, _ = run_plain(op + suffix, a, a_pad, p, p_pad)
+                import numpy as np
+                bu = num_blocks_usize(255)
+                mp = prog(op + suffix, [len(string_blocks(a, a_pad)) // 4, len(string_blocks(p, p_pad)) // 4], bu)
+                mono_raw = mp.run_plain(np.concatenate([string_blocks(a, a_pad), string_blocks(p, p_pad)]).astype("int64"))
+                for cut in (0, 2, 100):
+                    raw, _ = _staged_split_plain(op, a, a_pad, p, p_pad, cut, suffix)
+                    assert list(raw % 4) == list(mono_raw % 4), (a, a_pad, p, p_pad, op, suffix, cut)
+                    assert decode_result(op, raw, bu, a) == mono, (a, p, op, suffix, cut)
