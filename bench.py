@@ -389,31 +389,55 @@ def main():
                     barrier()
                     check(lib.fhes_reset_stats(ctx))
                     t_s = time.perf_counter()
-                    hs = comm.sharded_search(op, ha, len(a_blk) // 4, hb, len(p_blk) // 4, bu_case)
+                    hs = comm.sharded_op(op, ha, len(a_blk) // 4, hb, len(p_blk) // 4, bu_case)
                     sync()
                     d_s = time.perf_counter() - t_s
                     st_s = Stats()
                     check(lib.fhes_get_stats(ctx, C.byref(st_s)))
-                    res = np.zeros((len(hs), W), dtype=np.uint64)
-                    check(lib.fhes_arena_download(ctx, hs[0], len(hs), res.ctypes.data))
-                    v = np.zeros(len(hs), dtype=np.uint8)
-                    check(lib.fhes_client_decrypt_blocks(ck, res.ctypes.data, len(hs), v.ctypes.data))
-                    check(lib.fhes_arena_free(ctx, hs[0], len(hs)))
-                    val = bool(v[0] & 1) if op == "contains" else (sum(int(v[1 + k] & 3) << (2 * k) for k in range(bu_case)) if v[0] & 1 else -1)
+                    is_split = op.startswith("split")
+                    n_sl = len(a_blk) // 4 + 1
+                    n_rows = n_sl * (1 + 2 * bu_case) if is_split else len(hs)
+                    res = np.zeros((n_rows, W), dtype=np.uint64)
+                    check(lib.fhes_arena_download(ctx, hs[0], n_rows, res.ctypes.data))
+                    v = np.zeros(n_rows, dtype=np.uint8)
+                    check(lib.fhes_client_decrypt_blocks(ck, res.ctypes.data, n_rows, v.ctypes.data))
+                    check(lib.fhes_arena_free(ctx, hs[0], n_rows))
+                    if is_split:     # FheStringSliceVector::decrypt (split.rs:208-226)
+                        rad = lambda d: sum(int(d[k] & 3) << (2 * k) for k in range(bu_case))
+                        val = []
+                        for i in range(n_sl):
+                            if v[i] & 1:
+                                st_i = rad(v[n_sl + i * bu_case:n_sl + (i + 1) * bu_case])
+                                en_i = rad(v[n_sl * (1 + bu_case) + i * bu_case:n_sl * (1 + bu_case) + (i + 1) * bu_case])
+                                val.append(s_text[st_i:en_i] if st_i <= en_i <= len(s_text) else "")
+                    else:
+                        val = bool(v[0] & 1) if op == "contains" else (sum(int(v[1 + k] & 3) << (2 * k) for k in range(bu_case)) if v[0] & 1 else -1)
                     if best is None or d_s < best[0]:
                         best = (d_s, int(st_s.pbs_count))
                 check(lib.fhes_arena_free(ctx, ha, len(a_blk)))
                 check(lib.fhes_arena_free(ctx, hb, len(p_blk)))
-                want = (s_pat in s_text) if op == "contains" else s_text.find(s_pat)
+                want = s_text.split(s_pat) if op.startswith("split") else ((s_pat in s_text) if op == "contains" else s_text.find(s_pat))
                 return {"op": name, "wall_ms": round(best[0] * 1e3, 3), "pbs_this_rank": best[1], "result_ok": bool(val == want)}
 
             rng4 = np.random.default_rng(0xF4E50004)
             s4 = "".join(chr(c) for c in rng4.integers(0x20, 0x7F, size=1000))
+            rng3 = np.random.default_rng(0xF4E50003)
+            c3 = [chr(c) for c in rng3.integers(0x61, 0x7B, size=256)]
+            for i3 in range(7, 256, 8):
+                c3[i3] = ","
+            s3 = "".join(c3)
             cases = [sharded_case("config 2: find, 64-char input / 4-char pattern", "find", text, None, pat, 4, 3),
-                     sharded_case("config 4: contains, 1000 chars padded to 1024 / 8-char pattern", "contains", s4, 1024, s4[700:708], 6, 2)]
+                     sharded_case("config 4: contains, 1000 chars padded to 1024 / 8-char pattern", "contains", s4, 1024, s4[700:708], 6, 2),
+                     sharded_case("config 3: split, 256-char input / 1-char separator (log-depth scans; the element_at_bool grid sharded by output index)",
+                                  "split_logdepth", s3, None, ",", 5, 2)]
+            if os.environ.get("FHES_BENCH_SHARDED_FAITHFUL_SPLIT") == "1":   # ~8 s per repetition: thousands of dependent levels
+                cases.append(sharded_case("config 3: split, faithful serial scans", "split", s3, None, ",", 5, 1))
             sharded = {"world": world_size, "transport": "host callbacks over gloo (rehearsal)" if (dist and rehearsal) else "RCCL (ncclAllGather on arena rows)",
                        "key_broadcast_ms": round(keys_ms, 2), "cases": cases,
-                       "note": "positions of find_all sharded over the ranks through the C ABI (fhes_sharded_search); wall-clock of one operation on one string, max over repetitions' best on rank 0; the serial first-match scan of `find` is replicated, not sharded"}
+                       "note": "one operation on ONE string through the C ABI (fhes_sharded_op): find_all positions sharded over the ranks (all-gather of the "
+                               "per-position booleans; contains: partial any + all-reduce), split: the element_at_bool grid sharded by output index; wall-clock "
+                               "on rank 0, best of the repetitions; the serial scans are replicated, not sharded.  Unmeasured on hardware for world > 1 until "
+                               "the driver has an 8-GPU node"}
             comm.close()
         except Exception as e:     # the headline measurement stands on its own
             sharded = {"error": repr(e)}

@@ -122,11 +122,23 @@ SIGNATURES = {
     "fhes_comm_broadcast_cts": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
     "fhes_comm_broadcast_keys": (C.c_int, [_P, C.c_int32]),
     "fhes_sharded_search": (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, C.c_int32, _i32p]),
+    "fhes_sharded_op": (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, C.c_int32, _i32p]),
+    "fhes_comm_create_host_exec": (_P, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "fhes_server_key_set_comm": (C.c_int, [_P, _P]),
 }
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+# fhes_executor (include/fhe_string_amd.h): the planner of fhes_sharded_op over host-memory rows
+EXEC_ALLOC_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32)
+EXEC_RELEASE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32)
+EXEC_ROWS_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32)
+EXEC_RUN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32))
+
+
+class Executor(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("row_words", C.c_int64), ("alloc", EXEC_ALLOC_FN), ("release", EXEC_RELEASE_FN),
+                ("rows", EXEC_ROWS_FN), ("run", EXEC_RUN_FN)]
 
 _lib = None
 

@@ -127,7 +127,7 @@ Blk Builder::pbs(const Blk &in, const std::function<uint64_t(uint64_t)> &f, bool
   const int sp = space();
   Table t{};
   uint32_t full_max = 0;
-  for (int x = 0; x < 16; x++) {
+  for (int x = 0; x < kMaxSpace; x++) {
     const uint64_t v = x < sp ? f((uint64_t)x) : 0;
     if (v >= (uint64_t)sp) throw std::logic_error("pbs: lookup value out of range");
     t[x] = (uint8_t)v;

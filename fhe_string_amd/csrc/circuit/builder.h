@@ -33,7 +33,10 @@ struct Blk {
 };
 
 using Radix = std::vector<Blk>;  // little-endian digits, base 2^message_bits
-using Table = std::array<uint8_t, 16>;
+// a lookup table: one entry per plaintext value below the padding bit, 2^(message_bits + carry_bits) <= 64 of them
+// (params_valid caps message + carry at 6 bits); entries beyond the parameter set's space stay 0
+constexpr int kMaxSpace = 64;
+using Table = std::array<uint8_t, kMaxSpace>;
 
 struct Node {
   int32_t lut;              // index into Program::luts, -1 = linear (materialise only)

@@ -218,6 +218,34 @@ static uint64_t sign_combine(uint64_t hi, uint64_t lo) { return hi != 1 ? hi : l
 
 Blk Ops::reduce_signs(std::vector<Blk> signs, Cmp op) {
   if (signs.empty()) return b.trivial(sign_final(op, 1));
+  if (b.space() < 16) {
+    // Two signs (values 0..2) do not fit one lookup input below 4 bits of plaintext space (the 1_1 / 1_2 shaped
+    // sets): carry (is_lt, is_eq) as two booleans per digit pair instead and fold them with boolean lookups,
+    // most significant pair dominating:  lt = lt_hi | (eq_hi & lt_lo),  eq = eq_hi & eq_lo.
+    struct LE { Blk lt, eq; };
+    std::vector<LE> v;
+    for (const Blk &sg : signs) {
+      if (sg.trivial()) { v.push_back({b.trivial(sg.cst == 0), b.trivial(sg.cst == 1)}); continue; }
+      Blk lt = b.pbs(sg, [](uint64_t x) { return x == 0 ? 1 : 0; }), eq = b.pbs(sg, [](uint64_t x) { return x == 1 ? 1 : 0; });
+      lt.deg = eq.deg = 1;
+      v.push_back({lt, eq});
+    }
+    while (v.size() > 1) {
+      std::vector<LE> next;
+      for (size_t i = 0; i < v.size(); i += 2) {
+        if (i + 1 == v.size()) { next.push_back(v[i]); continue; }
+        const LE &lo = v[i], &hi = v[i + 1];
+        next.push_back({bitor_(hi.lt, bitand_(hi.eq, lo.lt)), bitand_(hi.eq, lo.eq)});
+      }
+      v = next;
+    }
+    switch (op) {
+      case Cmp::LT: return v[0].lt;
+      case Cmp::LE: return bitor_(v[0].lt, v[0].eq);
+      case Cmp::GT: return bitnot_(bitor_(v[0].lt, v[0].eq));
+      default: return bitnot_(v[0].lt);
+    }
+  }
   if (signs.size() == 1) return b.pbs(signs[0], [op](uint64_t s) { return sign_final(op, std::min<uint64_t>(s, 2)); });
   while (true) {
     const bool last = signs.size() == 2;

@@ -244,10 +244,12 @@ struct S {
   }
 
   // search.rs:68-110
-  std::vector<Blk> find_all_non_overlapping(const Str &a, const Str &s) {
-    std::vector<Blk> matches = find_all(a, s);
+  std::vector<Blk> find_all_non_overlapping(const Str &a, const Str &s) { return suppress_overlaps(find_all(a, s), s); }
+  // the loop of search.rs:91-109 over given per-position matches (the position-sharded split hands in the
+  // gathered find_all)
+  std::vector<Blk> suppress_overlaps(const std::vector<Blk> &matches, const Str &s) {
     Radix s_len = len(s);
-    if (fast && max_len(s) >= 1 && max_len(s) - 1 <= 7) return suppress_overlaps_logdepth(matches, s_len, max_len(s) - 1);
+    if (fast && o.b.space() >= 16 && max_len(s) >= 1 && max_len(s) - 1 <= 7) return suppress_overlaps_logdepth(matches, s_len, max_len(s) - 1);
     if (fast && max_len(s) == 0) return matches;  // the empty pattern suppresses nothing (j < 0 never holds)
     Blk in_match = o.trivial_bool(false);
     Radix j = usize(0);
@@ -377,8 +379,8 @@ struct S {
   }
 
   // search.rs:114-152 (iterates `matches` front to back, exactly as the code does)
-  std::vector<Blk> rfind_all_non_overlapping(const Str &a, const Str &s) {
-    std::vector<Blk> matches = find_all(a, s);
+  std::vector<Blk> rfind_all_non_overlapping(const Str &a, const Str &s) { return rsuppress_overlaps(find_all(a, s), s); }
+  std::vector<Blk> rsuppress_overlaps(const std::vector<Blk> &matches, const Str &s) {
     Radix s_len = len(s);
     if (fast) {
       // In the loop `c = j_lt & mi` is always false (mi is forced to false whenever j_lt holds), so j
@@ -623,7 +625,8 @@ struct S {
 
   bool replace_fast_applies(const Str &a, const Str &p, const Str &sub, const Radix *n_max, size_t l) const {
     const size_t T = usize_modulus();
-    return fast && !n_max && max_len(p) <= 7 && max_len(sub) <= 4 && T != 0 && l + a.size() <= T && l >= 1;
+    // (the transducer's tables pack a state and a symbol count into one lookup input: 4 bits of plaintext space)
+    return fast && o.b.space() >= 16 && !n_max && max_len(p) <= 7 && max_len(sub) <= 4 && T != 0 && l + a.size() <= T && l >= 1;
   }
 
   Str replace_logdepth(const Str &a, const Str &p, const Str &sub, size_t l) {
@@ -1000,14 +1003,43 @@ struct S {
     return v;
   }
 
-  // split.rs:238-333
+  // split.rs:238-333, in the three stages the position-sharded form (csrc/comm.hip) cuts it into:
+  //   split_head     matches (split.rs:259-266), len(p), len(self)               [found[] may be handed in]
+  //   split_is_some  is_some_i = element_at_bool(matches, i - len(p)) & (i < len(self) + 2), split.rs:283-287:
+  //                  one O(n) gather per output index i, independent across i -> sharded by i
+  //   split_tail     the carried next_match chain and the slice bounds, split.rs:289-319
+  struct SplitHead { std::vector<Blk> matches; Radix p_len, self_len; Blk pattern_empty; };
+  SplitHead split_head(const Str &a, const Str &p, bool reverse, const std::vector<Blk> *found = nullptr) {
+    SplitHead h;
+    h.pattern_empty = is_empty(p);
+    if (found) h.matches = reverse ? rsuppress_overlaps(*found, p) : suppress_overlaps(*found, p);
+    else h.matches = reverse ? rfind_all_non_overlapping(a, p) : find_all_non_overlapping(a, p);
+    h.matches.push_back(h.pattern_empty);
+    h.matches.push_back(h.pattern_empty);
+    h.p_len = len(p);
+    h.self_len = len(a);
+    return h;
+  }
+  // is_some_i for i in [lo, hi) (faithful form: one one-hot gather per i)
+  std::vector<Blk> split_is_some(const std::vector<Blk> &matches, const Radix &p_len, const Radix &self_len, size_t lo, size_t hi) {
+    Radix n_hidden = o.scalar_add(self_len, 2);
+    std::vector<Blk> out;
+    for (size_t i = lo; i < hi; i++) {
+      if (i == 0) { out.push_back(o.trivial_bool(true)); continue; }
+      Radix i_sub_plen = o.sub(usize(i), p_len);
+      Blk mi = element_at_bool(matches, i_sub_plen);
+      Blk i_lt_n_hidden = o.scalar_cmp(n_hidden, i, Cmp::GT);
+      out.push_back(o.bitand_(i_lt_n_hidden, mi));
+    }
+    return out;
+  }
   std::vector<Slice> split_opt(const Str &a, const Str &p, bool inclusive, bool reverse) {
-    Blk pattern_empty = is_empty(p);
-    std::vector<Blk> matches = reverse ? rfind_all_non_overlapping(a, p) : find_all_non_overlapping(a, p);
-    matches.push_back(pattern_empty);
-    matches.push_back(pattern_empty);
-    Radix p_len = len(p), self_len = len(a);
-    const size_t n = max_len(a) + 2;
+    SplitHead h = split_head(a, p, reverse);
+    return split_tail(h.matches, h.p_len, h.self_len, h.pattern_empty, max_len(a) + 2, inclusive, nullptr);
+  }
+  // `is_some_in`: the gathered is_some_i of the sharded form (nullptr: computed here)
+  std::vector<Slice> split_tail(const std::vector<Blk> &matches, const Radix &p_len, const Radix &self_len, const Blk &pattern_empty,
+                                size_t n, bool inclusive, const std::vector<Blk> *is_some_in) {
     Radix n_hidden = o.scalar_add(self_len, 2);
     Radix next_match = self_len;
     std::vector<Slice> elems(n);
@@ -1040,14 +1072,16 @@ struct S {
     // T = msg_mod^Bu is a right ROTATION of the zero-extended `matches` by len(p): a barrel shifter
     // (Bu stages of n lookups) instead of n one-hot gathers over n entries
     std::vector<Blk> shifted;
-    if (fast && usize_modulus() >= matches.size() && usize_modulus() >= n) {
+    if (!is_some_in && fast && usize_modulus() >= matches.size() && usize_modulus() >= n) {
       std::vector<Radix> mm;
       for (const Blk &x : matches) mm.push_back(Radix{x});
       for (const Radix &r : rotate_logdepth(mm, p_len, usize_modulus(), true, n)) shifted.push_back(r[0]);
     }
     for (size_t i = n; i-- > 0;) {
       Blk is_some;
-      if (i == 0) {
+      if (is_some_in) {
+        is_some = (*is_some_in)[i];
+      } else if (i == 0) {
         is_some = o.trivial_bool(true);
       } else if (!shifted.empty()) {
         Blk i_lt_n_hidden = o.scalar_cmp(n_hidden, i, Cmp::GT);
@@ -1115,7 +1149,11 @@ const char *op_signature(const std::string &op_full) {
   for (const auto &e : kOps)
     if (op == e.name) return e.sig;
   if (op == "find_all_range") return "SSII";
-  if (op == "any_of" || op == "index_of" || op == "rindex_of") return "I";
+  // stages of the position-sharded split (csrc/comm.hip): L = one BooleanBlock per element, one object
+  if (op == "split_head" || op == "rsplit_head") return "SSL";
+  if (op == "split_is_some_range") return "LUUII";
+  if (op == "split_tail" || op == "rsplit_tail") return "LLUUB";
+  if (op == "any_of" || op == "index_of" || op == "rindex_of" || op == "sum_gt_zero") return "I";
   // find_pred_unchecked / rfind_pred_unchecked (search.rs:196-213): the closure runs on the caller's side,
   // L = its results, one BooleanBlock per character, as one ciphertext object
   if (op == "find_pred" || op == "rfind_pred") return "L";
@@ -1152,6 +1190,84 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
     for (int i = shape[2]; i < shape[3]; i++) out.push_back(s.substr_eq(sa, (size_t)i, sb));  // search.rs:33-41
     Program prog = b.finish(out, op_full);
     prog.out_parts = {(int32_t)out.size()};
+    return prog;
+  }
+  // ---- stages of the position-sharded split / rsplit (split.rs:238-333; S::split_head / split_is_some / split_tail) ----
+  if (op == "split_head" || op == "rsplit_head") {  // shape {slots_a, slots_p}: a, p, found[slots_a - 1] -> matches[n], len(p), len(a), pattern_empty
+    if (shape.size() != 2 || shape[0] < 1 || shape[1] < 1) throw std::invalid_argument(op + " needs {slots_a, slots_p}");
+    const int n_found = shape[0] - 1;
+    Builder b(p, (shape[0] + shape[1]) * Bc + n_found);
+    Ops o(b);
+    S s{o, Bc, Bu, fast};
+    Str sa, sb;
+    int32_t next = 0;
+    for (int c = 0; c < shape[0]; c++) { Radix ch; for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1)); sa.push_back(ch); }
+    for (int c = 0; c < shape[1]; c++) { Radix ch; for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1)); sb.push_back(ch); }
+    std::vector<Blk> found;
+    for (int i = 0; i < n_found; i++) found.push_back(b.input(next++, 1));
+    S::SplitHead h = s.split_head(sa, sb, op == "rsplit_head", &found);
+    std::vector<Blk> out(h.matches);
+    push_all(out, h.p_len);
+    push_all(out, h.self_len);
+    out.push_back(h.pattern_empty);
+    Program prog = b.finish(out, op_full);
+    prog.out_parts = {(int32_t)h.matches.size(), Bu, Bu, 1};
+    return prog;
+  }
+  if (op == "split_is_some_range") {  // shape {n, lo, hi}: matches[n], len(p), len(a) -> is_some[lo, hi)
+    if (shape.size() != 3 || shape[0] < 2 || shape[1] < 0 || shape[2] < shape[1] || shape[2] > shape[0])
+      throw std::invalid_argument("split_is_some_range needs {n, lo, hi} with 0 <= lo <= hi <= n");
+    Builder b(p, shape[0] + 2 * Bu);
+    Ops o(b);
+    S s{o, Bc, Bu, fast};
+    int32_t next = 0;
+    std::vector<Blk> matches;
+    for (int i = 0; i < shape[0]; i++) matches.push_back(b.input(next++, 1));
+    Radix p_len, self_len;
+    for (int q = 0; q < Bu; q++) p_len.push_back(b.input(next++, msg_mod - 1));
+    for (int q = 0; q < Bu; q++) self_len.push_back(b.input(next++, msg_mod - 1));
+    std::vector<Blk> out = s.split_is_some(matches, p_len, self_len, (size_t)shape[1], (size_t)shape[2]);
+    Program prog = b.finish(out, op_full);
+    prog.out_parts = {(int32_t)out.size()};
+    return prog;
+  }
+  if (op == "split_tail" || op == "rsplit_tail") {  // shape {n}: matches[n], is_some[n], len(p), len(a), pattern_empty -> slices
+    if (shape.size() != 1 || shape[0] < 2) throw std::invalid_argument(op + " needs {n}");
+    const int n = shape[0];
+    Builder b(p, 2 * n + 2 * Bu + 1);
+    Ops o(b);
+    S s{o, Bc, Bu, fast};
+    int32_t next = 0;
+    std::vector<Blk> matches, is_some;
+    for (int i = 0; i < n; i++) matches.push_back(b.input(next++, 1));
+    for (int i = 0; i < n; i++) is_some.push_back(b.input(next++, 1));
+    Radix p_len, self_len;
+    for (int q = 0; q < Bu; q++) p_len.push_back(b.input(next++, msg_mod - 1));
+    for (int q = 0; q < Bu; q++) self_len.push_back(b.input(next++, msg_mod - 1));
+    Blk pattern_empty = b.input(next++, 1);
+    std::vector<S::Slice> v = s.split_tail(matches, p_len, self_len, pattern_empty, (size_t)n, false, &is_some);
+    if (op == "rsplit_tail") std::reverse(v.begin(), v.end());  // split.rs:374-378
+    std::vector<Blk> out;
+    for (auto &e : v) out.push_back(e.is_some);
+    for (auto &e : v) push_all(out, e.start);
+    for (auto &e : v) push_all(out, e.end);
+    Program prog = b.finish(out, op_full);
+    prog.out_parts = {n, n * Bu, n * Bu};
+    return prog;
+  }
+  // [sum > 0] of ONE block that is a sum of up to shape[0] booleans (the all-reduced partial `any`s of the
+  // position-sharded contains, SURVEY.md 2.4 C3: LWE addition is wrapping u64 addition): one lookup
+  if (op == "sum_gt_zero") {
+    if (shape.size() != 1 || shape[0] < 1 || shape[0] >= (1 << (p.message_bits + p.carry_bits)))
+      throw std::invalid_argument("sum_gt_zero needs {terms} with 1 <= terms < 2^(message_bits + carry_bits)");
+    Builder b(p, 1);
+    Blk x = b.input(0, (uint32_t)shape[0]);
+    x.noise = (double)shape[0];  // a sum of `terms` bootstrapped booleans
+    if (x.noise > b.noise_cap()) throw std::invalid_argument("sum_gt_zero: too many terms for this parameter set's noise cap");
+    std::vector<Blk> out{b.pbs(x, [](uint64_t v) { return v > 0 ? 1 : 0; })};
+    out[0].deg = 1;
+    Program prog = b.finish(out, op);
+    prog.out_parts = {1};
     return prog;
   }
   // reductions over n boolean blocks: shape = {n}

@@ -25,6 +25,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
 };
@@ -46,6 +47,7 @@ RcclApi *rccl() {
     FHES_SYM(CommDestroy, "ncclCommDestroy")
     FHES_SYM(AllGather, "ncclAllGather")
     FHES_SYM(Broadcast, "ncclBroadcast")
+    FHES_SYM(AllReduce, "ncclAllReduce")
     FHES_SYM(GetErrorString, "ncclGetErrorString")
 #undef FHES_SYM
   });
@@ -61,6 +63,9 @@ int rccl_fail(ncclResult_t r, const char *what) {
 
 struct fhes_comm {
   fhes_ctx *ctx = nullptr;
+  fhes_params params{};            // of ctx, or given with the executor hook
+  bool has_exec = false;           // host-memory executor hook instead of a device context (fhes_comm_create_host_exec)
+  fhes_executor exec{};
   int32_t rank = 0, world = 1;
   ncclComm_t nccl = nullptr;  // RCCL transport
   fhes_allgather_fn ag = nullptr;  // host transport
@@ -108,6 +113,95 @@ static int dev_broadcast(fhes_comm *c, void *buf, size_t bytes, int root) {
   return FHES_OK;
 }
 
+// in-place sum (wrapping u64 = LWE addition) of `bytes` bytes over all ranks
+static int dev_all_reduce_sum(fhes_comm *c, void *buf, size_t bytes) {
+  fhes_ctx *ctx = c->ctx;
+  if (c->world == 1 || bytes == 0) return FHES_OK;
+  if (c->nccl) {
+    FHES_NCCL(rccl()->AllReduce(buf, buf, bytes / 8, ncclUint64, ncclSum, c->nccl, ctx->stream));
+    return FHES_OK;
+  }
+  std::vector<uint64_t> send(bytes / 8), recv(bytes / 8 * (size_t)c->world);
+  FHES_HIP(hipStreamSynchronize(ctx->stream));
+  FHES_HIP(hipMemcpy(send.data(), buf, bytes, hipMemcpyDeviceToHost));
+  if (c->ag(c->user, send.data(), recv.data(), (int64_t)bytes) != 0) return fail(FHES_ERR_STATE, "host all-gather callback failed");
+  for (size_t w = 0; w < send.size(); w++) {
+    uint64_t acc = 0;
+    for (int r = 0; r < c->world; r++) acc += recv[(size_t)r * send.size() + w];
+    send[w] = acc;
+  }
+  FHES_HIP(hipMemcpy(buf, send.data(), bytes, hipMemcpyHostToDevice));
+  return FHES_OK;
+}
+
+// ---- the planner's view of "ciphertext rows and programs": the device context, or a caller's executor ----
+// (fhes_comm_create_host_exec: the CPU-only tests run THIS planner with the oracle as the executor, over gloo)
+namespace {
+struct X {
+  fhes_comm *c;
+  int32_t alloc(int32_t n) { return c->has_exec ? c->exec.alloc(c->exec.user, n) : fhes_arena_alloc(c->ctx, n); }
+  void release(int32_t first, int32_t n) {
+    if (first < 0 || n <= 0) return;
+    if (c->has_exec) (void)c->exec.release(c->exec.user, first, n);
+    else (void)fhes_arena_free(c->ctx, first, n);
+  }
+  int run(const fhes_program *p, const int32_t *in, int32_t *out) {
+    if (!c->has_exec) return fhes_program_run(c->ctx, p, in, out);
+    const int rc = c->exec.run(c->exec.user, p, in, out);
+    return rc == 0 ? FHES_OK : fail(FHES_ERR_STATE, "executor hook failed (%d)", rc);
+  }
+  size_t row_bytes() const { return c->has_exec ? (size_t)c->exec.row_words * 8 : (size_t)c->ctx->ct_stride * 8; }
+  int copy_rows(int32_t dst, int32_t src, int32_t n) {
+    if (n <= 0) return FHES_OK;
+    if (c->has_exec) { memmove(c->exec.rows(c->exec.user, dst), c->exec.rows(c->exec.user, src), (size_t)n * row_bytes()); return FHES_OK; }
+    fhes_ctx *ctx = c->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    FHES_HIP(hipSetDevice(ctx->device));
+    FHES_HIP(hipMemcpyAsync(ctx->arena + (size_t)dst * ctx->ct_stride, ctx->arena + (size_t)src * ctx->ct_stride,
+                            (size_t)n * row_bytes(), hipMemcpyDeviceToDevice, ctx->stream));
+    return FHES_OK;
+  }
+  int zero_rows(int32_t first, int32_t n) {  // all-zero words = the trivial encryption of 0
+    if (n <= 0) return FHES_OK;
+    if (c->has_exec) { memset(c->exec.rows(c->exec.user, first), 0, (size_t)n * row_bytes()); return FHES_OK; }
+    fhes_ctx *ctx = c->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    FHES_HIP(hipSetDevice(ctx->device));
+    FHES_HIP(hipMemsetAsync(ctx->arena + (size_t)first * ctx->ct_stride, 0, (size_t)n * row_bytes(), ctx->stream));
+    return FHES_OK;
+  }
+  int all_gather_rows(int32_t first, int32_t per_rank) {  // in place: rank r owns rows [first + r * per_rank, ...)
+    if (c->world == 1 || per_rank <= 0) return FHES_OK;
+    if (!c->has_exec) return fhes_comm_all_gather_cts(c, first, per_rank);
+    const size_t b = (size_t)per_rank * row_bytes();
+    std::vector<unsigned char> recv(b * (size_t)c->world);
+    if (c->ag(c->user, c->exec.rows(c->exec.user, first + c->rank * per_rank), recv.data(), (int64_t)b) != 0)
+      return fail(FHES_ERR_STATE, "host all-gather callback failed");
+    memcpy(c->exec.rows(c->exec.user, first), recv.data(), recv.size());
+    return FHES_OK;
+  }
+  int all_reduce_rows(int32_t first, int32_t n) {  // in place: sum over the ranks, word by word
+    if (c->world == 1 || n <= 0) return FHES_OK;
+    if (!c->has_exec) {
+      fhes_ctx *ctx = c->ctx;
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      FHES_HIP(hipSetDevice(ctx->device));
+      return dev_all_reduce_sum(c, ctx->arena + (size_t)first * ctx->ct_stride, (size_t)n * row_bytes());
+    }
+    const size_t words = (size_t)n * row_bytes() / 8;
+    uint64_t *rows = c->exec.rows(c->exec.user, first);
+    std::vector<uint64_t> recv(words * (size_t)c->world);
+    if (c->ag(c->user, rows, recv.data(), (int64_t)(words * 8)) != 0) return fail(FHES_ERR_STATE, "host all-gather callback failed");
+    for (size_t w = 0; w < words; w++) {
+      uint64_t acc = 0;
+      for (int r = 0; r < c->world; r++) acc += recv[(size_t)r * words + w];
+      rows[w] = acc;
+    }
+    return FHES_OK;
+  }
+};
+}  // namespace
+
 extern "C" {
 
 int fhes_comm_unique_id(uint8_t id[FHES_COMM_ID_BYTES]) {
@@ -129,7 +223,7 @@ fhes_comm *fhes_comm_create_rccl(fhes_ctx *ctx, int32_t rank, int32_t world, con
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   auto *c = new fhes_comm;
-  c->ctx = ctx; c->rank = rank; c->world = world;
+  c->ctx = ctx; c->rank = rank; c->world = world; c->params = ctx->p;
   ncclResult_t r = a->CommInitRank(&c->nccl, world, u, rank);
   if (r != ncclSuccess) { rccl_fail(r, "ncclCommInitRank"); delete c; return nullptr; }
   return c;
@@ -139,6 +233,23 @@ fhes_comm *fhes_comm_create_host(fhes_ctx *ctx, int32_t rank, int32_t world, fhe
   if (world < 1 || rank < 0 || rank >= world || (world > 1 && (!ag || !bc))) { fail(FHES_ERR_INVALID, "comm_create_host: bad argument"); return nullptr; }
   auto *c = new fhes_comm;
   c->ctx = ctx; c->rank = rank; c->world = world; c->ag = ag; c->bc = bc; c->user = user;
+  if (ctx) c->params = ctx->p;
+  return c;
+}
+
+fhes_comm *fhes_comm_create_host_exec(const fhes_params *p, int32_t rank, int32_t world, fhes_allgather_fn ag, fhes_bcast_fn bc,
+                                      void *user, const fhes_executor *exec) {
+  std::string why;
+  if (!p || !params_valid(*p, &why) || !exec || !exec->alloc || !exec->release || !exec->rows || !exec->run ||
+      exec->row_words < fhes_ct_words(p) || world < 1 || rank < 0 || rank >= world || (world > 1 && (!ag || !bc))) {
+    fail(FHES_ERR_INVALID, "comm_create_host_exec: bad argument %s", why.c_str());
+    return nullptr;
+  }
+  auto *c = new fhes_comm;
+  c->rank = rank; c->world = world; c->ag = ag; c->bc = bc; c->user = user;
+  c->params = *p;
+  c->has_exec = true;
+  c->exec = *exec;
   return c;
 }
 
@@ -206,20 +317,30 @@ int fhes_comm_broadcast_cts(fhes_comm *c, int32_t first, int32_t count, int32_t 
 int fhes_comm_broadcast_keys(fhes_comm *c, int32_t root) {
   if (!c || !c->ctx || root < 0 || root >= c->world) return fail(FHES_ERR_INVALID, "broadcast_keys: bad argument");
   fhes_ctx *ctx = c->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  MainLaneHold hold(ctx);
   FHES_HIP(hipSetDevice(ctx->device));
+  FHES_HIP(hipDeviceSynchronize());  // no lane may still read the keys that are replaced
   if (c->rank == root && !ctx->keys_loaded) return fail(FHES_ERR_STATE, "broadcast_keys: the root has no keys");
   const Dims &d = ctx->dims;
   const size_t ksk_b = (size_t)d.big * d.ks_level * ctx->ks_stride * 8, bias_b = (size_t)ctx->ks_stride * 8;
-  const size_t bsk_b = (size_t)d.n_ggsw * 4 * d.M * 16;
+  const size_t bsk_b = (size_t)d.n_ggsw * d.L * (d.k + 1) * (d.k + 1) * d.M * 16;
   if (!ctx->ksk) FHES_HIP(hipMalloc(&ctx->ksk, ksk_b));
   if (!ctx->ksk_bias) FHES_HIP(hipMalloc(&ctx->ksk_bias, bias_b));
   if (!ctx->bsk_f) FHES_HIP(hipMalloc(&ctx->bsk_f, bsk_b));
-  if (!ctx->bsk_e) FHES_HIP(hipMalloc(&ctx->bsk_e, bsk_b));
+  const bool has_e = ctx->bsk_e != nullptr || (d.k == 1 && d.L == 1 && (d.N == 2048 || d.N == 256));  // throughput-kernel layout
+  if (has_e && !ctx->bsk_e) FHES_HIP(hipMalloc(&ctx->bsk_e, bsk_b));
+  // the packed i8 key of the matrix-core keyswitch (the default path) travels too: a rank that kept a stale
+  // one would keyswitch with the OLD key, a rank without one would fall back to the VALU kernel
+  const bool has_pk = ((size_t)d.big * d.ks_level) % 64 == 0;
+  const int n_wb = (d.n + 1 + 15) / 16;
+  const size_t pk_b = has_pk ? (size_t)(d.big * d.ks_level / 64) * n_wb * 8 * 64 * 16 : 0;
+  if (has_pk && !ctx->ksk_pk) FHES_HIP(hipMalloc(&ctx->ksk_pk, pk_b));
   int rc = dev_broadcast(c, ctx->ksk, ksk_b, root);
+  if (rc == FHES_OK && has_pk) rc = dev_broadcast(c, ctx->ksk_pk, pk_b, root);
+  if (rc == FHES_OK && has_pk) ctx->ks_n_wb = n_wb;
   if (rc == FHES_OK) rc = dev_broadcast(c, ctx->ksk_bias, bias_b, root);
   if (rc == FHES_OK) rc = dev_broadcast(c, ctx->bsk_f, bsk_b, root);
-  if (rc == FHES_OK) rc = dev_broadcast(c, ctx->bsk_e, bsk_b, root);
+  if (rc == FHES_OK && has_e) rc = dev_broadcast(c, ctx->bsk_e, bsk_b, root);
   if (rc == FHES_OK) { FHES_HIP(hipStreamSynchronize(ctx->stream)); ctx->keys_loaded = true; }
   return rc;
 }
@@ -230,21 +351,41 @@ static fhes_program *comm_program(fhes_comm *c, const char *op, const std::vecto
   key += ":u" + std::to_string(bu);
   auto it = c->progs.find(key);
   if (it != c->progs.end()) return it->second;
-  fhes_program *p = fhes_program_compile(&c->ctx->p, op, shape.data(), (int32_t)shape.size(), bu);
+  fhes_program *p = fhes_program_compile(&c->params, op, shape.data(), (int32_t)shape.size(), bu);
   if (p) c->progs[key] = p;
   return p;
 }
 
-int fhes_sharded_search(fhes_comm *c, const char *op, int32_t a_first, int32_t a_slots, int32_t p_first,
-                        int32_t p_slots, int32_t bu, int32_t *out_handles, int32_t max_out, int32_t *n_out) {
-  if (!c || !c->ctx || !op || !out_handles || !n_out || a_slots < 1 || p_slots < 1 || a_first < 0 || p_first < 0)
-    return fail(FHES_ERR_INVALID, "sharded_search: bad argument");
-  const std::string o = op;
+// one status word per rank after the last stage of an operation: a rank that failed locally has still entered
+// every collective (with zero rows), so nobody hangs, and EVERY rank learns that the result is void
+static int commit(fhes_comm *c, int rc_local, const char *what) {
+  if (c->world == 1) return rc_local;
+  int64_t mine = rc_local;
+  std::vector<int64_t> all((size_t)c->world, 0);
+  const int rc = fhes_comm_all_gather_host(c, &mine, all.data(), 8);
+  if (rc) return rc;
+  for (int r = 0; r < c->world; r++)
+    if (all[(size_t)r] != 0)
+      return r == c->rank ? rc_local
+                          : fail(FHES_ERR_STATE, "%s: rank %d failed with status %lld; the result is void on every rank", what, r, (long long)all[(size_t)r]);
+  return FHES_OK;
+}
+
+int fhes_sharded_op(fhes_comm *c, const char *op_in, int32_t a_first, int32_t a_slots, int32_t p_first,
+                    int32_t p_slots, int32_t bu, int32_t *out_handles, int32_t max_out, int32_t *n_out) {
+  if (!c || (!c->ctx && !c->has_exec) || !op_in || !out_handles || !n_out || a_slots < 1 || p_slots < 1 || a_first < 0 || p_first < 0)
+    return fail(FHES_ERR_INVALID, "sharded_op: bad argument");
+  std::string o = op_in, suffix;
+  {
+    static const std::string ld = "_logdepth";  // opt-in parallel-prefix forms: passed on to every stage
+    if (o.size() > ld.size() && o.compare(o.size() - ld.size(), ld.size(), ld) == 0) { suffix = ld; o.resize(o.size() - ld.size()); }
+  }
+  const bool is_split = o == "split" || o == "rsplit";
   const char *reduce = o == "contains" ? "any_of" : o == "find" ? "index_of" : o == "rfind_last" ? "rindex_of" : nullptr;
-  if (!reduce) return fail(FHES_ERR_INVALID, "sharded_search: op must be contains / find / rfind_last");
+  if (!reduce && !is_split) return fail(FHES_ERR_INVALID, "sharded_op: op must be contains / find / rfind_last / split / rsplit");
   std::lock_guard<std::mutex> lk(c->mu);
-  fhes_ctx *ctx = c->ctx;
-  const int msg_mod = 1 << ctx->p.message_bits;
+  X x{c};
+  const int msg_mod = 1 << c->params.message_bits;
   int bc = 0;
   for (int v = 1; v < 128; v *= msg_mod) bc++;  // blocks per char (lib.rs:60-61)
   const int64_t n_pos = a_slots - 1;               // start positions (search.rs:34)
@@ -252,51 +393,118 @@ int fhes_sharded_search(fhes_comm *c, const char *op, int32_t a_first, int32_t a
   int rc = fhes_shard_range(n_pos, c->world, c->rank, &lo, &hi);
   if (rc) return rc;
   const int32_t chunk = (int32_t)((n_pos + c->world - 1) / c->world);
-  const int32_t n_red_out = o == "contains" ? 1 : 1 + bu;
-  if (max_out < n_red_out) return fail(FHES_ERR_INVALID, "sharded_search: need room for %d handles", n_red_out);
+  const int32_t n_split = a_slots + 1;             // slices of split_opt: max_len(self) + 2 (split.rs:270)
+  const int32_t n_final = is_split ? n_split * (1 + 2 * bu) : (o == "contains" ? 1 : 1 + bu);
+  if (max_out < (is_split ? 3 : n_final)) return fail(FHES_ERR_INVALID, "sharded_op: need room for %d handles", is_split ? 3 : n_final);
+  std::vector<int32_t> ab;                         // handles of the two operands, in program order
+  for (int k = 0; k < a_slots * bc; k++) ab.push_back(a_first + k);
+  for (int k = 0; k < p_slots * bc; k++) ab.push_back(p_first + k);
+  // everything below runs on EVERY rank in the same order; a local failure is carried in `rc` past the collectives
+  std::vector<std::pair<int32_t, int32_t>> owned;  // scratch ranges to hand back
+  auto take = [&](int32_t n) { int32_t h = n > 0 ? x.alloc(n) : -1; if (h >= 0) owned.push_back({h, n}); else if (n > 0 && rc == FHES_OK) rc = h; return h; };
+  auto drop_all = [&]() { for (auto &r : owned) x.release(r.first, r.second); owned.clear(); };
+  auto run_prog = [&](const char *name, const std::vector<int32_t> &shape, const std::vector<int32_t> &in, std::vector<int32_t> &out) {
+    if (rc != FHES_OK) return;
+    fhes_program *pr = comm_program(c, (std::string(name) + suffix).c_str(), shape, bu);
+    if (!pr) { rc = FHES_ERR_INVALID; return; }
+    int64_t info[8];
+    fhes_program_info(pr, info);
+    out.assign((size_t)std::max<int64_t>(info[1], 1), -1);
+    if ((int64_t)in.size() != info[0]) { rc = fail(FHES_ERR_STATE, "internal: %s takes %lld inputs, %zu given", name, (long long)info[0], in.size()); return; }
+    rc = x.run(pr, in.data(), out.data());
+    if (rc != FHES_OK) out.assign(out.size(), -1);
+  };
 
-  // gathered found[]: world segments of `chunk` rows, so that found[i] is row G + i
-  int32_t G = -1;
-  if (n_pos > 0) {
-    G = fhes_arena_alloc(ctx, chunk * c->world);
-    if (G < 0) return G;
-  }
-  auto release = [&]() { if (G >= 0) fhes_arena_free(ctx, G, chunk * c->world); };
-  if (hi > lo) {
-    fhes_program *pr = comm_program(c, "find_all_range", {a_slots, p_slots, (int32_t)lo, (int32_t)hi}, bu);
-    if (!pr) { release(); return FHES_ERR_INVALID; }
-    std::vector<int32_t> in;
-    for (int k = 0; k < a_slots * bc; k++) in.push_back(a_first + k);
-    for (int k = 0; k < p_slots * bc; k++) in.push_back(p_first + k);
-    std::vector<int32_t> out((size_t)(hi - lo));
-    rc = fhes_program_run(ctx, pr, in.data(), out.data());
-    if (rc) { release(); return rc; }
-    {  // own segment into place (device-to-device, stream-ordered behind the program)
-      std::lock_guard<std::mutex> lk2(ctx->mu);
-      hipError_t e = hipSetDevice(ctx->device);
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(ctx->arena + (size_t)(G + lo) * ctx->ct_stride, ctx->arena + (size_t)out[0] * ctx->ct_stride,
-                           (size_t)(hi - lo) * ctx->ct_stride * 8, hipMemcpyDeviceToDevice, ctx->stream);
-      if (e != hipSuccess) rc = hip_fail(e, "segment copy");
+  // ---- stage 1: found[i] = substr_eq(i, p) for this rank's block of start positions (search.rs:33-41) ----
+  const bool partial_any = o == "contains" && c->world > 1 && c->world <= 15 && suffix.empty();
+  int32_t G = -1;                                  // gathered found[]: world segments of `chunk` rows, found[i] = row G + i
+  std::vector<int32_t> local;                      // this rank's found[lo, hi)
+  if (hi > lo) run_prog("find_all_range", {a_slots, p_slots, (int32_t)lo, (int32_t)hi}, ab, local);
+  if (rc == FHES_OK && hi > lo) owned.push_back({local[0], (int32_t)(hi - lo)});
+  std::vector<int32_t> result;
+  if (partial_any) {
+    // contains (search.rs:17-20): `any` of the local block, then ONE all-reduce of that single
+    // boolean -- LWE addition is wrapping u64 addition -- and a final lookup [sum > 0] (sum <= world <= 15 < 16)
+    const int32_t R = take(1);
+    if (R >= 0) {
+      int zr = x.zero_rows(R, 1);             // a rank without positions contributes the trivial 0
+      if (zr && rc == FHES_OK) rc = zr;
+      if (hi > lo && rc == FHES_OK) {
+        std::vector<int32_t> part;
+        run_prog("any_of", {(int32_t)(hi - lo)}, local, part);
+        if (rc == FHES_OK) { owned.push_back({part[0], 1}); rc = x.copy_rows(R, part[0], 1); }
+      }
+      int cr = x.all_reduce_rows(R, 1);
+      if (cr && rc == FHES_OK) rc = cr;
+      run_prog("sum_gt_zero", {c->world}, {R}, result);
     }
-    fhes_arena_free(ctx, out[0], (int32_t)(hi - lo));
-    if (rc) { release(); return rc; }
+  } else {
+    if (n_pos > 0) {
+      G = take(chunk * c->world);
+      if (G >= 0) {
+        if (hi > lo && rc == FHES_OK) rc = x.copy_rows(G + (int32_t)lo, local[0], (int32_t)(hi - lo));
+        int cr = x.all_gather_rows(G, chunk);
+        if (cr && rc == FHES_OK) rc = cr;
+      }
+    }
+    std::vector<int32_t> found((size_t)n_pos);
+    for (int64_t i = 0; i < n_pos; i++) found[(size_t)i] = G + (int32_t)i;
+    if (!is_split) {
+      run_prog(reduce, {(int32_t)n_pos}, found, result);   // replicated: deterministic, identical on every rank
+    } else {
+      // ---- split / rsplit (split.rs:238-333) ----
+      // stage 2 (replicated): non-overlapping matches, len(p), len(self), pattern_empty
+      std::vector<int32_t> in2(ab), head;
+      in2.insert(in2.end(), found.begin(), found.end());
+      run_prog(o == "split" ? "split_head" : "rsplit_head", {a_slots, p_slots}, in2, head);
+      if (rc == FHES_OK) owned.push_back({head[0], n_split + 2 * bu + 1});
+      // stage 3: is_some_i = element_at_bool(matches, i - len(p)) & ... for this rank's block of OUTPUT indices
+      // (mod.rs:271-287 called per index at split.rs:283-285: the O(n^2) grid), one all-gather of the booleans
+      int64_t lo3 = 0, hi3 = 0;
+      (void)fhes_shard_range(n_split, c->world, c->rank, &lo3, &hi3);
+      const int32_t chunk3 = (n_split + c->world - 1) / c->world;
+      const int32_t G3 = take(chunk3 * c->world);
+      if (G3 >= 0 && hi3 > lo3) {
+        std::vector<int32_t> in3, part;
+        if (rc == FHES_OK) for (int i = 0; i < n_split + 2 * bu; i++) in3.push_back(head[0] + i);   // matches, len(p), len(self)
+        run_prog("split_is_some_range", {n_split, (int32_t)lo3, (int32_t)hi3}, in3, part);
+        if (rc == FHES_OK) { owned.push_back({part[0], (int32_t)(hi3 - lo3)}); rc = x.copy_rows(G3 + (int32_t)lo3, part[0], (int32_t)(hi3 - lo3)); }
+      }
+      if (G3 >= 0) { int cr = x.all_gather_rows(G3, chunk3); if (cr && rc == FHES_OK) rc = cr; }
+      // stage 4 (replicated): the carried next_match chain and the slice bounds
+      std::vector<int32_t> in4;
+      if (rc == FHES_OK) {
+        for (int i = 0; i < n_split; i++) in4.push_back(head[0] + i);
+        for (int i = 0; i < n_split; i++) in4.push_back(G3 + i);
+        for (int i = 0; i < 2 * bu + 1; i++) in4.push_back(head[0] + n_split + i);
+      }
+      run_prog(o == "split" ? "split_tail" : "rsplit_tail", {n_split}, in4, result);
+    }
   }
-  if (n_pos > 0 && c->world > 1) {
-    rc = fhes_comm_all_gather_cts(c, G, chunk);
-    if (rc) { release(); return rc; }
+  drop_all();
+  rc = commit(c, rc, op_in);
+  if (rc) {
+    if (!result.empty() && result[0] >= 0) x.release(result[0], n_final);
+    return rc;
   }
-  fhes_program *red = comm_program(c, reduce, {(int32_t)n_pos}, bu);
-  if (!red) { release(); return FHES_ERR_INVALID; }
-  std::vector<int32_t> in((size_t)n_pos);
-  for (int64_t i = 0; i < n_pos; i++) in[(size_t)i] = G + (int32_t)i;
-  std::vector<int32_t> out((size_t)n_red_out);
-  rc = fhes_program_run(ctx, red, in.data(), out.data());
-  release();
-  if (rc) return rc;
-  for (int k = 0; k < n_red_out; k++) out_handles[k] = out[k];
-  *n_out = n_red_out;
+  if (is_split) {  // one contiguous range: is_some[n], start[n][Bu], end[n][Bu]
+    out_handles[0] = result[0];
+    out_handles[1] = result[0] + n_split;
+    out_handles[2] = result[0] + n_split * (1 + bu);
+    *n_out = 3;
+  } else {
+    for (int k = 0; k < n_final; k++) out_handles[k] = result[0] + k;
+    *n_out = n_final;
+  }
   return FHES_OK;
+}
+
+int fhes_sharded_search(fhes_comm *c, const char *op, int32_t a_first, int32_t a_slots, int32_t p_first,
+                        int32_t p_slots, int32_t bu, int32_t *out_handles, int32_t max_out, int32_t *n_out) {
+  const std::string o = op ? op : "";
+  if (o.rfind("contains", 0) != 0 && o.rfind("find", 0) != 0 && o.rfind("rfind_last", 0) != 0)
+    return fail(FHES_ERR_INVALID, "sharded_search: op must be contains / find / rfind_last");
+  return fhes_sharded_op(c, op, a_first, a_slots, p_first, p_slots, bu, out_handles, max_out, n_out);
 }
 
 }  // extern "C"

@@ -28,6 +28,8 @@ struct Lane {
   int64_t ks_out_nodes = 0;
   int8_t *ks_dig = nullptr;     // digits of a wide launch, A-fragment order: [ceil(nodes / 128) * 8][ksteps][64][16]
   uint64_t *ks_body = nullptr;  // [nodes]
+  unsigned char *gen_scratch = nullptr;  // generic blind rotate: accumulators and digit spectra of a launch
+  size_t gen_scratch_bytes = 0;
   int32_t *slot_map = nullptr;  // slot map of the program run this lane carries
   size_t slot_map_cap = 0;
   bool is_main = false;

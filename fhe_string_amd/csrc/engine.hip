@@ -109,18 +109,32 @@ void host_fwd_tables(int N, std::vector<double> &root, std::vector<double> &psi,
     }
 }
 
+// the shapes the specialised throughput kernels (variant 5, multi-bit) are written for
+static bool fast_shape(const fhes_params &p) {
+  return p.glwe_dim == 1 && p.pbs_level == 1 && (p.pbs_base_log == 23 || p.pbs_base_log == 18) && (p.poly_size == 2048 || p.poly_size == 256);
+}
+
+// What the device serves (round 3: every classic shape of `generate_keys_with_params`, lib.rs:50-62, within the
+// limits below; anything else is refused HERE, loudly, never run on a wrong kernel):
+//   * k = 1, L = 1, N = 2048 (256 for tests), base 2^23 / 2^18: the throughput kernels, classic and multi-bit;
+//   * classic sets with k <= 3, L <= 3, N = 256 .. 8192: the generic kernel (blind_rotate_gen_kernel) -- one
+//     workgroup of (k + 1) * N / 16 threads (<= 1024) with (k + 1) * N * 8 bytes of LDS (<= 128 KB).
 static bool kernels_support(const fhes_params &p, std::string *why) {
-  if (p.glwe_dim != 1) { *why = "HIP kernels support glwe_dim == 1 only"; return false; }
-  if (p.pbs_level != 1) { *why = "HIP kernels support pbs_level == 1 only"; return false; }
-  // one decomposition level; the base is a template parameter of the blind-rotate kernels: 2^23 (the
-  // parameter sets of this engine) and 2^18 (the value recalled for tfhe-rs's multi-bit sets)
-  if (p.pbs_base_log != 23 && p.pbs_base_log != 18) { *why = "HIP kernels are instantiated for pbs_base_log 23 and 18"; return false; }
-  if (p.poly_size != 2048 && p.poly_size != 256) { *why = "HIP kernels are instantiated for poly_size 2048 (and 256 for tests)"; return false; }
+  if (p.poly_size < 256 || p.poly_size > 8192) { *why = "HIP kernels are instantiated for poly_size 256 .. 8192"; return false; }
   if (p.ks_level > dev::KS_MAXLV || p.ks_base_log > 7) { *why = "keyswitch decomposition too large"; return false; }
   // keyswitch_kernel keeps the rounded prefix of a mask coefficient in 32 bits
   if (p.ks_level * p.ks_base_log > 31) { *why = "keyswitch decomposition wider than 31 bits (ks_level * ks_base_log)"; return false; }
-  if (p.lwe_dim + 1 > 1024) { *why = "lwe_dim too large"; return false; }
-  if (p.grouping_factor > 3) { *why = "HIP kernels support grouping factors 2 and 3"; return false; }
+  if (p.lwe_dim + 1 > 1024) { *why = "lwe_dim too large (at most 1023)"; return false; }
+  if (p.grouping_factor > 1) {
+    if (p.grouping_factor > 3) { *why = "HIP kernels support grouping factors 2 and 3"; return false; }
+    if (!fast_shape(p)) { *why = "the multi-bit kernels are written for glwe_dim 1, pbs_level 1, pbs_base_log 23 / 18, poly_size 2048 (256)"; return false; }
+    return true;
+  }
+  if (fast_shape(p)) return true;
+  if (p.glwe_dim > 3 || p.pbs_level > 3) { *why = "the generic blind rotate serves glwe_dim <= 3 and pbs_level <= 3"; return false; }
+  if ((p.glwe_dim + 1) * (p.poly_size / 16) > 1024) { *why = "the generic blind rotate needs (glwe_dim + 1) * poly_size / 16 <= 1024 threads"; return false; }
+  if ((size_t)(p.glwe_dim + 1) * p.poly_size * 8 + (size_t)(p.lwe_dim + 4) * 4 > 160 * 1024) { *why = "the generic blind rotate needs (glwe_dim + 1) * poly_size * 8 bytes of LDS"; return false; }
+  if (p.pbs_base_log * p.pbs_level > 62) { *why = "PBS decomposition wider than 62 bits"; return false; }
   return true;
 }
 
@@ -451,6 +465,47 @@ static int launch_br_v5(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+// generic shapes (k <= 3, L <= 3, N = 256 .. 8192): blind_rotate_gen_kernel with its per-workgroup global scratch
+static size_t gen_scratch_per_wg(const Dims &d) {
+  return (size_t)(d.k + 1) * d.N * 8 + (size_t)(d.k + 1) * d.L * d.M * 16;
+}
+template <int LOGN>
+static int launch_br_gen_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  constexpr int N = 1 << LOGN, M = N / 2;
+  const Dims &dm = ctx->dims;
+  const size_t per = gen_scratch_per_wg(dm), need = per * (size_t)d.v_count;
+  if (lane.gen_scratch_bytes < need) {
+    if (lane.gen_scratch) FHES_HIP(hipFree(lane.gen_scratch));
+    lane.gen_scratch = nullptr;
+    lane.gen_scratch_bytes = 0;
+    FHES_HIP(hipMalloc(&lane.gen_scratch, need));
+    lane.gen_scratch_bytes = need;
+  }
+  const size_t lds = (size_t)(dm.k + 1) * M * 16 + (size_t)((dm.n + 1 + 3) & ~3) * 4;
+  auto kern = dev::blind_rotate_gen_kernel<LOGN>;
+  const unsigned bit = 1u << (2 + (LOGN - 8));  // bits 2..7
+  if (!(ctx->attr_done & bit)) {
+    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ctx->attr_done |= bit;
+  }
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3((dm.k + 1) * (M / 8)), lds, lane.stream, d, ctx->arena, ctx->ct_stride,
+                     lane.ks_out, ctx->ks_stride, dm.n, dm.k, dm.L, dm.pbs_base_log, ctx->bsk_f, ctx->lut_polys, ctx->twist,
+                     ctx->tw, ctx->psi, lane.gen_scratch, per);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+static int launch_br_gen(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  switch (ctx->dims.N) {
+    case 256: return launch_br_gen_n<8>(ctx, lane, d);
+    case 512: return launch_br_gen_n<9>(ctx, lane, d);
+    case 1024: return launch_br_gen_n<10>(ctx, lane, d);
+    case 2048: return launch_br_gen_n<11>(ctx, lane, d);
+    case 4096: return launch_br_gen_n<12>(ctx, lane, d);
+    case 8192: return launch_br_gen_n<13>(ctx, lane, d);
+    default: return fail(FHES_ERR_UNSUPPORTED, "poly_size %d", ctx->dims.N);
+  }
+}
+
 // variant: 0 = auto (variant 5), 1 = the simple kernel, 5 = the throughput kernel, 6 / 7 = 5 with other
 // wave-priority policies; all produce the same bits.  (Variants 2-4 of earlier rounds are gone.)
 static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
@@ -464,6 +519,7 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
     if (ctx->dims.N == 2048) return lat ? launch_br_mb<11, 2, true, true>(ctx, lane, d) : launch_br_mb<11, 2, false>(ctx, lane, d);
     return lat ? launch_br_mb<8, 2, true, true>(ctx, lane, d) : launch_br_mb<8, 2, false>(ctx, lane, d);
   }
+  if (!fast_shape(ctx->p) || ctx->br_variant == 12) return launch_br_gen(ctx, lane, d);  // 12: the generic kernel on a 2_2 set (tests)
   int variant = ctx->br_variant;
   if (variant == 0) variant = 5;  // every launch size
   if (variant != 1 && (variant < 5 || variant > 10 || variant == 8))
@@ -515,7 +571,9 @@ int launch_pbs(fhes_ctx *ctx, Lane &lane, const DevNodeArrays &a, int32_t first,
   if (count <= 0 || n_inst <= 0) return FHES_OK;
   const int64_t total = (int64_t)count * n_inst;
   if (total > INT32_MAX) return fail(FHES_ERR_INVALID, "batch too large");
-  const int32_t kMaxChunk = 16384;
+  int32_t kMaxChunk = 16384;
+  if (!fast_shape(ctx->p) || ctx->br_variant == 12)  // the generic kernel's global scratch: at most 1 GiB per launch
+    kMaxChunk = (int32_t)std::max<size_t>(64, std::min<size_t>(16384, ((size_t)1 << 30) / gen_scratch_per_wg(ctx->dims)));
   for (int32_t off = 0; off < (int32_t)total; off += kMaxChunk) {
     const int32_t c = std::min<int32_t>(kMaxChunk, (int32_t)total - off);
     int rc = ensure_ks_out(ctx, lane, c);
@@ -699,7 +757,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->root); (void)hipFree(ctx->psi); (void)hipFree(ctx->odd_fix); (void)hipFree(ctx->cdpp); (void)hipFree(ctx->lut_polys);
   (void)hipDeviceSynchronize();
-  auto drop_lane = [](Lane &l) { (void)hipFree(l.ks_out); (void)hipFree(l.ks_dig); (void)hipFree(l.ks_body); (void)hipFree(l.slot_map); };
+  auto drop_lane = [](Lane &l) { (void)hipFree(l.ks_out); (void)hipFree(l.ks_dig); (void)hipFree(l.ks_body); (void)hipFree(l.slot_map); (void)hipFree(l.gen_scratch); };
   drop_lane(ctx->main);
   for (auto &l : ctx->side) {
     drop_lane(*l);
@@ -760,23 +818,31 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
   }
   // bootstrapping key -> Fourier domain on the device
   {
-    const size_t npoly = (size_t)d.n_ggsw * 4;
+    const size_t npoly = (size_t)d.n_ggsw * d.L * (d.k + 1) * (d.k + 1);
     uint64_t *tmp = nullptr;
     FHES_HIP(hipMalloc(&tmp, npoly * d.N * 8));
     FHES_HIP(hipMemcpy(tmp, bsk, npoly * d.N * 8, hipMemcpyHostToDevice));
     if (!ctx->bsk_f) FHES_HIP(hipMalloc(&ctx->bsk_f, npoly * d.M * 16));
     const size_t lds = (size_t)d.M * 16;
-    if (d.N == 2048)
-      hipLaunchKernelGGL((dev::bsk_to_fourier_kernel<11>), dim3(npoly), dim3(d.M / 8), lds, ctx->stream, tmp, ctx->bsk_f, ctx->psi, ctx->odd_fix);
-    else
-      hipLaunchKernelGGL((dev::bsk_to_fourier_kernel<8>), dim3(npoly), dim3(d.M / 8), lds, ctx->stream, tmp, ctx->bsk_f, ctx->psi, ctx->odd_fix);
+#define FHES_B2F(LG) hipLaunchKernelGGL((dev::bsk_to_fourier_kernel<LG>), dim3(npoly), dim3(d.M / 8), lds, ctx->stream, tmp, ctx->bsk_f, ctx->psi, ctx->odd_fix)
+    switch (d.N) {
+      case 256: FHES_B2F(8); break;
+      case 512: FHES_B2F(9); break;
+      case 1024: FHES_B2F(10); break;
+      case 2048: FHES_B2F(11); break;
+      case 4096: FHES_B2F(12); break;
+      default: FHES_B2F(13); break;
+    }
+#undef FHES_B2F
     FHES_HIP(hipGetLastError());
-    if (!ctx->bsk_e) FHES_HIP(hipMalloc(&ctx->bsk_e, npoly * d.M * 16));
-    if (d.N == 2048)
-      hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<11>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e);
-    else
-      hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<8>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e);
-    FHES_HIP(hipGetLastError());
+    if (fast_shape(ctx->p)) {  // the register-order layout of the throughput kernels
+      if (!ctx->bsk_e) FHES_HIP(hipMalloc(&ctx->bsk_e, npoly * d.M * 16));
+      if (d.N == 2048)
+        hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<11>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e);
+      else
+        hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<8>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e);
+      FHES_HIP(hipGetLastError());
+    }
     FHES_HIP(hipStreamSynchronize(ctx->stream));
     FHES_HIP(hipFree(tmp));
   }
@@ -898,7 +964,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  if (v < 0 || v > 10) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
+  if (v < 0 || (v > 10 && v != 12)) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
   ctx->br_variant = v;
   return FHES_OK;
 }
@@ -907,7 +973,7 @@ int fhes_debug_bsk_fourier(fhes_ctx *ctx, double *out) {
   if (!ctx || !out) return fail(FHES_ERR_INVALID, "null argument");
   if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
   FHES_HIP(hipSetDevice(ctx->device));
-  FHES_HIP(hipMemcpy(out, ctx->bsk_f, (size_t)ctx->dims.n_ggsw * 4 * ctx->dims.M * 16, hipMemcpyDeviceToHost));
+  FHES_HIP(hipMemcpy(out, ctx->bsk_f, (size_t)ctx->dims.n_ggsw * ctx->dims.L * (ctx->dims.k + 1) * (ctx->dims.k + 1) * ctx->dims.M * 16, hipMemcpyDeviceToHost));
   return FHES_OK;
 }
 

@@ -636,6 +636,134 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
 }
 
 // ------------------------------------------------------------------------------------------
+// K2+K3 (generic): blind rotate + sample extract for EVERY classic parameter shape the public constructor
+// accepts (`generate_keys_with_params(p: ClassicPBSParameters, l)`, /root/reference/src/lib.rs:50-62):
+// glwe_dim k in 1..3, pbs_level L in 1..3, any pbs_base_log, N = 2^LOGN (256 .. 8192).  Correctness first: the
+// arithmetic is exactly DESIGN.md section 4 (same transforms, FMA chains and rounding as the oracle), the data
+// path is the simple one of variant 1 -- block = (k + 1) groups of M/8 threads, group r owns accumulator
+// polynomial r -- with the accumulator and the digit spectra of the (k + 1) * L polynomials in a per-workgroup
+// GLOBAL scratch (L2-resident; N = 8192 needs 384 KB per ciphertext, more than the LDS) and only the transforms'
+// exchange buffers in LDS.  The 2_2 sets (k = 1, L = 1, N = 2048) never come here: they have variant 5.
+//   LDS: fbuf double2[k + 1][M] | at u32[n + 1]
+//   scratch per workgroup: acc u64[k + 1][N] | D double2[(k + 1) * L][M]
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(1024) void blind_rotate_gen_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride,
+    int n_small, int k, int L, int BL, const double2 *__restrict__ bsk_f, const uint64_t *__restrict__ lut_polys,
+    const double2 *__restrict__ twist, const double2 *__restrict__ tw, const double2 *__restrict__ psi,
+    unsigned char *__restrict__ scratch, size_t scratch_per_wg) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
+  constexpr int NB0 = FftPlan<LOGM>::NB_LAST;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int kp1 = k + 1;
+  double2 *fbuf = reinterpret_cast<double2 *>(smem_raw);                                  // [kp1][M]
+  uint32_t *at = reinterpret_cast<uint32_t *>(smem_raw + (size_t)kp1 * M * 16);           // [n + 1]
+  uint64_t *acc = reinterpret_cast<uint64_t *>(scratch + (size_t)blockIdx.x * scratch_per_wg);  // [kp1][N]
+  double2 *D = reinterpret_cast<double2 *>(acc + (size_t)kp1 * N);                        // [kp1 * L][M]
+
+  const int tid = threadIdx.x;
+  const int r = tid / TP;  // accumulator polynomial (and output column) of this thread
+  const int q = tid % TP;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  for (int j = tid; j <= n_small; j += blockDim.x)
+    at[j] = (uint32_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  __syncthreads();
+  {  // acc = (0, ..., 0, X^{-b~} * LUT)
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
+    for (int j = tid; j < kp1 * N; j += blockDim.x) {
+      const int pr = j / N, jj = j % N;
+      acc[j] = pr < k ? 0 : ((t == 0) ? lut[jj] : rot_read<N>(lut, t, jj));
+    }
+  }
+  __syncthreads();
+
+  uint64_t *acc_r = acc + (size_t)r * N;
+  double2 *buf_r = fbuf + (size_t)r * M;
+  const double scale = 1.0 / (double)M;
+  const int total = BL * L;
+  const uint64_t Bm1 = ((uint64_t)1 << BL) - 1, half = (uint64_t)1 << (BL - 1);
+
+  for (int i = 0; i < n_small; ++i) {
+    const int a = (int)at[i];
+    if (a == 0) continue;  // X^0 * acc - acc == 0: exact no-op (uniform branch)
+    // ---- digits of the rotated difference (closest representable, balanced digits taken LSB
+    //      first, level L-1 = least significant), one forward transform per level ----
+    uint64_t v0[8], v1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);
+      const uint64_t d0 = rot_read<N>(acc_r, a, p) - acc_r[p];
+      const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - acc_r[p + M];
+      v0[e] = (((d0 >> (64 - total - 1)) + 1) >> 1) & (((uint64_t)1 << total) - 1);
+      v1[e] = (((d1 >> (64 - total - 1)) + 1) >> 1) & (((uint64_t)1 << total) - 1);
+    }
+    for (int l = L - 1; l >= 0; --l) {
+      double2 x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int64_t g0 = (int64_t)(v0[e] & Bm1), g1 = (int64_t)(v1[e] & Bm1);
+        v0[e] >>= BL;
+        v1[e] >>= BL;
+        if ((uint64_t)g0 >= half) { g0 -= (int64_t)1 << BL; v0[e] += 1; }
+        if ((uint64_t)g1 >= half) { g1 -= (int64_t)1 << BL; v1[e] += 1; }
+        x[e] = make_double2((double)g0, (double)g1);
+      }
+      fft_forward<LOGM, LOGM>(x, q, buf_r, psi);  // ends with a barrier: this group's spectrum in buf_r
+      double2 *Dl = D + ((size_t)r * L + l) * M;
+      for (int m = q; m < M; m += TP) Dl[m] = buf_r[m];
+      __syncthreads();  // buf_r is re-used by the next level; D must be complete before the products
+    }
+    // ---- external product, output column r: sum over (row, level) in the oracle's order ----
+    const double2 *G = bsk_f + (size_t)i * L * kp1 * kp1 * M;  // [L][row][col][M]
+    double2 x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, 0, NB0>(q, e);
+      double re = 0, im = 0;
+      bool first = true;
+      for (int row = 0; row < kp1; ++row)
+        for (int l = 0; l < L; ++l) {
+          const double2 dd = D[((size_t)row * L + l) * M + p];
+          const double2 g = G[(((size_t)l * kp1 + row) * kp1 + r) * M + p];
+          if (first) {
+            re = dd.x * g.x;
+            im = dd.x * g.y;
+            first = false;
+          } else {
+            re = __builtin_fma(dd.x, g.x, re);
+            im = __builtin_fma(dd.x, g.y, im);
+          }
+          re = __builtin_fma(-dd.y, g.y, re);
+          im = __builtin_fma(dd.y, g.x, im);
+        }
+      x[e] = make_double2(re, im);
+    }
+    fft_inverse<LOGM, 0, NB0>(x, q, buf_r, tw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);
+      const double2 v = cmul_conj(x[e], twist[p]);
+      acc_r[p] += torus_from_f64(v.x * scale);
+      acc_r[p + M] += torus_from_f64(v.y * scale);
+    }
+    __syncthreads();  // every group's accumulator and buf are settled before the next rotation reads them
+  }
+
+  // ---- sample extract: a'_{r,0} = a_{r,0}, a'_{r,j} = -a_{r,N-j}, b' = b_0 ----
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+  for (int j = tid; j < k * N; j += blockDim.x) {
+    const int pr = j / N, jj = j % N;
+    out[j] = (jj == 0) ? acc[(size_t)pr * N] : (uint64_t)0 - acc[(size_t)pr * N + N - jj];
+  }
+  if (tid == 0) out[(size_t)k * N] = acc[(size_t)k * N];
+}
+
+// ------------------------------------------------------------------------------------------
 // Shared pieces of the throughput kernels (variant 5, multi-bit): 128 threads x 8 points per
 // polynomial, three register passes of 3 index bits + one lane-pair stage on index bit 0 (DPP),
 // XOR-swizzled LDS exchange buffers (conflict-free ds_read/write_b128 in every pass layout).

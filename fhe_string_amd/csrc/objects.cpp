@@ -462,21 +462,26 @@ int fhes_string_op(fhes_server_key *sk, const char *op_in, fhes_ct *const *args,
   }
   const char *op = op_name.c_str();
   // position-sharded path: every rank of the attached communicator makes this call
+  const std::string base_name = op_in;
+  const bool shard_split = base_name == "split" || base_name == "rsplit";
   if (sk->comm && fhes_comm_world(sk->comm) > 1 && n_args == 2 && args[0] && args[1] &&
-      (std::string(op_in) == "contains" || std::string(op_in) == "find")) {
+      (base_name == "contains" || base_name == "find" || shard_split)) {
     for (int i = 0; i < 2; i++) {
       if (args[i]->n_blocks % sk->nb_char) return fail(FHES_ERR_INVALID, "operand %d is not a string", i);
       int rc = ensure_device(sk, args[i]);
       if (rc) return rc;
     }
     int32_t h[32], n = 0;
-    int rc = fhes_sharded_search(sk->comm, op_in, args[0]->handle, args[0]->n_blocks / sk->nb_char, args[1]->handle,
-                                 args[1]->n_blocks / sk->nb_char, sk->nb_usize, h, 32, &n);
+    // the key's log-depth switch reaches the replicated scans of the sharded form too
+    int rc = fhes_sharded_op(sk->comm, op, args[0]->handle, args[0]->n_blocks / sk->nb_char, args[1]->handle,
+                             args[1]->n_blocks / sk->nb_char, sk->nb_usize, h, 32, &n);
     if (rc) return rc;
-    const int32_t n_parts = n == 1 ? 1 : 2;
+    const int32_t n_slices = args[0]->n_blocks / sk->nb_char + 1;
+    const int32_t n_parts = shard_split ? 3 : (n == 1 ? 1 : 2);
     if (n_parts > max_outs) return fail(FHES_ERR_INVALID, "need room for %d results", n_parts);
     const Dims d(sk->p);
-    const int32_t part_blocks[2] = {1, n - 1};
+    const int32_t part_blocks[3] = {shard_split ? n_slices : 1, shard_split ? n_slices * sk->nb_usize : n - 1,
+                                    shard_split ? n_slices * sk->nb_usize : 0};
     int32_t off = 0;
     for (int32_t k = 0; k < n_parts; k++) {
       auto *c = new fhes_ct;
@@ -484,7 +489,7 @@ int fhes_string_op(fhes_server_key *sk, const char *op_in, fhes_ct *const *args,
       c->ct_words = d.ct_words();
       c->ctx = sk->ctx;
       c->handle = h[0] + off;
-      c->degree.assign((size_t)c->n_blocks, c->n_blocks == 1 ? 1 : (uint8_t)(sk->msg_mod - 1));
+      c->degree.assign((size_t)c->n_blocks, (k == 0) ? 1 : (uint8_t)(sk->msg_mod - 1));  // part 0 is boolean in every layout
       c->noise.assign((size_t)c->n_blocks, 1);
       off += part_blocks[k];
       outs[k] = c;

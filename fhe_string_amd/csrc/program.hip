@@ -1,5 +1,7 @@
 // program.hip -- Level 1 of the C ABI: compiled circuits (host-side compile / export) and
 // their execution on the device engine, one keyswitch + blind-rotate launch pair per level.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -163,8 +165,9 @@ int fhes_program_export(const fhes_program *fp, int32_t *level_ptr, int32_t *ter
   memcpy(consts, fp->consts.data(), 8 * fp->consts.size());
   memcpy(lut_ids, fp->lut_ids.data(), 4 * fp->lut_ids.size());
   memcpy(out_idx, fp->out_idx.data(), 4 * fp->out_idx.size());
+  const int space = 1 << (fp->prog.params.message_bits + fp->prog.params.carry_bits);  // entries per table (16 for the 2_2 sets)
   for (size_t i = 0; i < fp->prog.luts.size(); i++)
-    for (int x = 0; x < 16; x++) lut_tables[i * 16 + x] = fp->prog.luts[i][x];
+    for (int x = 0; x < space; x++) lut_tables[i * (size_t)space + x] = fp->prog.luts[i][x];
   for (size_t i = 0; i < fp->prog.out_slots.size(); i++) {
     out_slots[i] = fp->prog.out_slots[i];
     if (out_trivial) out_trivial[i] = 0;
@@ -202,8 +205,8 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
     std::vector<int32_t> luts(fp->lut_ids.size());
     std::vector<int32_t> local2ctx(p.luts.size());
     for (size_t i = 0; i < p.luts.size(); i++) {
-      uint64_t t[16];
-      for (int x = 0; x < 16; x++) t[x] = p.luts[i][x];
+      uint64_t t[circ::kMaxSpace];
+      for (int x = 0; x < circ::kMaxSpace; x++) t[x] = p.luts[i][x];
       const int32_t id = lut_register_locked(ctx, t, ctx->dims.space());
       if (id < 0) return id;
       local2ctx[i] = id;
@@ -317,8 +320,15 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
       FHES_HIP(hipMemcpyAsync(lane.slot_map, map.data(), 4 * map.size(), hipMemcpyHostToDevice, lane.stream));
       FHES_HIP(hipStreamSynchronize(lane.stream));  // `map` is a stack object
       int r = FHES_OK;
-      for (int lv = 0; lv < fp->n_pbs_levels && r == FHES_OK; lv++)
+      // per-level trace, the engine's form of the reference's `log::trace!` per loop index (search.rs:37, mod.rs:342,
+      // split.rs:277; enabled there by RUST_LOG=trace): FHES_LOG=trace prints one line per level as it is queued
+      static const bool trace = [] { const char *e = getenv("FHES_LOG"); return e && std::string(e) == "trace"; }();
+      for (int lv = 0; lv < fp->n_pbs_levels && r == FHES_OK; lv++) {
+        if (trace)
+          fprintf(stderr, "[fhes trace] %s: level %d/%d, %d bootstraps x %d instance(s), lane %s\n", p.name.c_str(), lv + 1,
+                  fp->n_pbs_levels, p.level_ptr[lv + 1] - p.level_ptr[lv], n_inst, lane.is_main ? "main" : "side");
         r = launch_pbs(ctx, lane, arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv], n_inst, &cnt);
+      }
       if (r == FHES_OK && fp->has_linear_level) {
         const int lv = fp->n_pbs_levels;
         r = launch_linear(ctx, lane, arrays, p.level_ptr[lv], p.level_ptr[lv + 1] - p.level_ptr[lv], n_inst, &cnt);

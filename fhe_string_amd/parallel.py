@@ -110,6 +110,78 @@ class Comm:
         check(_lib.load().fhes_sharded_search(self._h, op.encode(), a_first, a_slots, p_first, p_slots, bu, out, 32, C.byref(n)))
         return [int(out[i]) for i in range(n.value)]
 
+    def sharded_op(self, op, a_first, a_slots, p_first, p_slots, bu):
+        """fhes_sharded_op: contains / find / rfind_last -> output handles; split / rsplit -> the first handles of
+        is_some[n], start[n][Bu], end[n][Bu] (n = a_slots + 1, one contiguous range of n * (1 + 2 * Bu) rows)"""
+        out = (C.c_int32 * 32)()
+        n = C.c_int32()
+        check(_lib.load().fhes_sharded_op(self._h, op.encode(), a_first, a_slots, p_first, p_slots, bu, out, 32, C.byref(n)))
+        return [int(out[i]) for i in range(n.value)]
+
+    @staticmethod
+    def host_exec(params, executor, dist=None, rank=None, world=None):
+        """fhes_comm_create_host_exec: the shipped planner over an executor that keeps ciphertext rows in host memory
+        (`executor`: .row_words, .alloc(n), .release(first, n), .rows_address(first), .run(program_handle, ins, outs))"""
+        import torch
+        rank = dist.get_rank() if dist else (rank or 0)
+        world = dist.get_world_size() if dist else (world or 1)
+
+        def all_gather(_user, send, recv, nbytes):
+            try:
+                src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+                t = torch.from_numpy(src.copy())
+                bufs = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(bufs, t)
+                for r, b in enumerate(bufs):
+                    dst[r * nbytes:(r + 1) * nbytes] = b.numpy()
+                return 0
+            except Exception:
+                return -1
+
+        def bcast(_user, buf, nbytes, root):
+            try:
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                t = torch.from_numpy(a.copy())
+                dist.broadcast(t, src=root)
+                a[:] = t.numpy()
+                return 0
+            except Exception:
+                return -1
+
+        def x_alloc(_u, n):
+            try:
+                return int(executor.alloc(n))
+            except Exception:
+                return -1
+
+        def x_release(_u, first, n):
+            try:
+                executor.release(first, n)
+                return 0
+            except Exception:
+                return -1
+
+        def x_rows(_u, first):
+            return executor.rows_address(first)
+
+        def x_run(_u, prog, ins, outs):
+            try:
+                return int(executor.run(prog, ins, outs))
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        ag, bc = _lib.ALLGATHER_FN(all_gather), _lib.BCAST_FN(bcast)
+        ex = _lib.Executor()
+        cbs = (_lib.EXEC_ALLOC_FN(x_alloc), _lib.EXEC_RELEASE_FN(x_release), _lib.EXEC_ROWS_FN(x_rows), _lib.EXEC_RUN_FN(x_run))
+        ex.user, ex.row_words = None, executor.row_words
+        ex.alloc, ex.release, ex.rows, ex.run = cbs
+        h = check_ptr(_lib.load().fhes_comm_create_host_exec(C.byref(params), rank, world, ag if dist else None, bc if dist else None,
+                                                             None, C.byref(ex)))
+        return Comm(h, keep=(ag, bc, cbs, ex))
+
     def close(self):
         if self._h:
             _lib.load().fhes_comm_destroy(self._h)

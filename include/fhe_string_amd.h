@@ -227,7 +227,7 @@ int32_t fhes_program_scratch_cells(const fhes_program *prog);
  * Slot numbering: inputs are slots [0,n_inputs); node j writes slot out_idx[j]. */
 int fhes_program_export(const fhes_program *prog, int32_t *level_ptr, int32_t *term_ptr,
                         int32_t *term_idx, int64_t *term_coef, uint64_t *consts,
-                        int32_t *lut_ids, int32_t *out_idx, uint64_t *lut_tables /*[n_luts][16]*/,
+                        int32_t *lut_ids, int32_t *out_idx, uint64_t *lut_tables /*[n_luts][2^(message_bits+carry_bits)]: 16 entries per table for the 2_2 sets*/,
                         int32_t *out_slots /*[n_outputs], -1 = trivial*/,
                         uint64_t *out_trivial /*[n_outputs] message value if trivial*/);
 /* Run on the device: inputs are arena handles (n_inputs), outputs are freshly
@@ -355,16 +355,45 @@ int fhes_comm_broadcast_cts(fhes_comm *comm, int32_t first, int32_t count, int32
 /* Broadcast of the device-resident server keys (keyswitch key + bias, Fourier BSK in both layouts)
  * from `root`; the other ranks need not have called fhes_upload_keys. */
 int fhes_comm_broadcast_keys(fhes_comm *comm, int32_t root);
-/* Position-sharded search.  op: "contains" (search.rs:17-20) -> 1 block, "find" (search.rs:23-28) ->
- * 1 + num_blocks_usize blocks, "rfind_last" (the reverse scan of search.rs:155-159).  a / p are arena
- * handles of the string (a_slots chars incl. terminator / padding) and the pattern, identical on every
- * rank (fhes_comm_broadcast_cts).  Collective; out_handles (freshly allocated, one contiguous range)
- * hold identical ciphertexts on every rank, bit-identical to the unsharded program. */
+/* Position-sharded operations on ONE string.  a / p are handles of the string (a_slots chars incl. terminator /
+ * padding) and the pattern, identical on every rank (fhes_comm_broadcast_cts).  Collective: every rank makes the
+ * same call; the results (freshly allocated, one contiguous range) are identical ciphertexts on every rank.
+ *   "find" (search.rs:23-28) -> out[0..1+Bu) = is_some, index; "rfind_last" (the reverse scan of search.rs:155-159):
+ *       rank g evaluates substr_eq for its block of start positions (search.rs:33-41), ONE all-gather of the
+ *       per-position BooleanBlocks, the first-match scan replicated (bit-identical to the unsharded program);
+ *   "contains" (search.rs:17-20) -> 1 block: `any` of the local block, ONE all-reduce (ncclUint64 / ncclSum: LWE
+ *       addition is wrapping u64 addition) of that single boolean, final lookup [sum > 0]  (world <= 15; else as find);
+ *   "split" / "rsplit" (split.rs:238-333) -> out[0..3) = first handles of is_some[n], start[n][Bu], end[n][Bu],
+ *       n = a_slots + 1: found[] as above, the non-overlapping matches replicated, then the O(n^2) grid
+ *       `element_at_bool(matches, i - len(p))` (mod.rs:271-287 per index at split.rs:283-285) partitioned by OUTPUT
+ *       index i with one all-gather of the booleans, the carried next_match chain replicated.
+ * An "<op>_logdepth" name selects the parallel-prefix forms of the replicated scans.  A rank that fails locally
+ * still enters every collective, and a closing status exchange makes EVERY rank return an error (nobody hangs,
+ * nobody keeps a void result). */
+int fhes_sharded_op(fhes_comm *comm, const char *op, int32_t a_first, int32_t a_slots, int32_t p_first,
+                    int32_t p_slots, int32_t num_blocks_usize, int32_t *out_handles, int32_t max_out,
+                    int32_t *n_out);
+/* the search subset of fhes_sharded_op under its round-1 name */
 int fhes_sharded_search(fhes_comm *comm, const char *op, int32_t a_first, int32_t a_slots, int32_t p_first,
                         int32_t p_slots, int32_t num_blocks_usize, int32_t *out_handles, int32_t max_out,
                         int32_t *n_out);
-/* Level 2: with a communicator attached, `contains` and `find` of fhes_string_op run position-sharded
- * over its ranks (every rank makes the same call with the same operands).  NULL detaches. */
+/* Executor hook: the SAME planner (fhes_sharded_op) over ciphertext rows that live in host memory and programs run
+ * by the caller -- a CPU implementation, another device, a test double.  tests/test_parallel_gloo.py runs the
+ * shipped planner this way with the CPU oracle as the executor, two ranks over gloo.  Handles are the executor's
+ * own row numbers; rows are `row_words` u64 apart and contiguous in handle order. */
+typedef struct fhes_executor {
+  void *user;
+  int64_t row_words;                                             /* >= fhes_ct_words(params) */
+  int32_t (*alloc)(void *user, int32_t count);                   /* first handle of `count` fresh rows, < 0 on failure */
+  int (*release)(void *user, int32_t first, int32_t count);
+  uint64_t *(*rows)(void *user, int32_t first);                  /* host address of row `first` */
+  int (*run)(void *user, const fhes_program *prog, const int32_t *in_handles, int32_t *out_handles); /* 0 = ok; allocates the outputs contiguously */
+} fhes_executor;
+fhes_comm *fhes_comm_create_host_exec(const fhes_params *p, int32_t rank, int32_t world, fhes_allgather_fn all_gather,
+                                      fhes_bcast_fn broadcast, void *user, const fhes_executor *exec);
+/* Level 2: with a communicator attached, `contains`, `find`, `split` and `rsplit` of fhes_string_op run
+ * position-sharded over its ranks (every rank makes the same call with the same operands).  NULL detaches; detach
+ * before the communicator is destroyed. */
 int fhes_server_key_set_comm(fhes_server_key *sk, fhes_comm *comm);
 
 #ifdef __cplusplus

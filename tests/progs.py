@@ -9,11 +9,12 @@ from tests.helpers import ptr
 
 
 class Prog:
-    def __init__(self, params, op, shape, bu):
+    def __init__(self, params, op, shape, bu, handle=None):
         self.lib = _lib.load(strict=False)
         self.params, self.op, self.shape, self.bu = params, op, list(shape), bu
         sh = np.array(shape, dtype=np.int32)
-        self.h = check_ptr(self.lib.fhes_program_compile(C.byref(params), op.encode(), ptr(sh), len(shape), bu))
+        self._owned = handle is None
+        self.h = check_ptr(self.lib.fhes_program_compile(C.byref(params), op.encode(), ptr(sh), len(shape), bu)) if handle is None else handle
         info = (C.c_int64 * 8)()
         check(self.lib.fhes_program_info(self.h, info))
         (self.n_inputs, self.n_outputs, self.n_nodes, self.n_levels, self.n_terms, self.n_luts,
@@ -25,7 +26,8 @@ class Prog:
         self.consts = np.zeros(max(self.n_nodes, 1), dtype=np.uint64)
         self.lut_ids = np.zeros(max(self.n_nodes, 1), dtype=np.int32)
         self.out_idx = np.zeros(max(self.n_nodes, 1), dtype=np.int32)
-        self.lut_tables = np.zeros((max(self.n_luts, 1), 16), dtype=np.uint64)
+        self.space = 1 << (params.message_bits + params.carry_bits)     # entries per lookup table
+        self.lut_tables = np.zeros((max(self.n_luts, 1), self.space), dtype=np.uint64)
         self.out_slots = np.zeros(max(self.n_outputs, 1), dtype=np.int32)
         check(self.lib.fhes_program_export(self.h, ptr(self.level_ptr), ptr(self.term_ptr), ptr(self.term_idx),
                                            ptr(self.term_coef), ptr(self.consts), ptr(self.lut_ids),
@@ -34,9 +36,15 @@ class Prog:
         n = self.lib.fhes_program_out_parts(self.h, parts, 16)
         self.out_parts = [int(parts[i]) for i in range(max(n, 0))]
 
+    @classmethod
+    def from_handle(cls, params, handle):
+        """view of a program somebody else compiled and owns (the executor hook of fhes_sharded_op receives these)"""
+        return cls(params, "?", [], 0, handle=handle)
+
     def __del__(self):
         try:
-            self.lib.fhes_program_destroy(self.h)
+            if self._owned:
+                self.lib.fhes_program_destroy(self.h)
         except Exception:
             pass
 
