@@ -2,29 +2,53 @@
 #include "builder.h"
 
 #include <algorithm>
+#include <cmath>
 #include <stdexcept>
 
 namespace fhes {
 namespace circ {
 
-// Noise cap of a lookup input in units of one bootstrap output.  The variance of a
-// bootstrap output is dominated by the rounding of the one-level decomposition, 2^(2(63-B))/3 per
-// coefficient times (1 + kN/2) per CMUX times n CMUX -- 2^49 for B = 23, n = 742, which is what the oracle
-// measures -- so the cap scales with 4^(B-23) from the values fixed for the 2^23 sets (256 classic, 34
-// multi-bit).  A set whose cap cannot even hold the packed comparison of four fresh blocks (34 units) has
-// no room to combine bootstrapped blocks at all: its circuits are refused (Level 0 still serves it).
+// Noise cap of a lookup input in units of one bootstrap output.
+//   * the 2_2 sets of this engine (k = 1, one level, N = 2048 / 256): the variance of a bootstrap output is
+//     dominated by the rounding of the one-level decomposition, 2^(2(63-B))/3 per coefficient times (1 + kN/2) per
+//     CMUX times n CMUX -- 2^49 for B = 23, n = 742, which is what the oracle measures -- so the cap scales with
+//     4^(B-23) from the values fixed for the 2^23 sets (256 classic, 34 multi-bit);
+//   * every other classic shape (round 3): the same budget from the parameters themselves.  With q = 2^64,
+//       var_f  = n * [ (1 + kN/2) * 2^(2(64 - L*B)) / 12  +  (k+1) L N * (2^(2B) / 12) * (sigma_glwe q)^2 ]   one bootstrap output
+//       var_ms = (1 + n/2) * (q / 2N)^2 / 12                                                                  modulus switch
+//       var_ks = kN * l_ks * (2^(2 B_ks) / 12) * (sigma_lwe q)^2 + (kN/2) * 2^(2(64 - l_ks B_ks)) / 12        keyswitch
+//     a lookup input of c units decodes correctly while  sqrt(c var_f + var_ms + var_ks) <= margin / 7.1,
+//     margin = 2^(62 - message_bits - carry_bits): 7.1 sigma is what the fixed 256 gives the default set.
+// A set whose cap cannot even hold the packed comparison of four fresh blocks (2 (1 + M^2) units, 34 for M = 4)
+// has no room to combine bootstrapped blocks at all: its circuits are refused (Level 0 still serves it).
 static double noise_cap_of(const fhes_params &p) {
-  double cap = p.grouping_factor > 1 ? 34.0 : 256.0;
-  for (int b = p.pbs_base_log; b < 23; b++) cap /= 4.0;
-  return cap;
+  const bool engine_2_2 = p.glwe_dim == 1 && p.pbs_level == 1 && (p.poly_size == 2048 || p.poly_size == 256);
+  if (engine_2_2) {
+    double cap = p.grouping_factor > 1 ? 34.0 : 256.0;
+    for (int b = p.pbs_base_log; b < 23; b++) cap /= 4.0;
+    return cap;
+  }
+  const double q = 0x1p64, n = p.lwe_dim, k = p.glwe_dim, N = p.poly_size, L = p.pbs_level, B = p.pbs_base_log;
+  const double var_f = n * ((1.0 + k * N / 2.0) * std::ldexp(1.0, 2 * (64 - p.pbs_level * p.pbs_base_log)) / 12.0 +
+                            (k + 1.0) * L * N * (std::ldexp(1.0, 2 * p.pbs_base_log) / 12.0) * (p.glwe_noise_std * q) * (p.glwe_noise_std * q));
+  const double var_ms = (1.0 + n / 2.0) * (q / (2.0 * N)) * (q / (2.0 * N)) / 12.0;
+  const double var_ks = k * N * p.ks_level * (std::ldexp(1.0, 2 * p.ks_base_log) / 12.0) * (p.lwe_noise_std * q) * (p.lwe_noise_std * q) +
+                        (k * N / 2.0) * std::ldexp(1.0, 2 * (64 - p.ks_level * p.ks_base_log)) / 12.0;
+  const double margin = std::ldexp(1.0, 62 - p.message_bits - p.carry_bits);
+  const double room = (margin / 7.1) * (margin / 7.1) - var_ms - var_ks;
+  (void)B;
+  if (room <= 0) return 0.0;
+  return std::min(256.0, room / var_f);
 }
 
 Builder::Builder(const fhes_params &p, int32_t n_inputs)
     : p_(p), n_inputs_(n_inputs), noise_cap_(noise_cap_of(p)) {
-  if (noise_cap_ < 34.0)
-    throw std::invalid_argument("this parameter set's bootstrap noise (one decomposition level of base 2^" + std::to_string(p.pbs_base_log) +
-                                ") leaves no room to combine bootstrapped blocks before the next lookup: the compiled circuits "
-                                "(Level 1 / Level 2) need pbs_base_log >= 23; fhes_pbs_batch (Level 0) still runs it");
+  const double need = 2.0 * (1.0 + (double)msg_mod() * msg_mod() * msg_mod() * msg_mod() / (double)(msg_mod() * msg_mod()));  // 2 (1 + M^2)
+  if (noise_cap_ < need)
+    throw std::invalid_argument("this parameter set's bootstrap noise (" + std::to_string(p.pbs_level) + " decomposition level(s) of base 2^" +
+                                std::to_string(p.pbs_base_log) + ": a lookup input may carry " + std::to_string((int)noise_cap_) + " bootstrap-output units, the packed "
+                                "comparison of four fresh blocks needs " + std::to_string((int)need) + ") leaves no room to combine bootstrapped blocks before the "
+                                "next lookup: the compiled circuits (Level 1 / Level 2) refuse it; fhes_pbs_batch (Level 0) still runs it");
 }
 
 Blk Builder::input(int32_t i, uint32_t deg) const {

@@ -38,6 +38,20 @@ def effective_cores():
     return n
 
 
+# Parameter shapes beyond the 2_2 family (`generate_keys_with_params` takes ANY ClassicPBSParameters,
+# /root/reference/src/lib.rs:50-62): message / carry widths, glwe_dim, poly_size and decomposition of
+# PARAM_MESSAGE_1_CARRY_1_KS_PBS and PARAM_MESSAGE_3_CARRY_3_KS_PBS as recalled from tfhe-rs 0.5 (k = 3, N = 512,
+# one level / k = 1, N = 8192, two levels of base 2^15), and two more corners of the generic kernel.  TEST sizes: a
+# short LWE key (n = 48) and the toy set's tiny noise, so that the oracle finishes in seconds; not secure.
+SHAPES = {
+    "shape_1_1": dict(message_bits=1, carry_bits=1, glwe_dim=3, poly_size=512, pbs_level=1, pbs_base_log=18, lwe_dim=48, ks_level=4, ks_base_log=3),
+    "shape_3_3": dict(message_bits=3, carry_bits=3, glwe_dim=1, poly_size=8192, pbs_level=2, pbs_base_log=15, lwe_dim=48, ks_level=6, ks_base_log=3),
+    "shape_k2_l2": dict(message_bits=2, carry_bits=2, glwe_dim=2, poly_size=1024, pbs_level=2, pbs_base_log=12, lwe_dim=48),
+    "shape_n4096": dict(message_bits=2, carry_bits=3, glwe_dim=1, poly_size=4096, pbs_level=1, pbs_base_log=22, lwe_dim=48),
+    "shape_l3": dict(message_bits=2, carry_bits=2, glwe_dim=1, poly_size=2048, pbs_level=3, pbs_base_log=9, lwe_dim=48),
+}
+
+
 class World:
     """One key set (client key + standard-domain server keys) plus an oracle context."""
 
@@ -47,7 +61,11 @@ class World:
         self.p = Params()
         b18 = which.endswith("_b18")                     # same set with the one-level decomposition base 2^18
         which = which[:-4] if b18 else which
-        if which[-1] in "23" and "multibit" in which:   # "multibit2", "toy_multibit3", ...
+        if which in SHAPES:                              # parameter SHAPES other than 2_2 (tests/helpers.SHAPES)
+            check(self.lib.fhes_params_toy(C.byref(self.p)))
+            for k, v in SHAPES[which].items():
+                setattr(self.p, k, v)
+        elif which[-1] in "23" and "multibit" in which:   # "multibit2", "toy_multibit3", ...
             check(getattr(self.lib, "fhes_params_" + which[:-1])(C.byref(self.p), int(which[-1])))
         else:
             check(getattr(self.lib, "fhes_params_" + which)(C.byref(self.p)))
