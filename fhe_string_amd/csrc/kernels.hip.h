@@ -648,7 +648,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
 //   scratch per workgroup: acc u64[k + 1][N] | D double2[(k + 1) * L][M]
 // ------------------------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(1024) void blind_rotate_gen_kernel(
+__global__ __launch_bounds__(((4 << LOGN) / 16) > 1024 ? 1024 : ((4 << LOGN) / 16)) void blind_rotate_gen_kernel(  // (k + 1) <= 4 groups of N / 16 threads
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride,
     int n_small, int k, int L, int BL, const double2 *__restrict__ bsk_f, const uint64_t *__restrict__ lut_polys,
     const double2 *__restrict__ twist, const double2 *__restrict__ tw, const double2 *__restrict__ psi,
