@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfhe_string_amd.so")
+# FHES_LIB: developer knob -- another build of the same library (compiler-flag A/B runs, scripts/flag_ab.sh)
+LIB_PATH = os.environ.get("FHES_LIB") or os.path.join(_HERE, "libfhe_string_amd.so")
 
 
 class Params(C.Structure):
