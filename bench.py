@@ -428,10 +428,10 @@ def main():
             s3 = "".join(c3)
             cases = [sharded_case("config 2: find, 64-char input / 4-char pattern", "find", text, None, pat, 4, 3),
                      sharded_case("config 4: contains, 1000 chars padded to 1024 / 8-char pattern", "contains", s4, 1024, s4[700:708], 6, 2),
-                     sharded_case("config 3: split, 256-char input / 1-char separator (log-depth scans; the element_at_bool grid sharded by output index)",
+                     sharded_case("config 3: split, 256-char input / 1-char separator (log-depth forms: find_all sharded, the scans and the barrel shifter replicated)",
                                   "split_logdepth", s3, None, ",", 5, 2)]
             if os.environ.get("FHES_BENCH_SHARDED_FAITHFUL_SPLIT") == "1":   # ~8 s per repetition: thousands of dependent levels
-                cases.append(sharded_case("config 3: split, faithful serial scans", "split", s3, None, ",", 5, 1))
+                cases.append(sharded_case("config 3: split, faithful circuits (find_all AND the element_at_bool grid sharded; serial scans replicated)", "split", s3, None, ",", 5, 1))
             sharded = {"world": world_size, "transport": "host callbacks over gloo (rehearsal)" if (dist and rehearsal) else "RCCL (ncclAllGather on arena rows)",
                        "key_broadcast_ms": round(keys_ms, 2), "cases": cases,
                        "note": "one operation on ONE string through the C ABI (fhes_sharded_op): find_all positions sharded over the ranks (all-gather of the "

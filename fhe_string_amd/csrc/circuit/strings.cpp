@@ -1150,7 +1150,7 @@ const char *op_signature(const std::string &op_full) {
     if (op == e.name) return e.sig;
   if (op == "find_all_range") return "SSII";
   // stages of the position-sharded split (csrc/comm.hip): L = one BooleanBlock per element, one object
-  if (op == "split_head" || op == "rsplit_head") return "SSL";
+  if (op == "split_head" || op == "rsplit_head" || op == "split_rest" || op == "rsplit_rest") return "SSL";
   if (op == "split_is_some_range") return "LUUII";
   if (op == "split_tail" || op == "rsplit_tail") return "LLUUB";
   if (op == "any_of" || op == "index_of" || op == "rindex_of" || op == "sum_gt_zero") return "I";
@@ -1212,6 +1212,33 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
     out.push_back(h.pattern_empty);
     Program prog = b.finish(out, op_full);
     prog.out_parts = {(int32_t)h.matches.size(), Bu, Bu, 1};
+    return prog;
+  }
+  if (op == "split_rest" || op == "rsplit_rest") {  // shape {slots_a, slots_p}: a, p, found[slots_a - 1] -> the slices
+    // everything of split_opt behind find_all in ONE replicated program: what the sharded form runs when the log-depth
+    // forms are selected -- their barrel shifter (S::split_tail) is cheaper than the O(n^2) grid even when that is
+    // divided by the number of ranks, and it does not partition by output index
+    if (shape.size() != 2 || shape[0] < 1 || shape[1] < 1) throw std::invalid_argument(op + " needs {slots_a, slots_p}");
+    const int n_found = shape[0] - 1;
+    Builder b(p, (shape[0] + shape[1]) * Bc + n_found);
+    Ops o(b);
+    S s{o, Bc, Bu, fast};
+    Str sa, sb;
+    int32_t next = 0;
+    for (int c = 0; c < shape[0]; c++) { Radix ch; for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1)); sa.push_back(ch); }
+    for (int c = 0; c < shape[1]; c++) { Radix ch; for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1)); sb.push_back(ch); }
+    std::vector<Blk> found;
+    for (int i = 0; i < n_found; i++) found.push_back(b.input(next++, 1));
+    S::SplitHead h = s.split_head(sa, sb, op == "rsplit_rest", &found);
+    std::vector<S::Slice> v = s.split_tail(h.matches, h.p_len, h.self_len, h.pattern_empty, (size_t)shape[0] + 1, false, nullptr);
+    if (op == "rsplit_rest") std::reverse(v.begin(), v.end());
+    std::vector<Blk> out;
+    for (auto &e : v) out.push_back(e.is_some);
+    for (auto &e : v) push_all(out, e.start);
+    for (auto &e : v) push_all(out, e.end);
+    Program prog = b.finish(out, op_full);
+    const int n = (int)v.size();
+    prog.out_parts = {n, n * Bu, n * Bu};
     return prog;
   }
   if (op == "split_is_some_range") {  // shape {n, lo, hi}: matches[n], len(p), len(a) -> is_some[lo, hi)

@@ -451,6 +451,12 @@ int fhes_sharded_op(fhes_comm *c, const char *op_in, int32_t a_first, int32_t a_
     for (int64_t i = 0; i < n_pos; i++) found[(size_t)i] = G + (int32_t)i;
     if (!is_split) {
       run_prog(reduce, {(int32_t)n_pos}, found, result);   // replicated: deterministic, identical on every rank
+    } else if (!suffix.empty()) {
+      // log-depth forms: everything behind find_all in one replicated program -- the barrel shifter that replaces the
+      // per-index gathers is cheaper than the grid divided by the ranks and does not partition by index
+      std::vector<int32_t> in2(ab);
+      in2.insert(in2.end(), found.begin(), found.end());
+      run_prog(o == "split" ? "split_rest" : "rsplit_rest", {a_slots, p_slots}, in2, result);
     } else {
       // ---- split / rsplit (split.rs:238-333) ----
       // stage 2 (replicated): non-overlapping matches, len(p), len(self), pattern_empty

@@ -367,7 +367,9 @@ int fhes_comm_broadcast_keys(fhes_comm *comm, int32_t root);
  *       n = a_slots + 1: found[] as above, the non-overlapping matches replicated, then the O(n^2) grid
  *       `element_at_bool(matches, i - len(p))` (mod.rs:271-287 per index at split.rs:283-285) partitioned by OUTPUT
  *       index i with one all-gather of the booleans, the carried next_match chain replicated.
- * An "<op>_logdepth" name selects the parallel-prefix forms of the replicated scans.  A rank that fails locally
+ * An "<op>_logdepth" name selects the parallel-prefix forms of the replicated scans; for split / rsplit everything behind
+ * find_all then runs as ONE replicated program (the barrel shifter that replaces the per-index gathers is cheaper than the
+ * grid divided by the ranks).  A rank that fails locally
  * still enters every collective, and a closing status exchange makes EVERY rank return an error (nobody hangs,
  * nobody keeps a void result). */
 int fhes_sharded_op(fhes_comm *comm, const char *op, int32_t a_first, int32_t a_slots, int32_t p_first,
