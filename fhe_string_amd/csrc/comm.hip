@@ -159,7 +159,7 @@ struct X {
     FHES_HIP(hipSetDevice(ctx->device));
     FHES_HIP(hipMemcpyAsync(ctx->arena + (size_t)dst * ctx->ct_stride, ctx->arena + (size_t)src * ctx->ct_stride,
                             (size_t)n * row_bytes(), hipMemcpyDeviceToDevice, ctx->stream));
-    return FHES_OK;
+    return main_pending_push_locked(ctx, dst, dst + n, 0, 0);  // queued on the main stream: other lanes order behind it
   }
   int zero_rows(int32_t first, int32_t n) {  // all-zero words = the trivial encryption of 0
     if (n <= 0) return FHES_OK;
@@ -168,7 +168,7 @@ struct X {
     std::lock_guard<std::mutex> lk(ctx->mu);
     FHES_HIP(hipSetDevice(ctx->device));
     FHES_HIP(hipMemsetAsync(ctx->arena + (size_t)first * ctx->ct_stride, 0, (size_t)n * row_bytes(), ctx->stream));
-    return FHES_OK;
+    return main_pending_push_locked(ctx, first, first + n, 0, 0);
   }
   int all_gather_rows(int32_t first, int32_t per_rank) {  // in place: rank r owns rows [first + r * per_rank, ...)
     if (c->world == 1 || per_rank <= 0) return FHES_OK;
@@ -186,7 +186,8 @@ struct X {
       fhes_ctx *ctx = c->ctx;
       std::lock_guard<std::mutex> lk(ctx->mu);
       FHES_HIP(hipSetDevice(ctx->device));
-      return dev_all_reduce_sum(c, ctx->arena + (size_t)first * ctx->ct_stride, (size_t)n * row_bytes());
+      const int rc = dev_all_reduce_sum(c, ctx->arena + (size_t)first * ctx->ct_stride, (size_t)n * row_bytes());
+      return rc ? rc : main_pending_push_locked(ctx, first, first + n, 0, 0);
     }
     const size_t words = (size_t)n * row_bytes() / 8;
     uint64_t *rows = c->exec.rows(c->exec.user, first);
@@ -302,7 +303,8 @@ int fhes_comm_all_gather_cts(fhes_comm *c, int32_t first, int32_t count) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   if ((int64_t)first + (int64_t)count * c->world > ctx->capacity) return fail(FHES_ERR_INVALID, "all_gather_cts: range outside the arena");
   FHES_HIP(hipSetDevice(ctx->device));
-  return dev_all_gather(c, ctx->arena + (size_t)first * ctx->ct_stride, (size_t)count * ctx->ct_stride * 8);
+  const int rc = dev_all_gather(c, ctx->arena + (size_t)first * ctx->ct_stride, (size_t)count * ctx->ct_stride * 8);
+  return rc ? rc : main_pending_push_locked(ctx, first, first + count * c->world, 0, 0);
 }
 
 int fhes_comm_broadcast_cts(fhes_comm *c, int32_t first, int32_t count, int32_t root) {
@@ -311,7 +313,8 @@ int fhes_comm_broadcast_cts(fhes_comm *c, int32_t first, int32_t count, int32_t 
   std::lock_guard<std::mutex> lk(ctx->mu);
   if ((int64_t)first + count > ctx->capacity) return fail(FHES_ERR_INVALID, "broadcast_cts: range outside the arena");
   FHES_HIP(hipSetDevice(ctx->device));
-  return dev_broadcast(c, ctx->arena + (size_t)first * ctx->ct_stride, (size_t)count * ctx->ct_stride * 8, root);
+  const int rc = dev_broadcast(c, ctx->arena + (size_t)first * ctx->ct_stride, (size_t)count * ctx->ct_stride * 8, root);
+  return rc ? rc : main_pending_push_locked(ctx, first, first + count, 0, 0);
 }
 
 int fhes_comm_broadcast_keys(fhes_comm *c, int32_t root) {

@@ -34,6 +34,10 @@ struct Lane {
   size_t slot_map_cap = 0;
   bool is_main = false;
   bool busy = false;            // side lanes: taken by a running call (guarded by fhes_ctx::mu)
+  // buffers this lane has outgrown: hipFree waits for the whole DEVICE, i.e. for every other lane's running work, so a
+  // side lane parks them here until the context goes away (the main lane, a single caller's, frees at once)
+  std::vector<void *> retired;
+  void drop(void *p) { if (!p) return; if (is_main) (void)hipFree(p); else retired.push_back(p); }
 };
 struct RunCounters {            // what one call adds to fhes_stats (merged under fhes_ctx::mu)
   uint64_t pbs = 0, launches = 0, linear = 0;
@@ -58,10 +62,17 @@ struct fhes_ctx {
   fhes::Lane main;                                 // wraps `stream` and the scratch pointers below
   std::vector<std::unique_ptr<fhes::Lane>> side;   // created on demand, at most kMaxSideLanes
   static constexpr int kMaxSideLanes = 15;         // main + 15 = the 16 hardware queues the library asks for (engine.hip, runtime_defaults)
-  hipEvent_t main_done_ev = nullptr;               // recorded on the main stream whenever a call hands the main lane back: "every
-                                                   // COMPLETED call's work" -- what a side lane has to wait for, since only a returned
-                                                   // call can have given anybody a handle (a call still queueing on the main lane is not
-                                                   // waited for: that would put the side lanes behind it)
+  // Work queued on the main stream by calls that have RETURNED (the main lane is asynchronous) and may still be
+  // running: the arena rows it writes (results) and reads or re-uses (scratch, handed back "stream-ordered" at return),
+  // with an event behind it.  A side lane waits for exactly those entries that overlap its own inputs or the rows it was
+  // just given -- not for a call that merely shares the context (that would put the lanes behind each other).
+  // `lo/hi[1]` (scratch) is handed back to the free list only when the event has completed: a range freed "stream-ordered"
+  // at return would be given to another lane while the kernels of this call still use it.
+  struct MainPending { int32_t lo[2], hi[2]; hipEvent_t ev; bool free_second; };
+  std::vector<MainPending> main_pending;
+  std::vector<hipEvent_t> pending_ev_free;
+  bool main_untracked = false;                     // a Level-0 call queued work on the main lane: its rows are unknown
+  int active_runs = 0;                             // program runs between set-up and clean-up (guarded by mu)
   bool main_held = false;                          // a call is queueing launches on the main lane
   std::thread::id main_user{};                     // the thread whose work the main stream last received
 
@@ -141,6 +152,9 @@ void acquire_main_locked(fhes_ctx *ctx, std::unique_lock<std::mutex> &lk);
 int acquire_lane_locked(fhes_ctx *ctx, std::unique_lock<std::mutex> &lk, Lane **out);
 void release_lane_locked(fhes_ctx *ctx, Lane *lane);
 int ensure_slot_map(Lane &lane, size_t entries);
+// main-lane bookkeeping (see fhes_ctx::main_pending); ranges are [lo, hi) pairs, an empty pair is lo == hi
+int main_pending_push_locked(fhes_ctx *ctx, int32_t lo0, int32_t hi0, int32_t lo1, int32_t hi1, bool free_second = false);
+void main_pending_prune_locked(fhes_ctx *ctx);
 struct MainLaneHold {  // Level-0 entry points: hold mu for the whole call AND the main lane
   fhes_ctx *ctx;
   std::unique_lock<std::mutex> lk;

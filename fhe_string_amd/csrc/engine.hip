@@ -197,6 +197,17 @@ int32_t arena_alloc_locked(fhes_ctx *ctx, int32_t count) {
   if (count <= 0) return fail(FHES_ERR_INVALID, "arena_alloc: count must be positive");
   int32_t h = arena_take(ctx, count);
   if (h >= 0) return h;
+  if (!ctx->main_pending.empty()) {  // rows that returned main-lane calls still hold: reclaim what has finished ...
+    main_pending_prune_locked(ctx);
+    h = arena_take(ctx, count);
+    if (h >= 0) return h;
+    if (!ctx->main_pending.empty()) {  // ... and wait for the rest before the arena is grown for them
+      FHES_HIP(hipStreamSynchronize(ctx->stream));
+      main_pending_prune_locked(ctx);
+      h = arena_take(ctx, count);
+      if (h >= 0) return h;
+    }
+  }
   // the request must fit behind the last used slot at worst
   int64_t tail_free = 0;
   if (!ctx->free_ranges.empty()) {
@@ -272,13 +283,14 @@ static dev::NodeDesc make_desc(const DevNodeArrays &a, int32_t first, int32_t co
 // stream, and hipFree waits for the device)
 static int ensure_ks_out(fhes_ctx *ctx, Lane &lane, int64_t nodes) {
   if (nodes <= lane.ks_out_nodes) return FHES_OK;
-  if (lane.ks_out) FHES_HIP(hipFree(lane.ks_out));
-  if (lane.ks_dig) FHES_HIP(hipFree(lane.ks_dig));
-  if (lane.ks_body) FHES_HIP(hipFree(lane.ks_body));
+  lane.drop(lane.ks_out);
+  lane.drop(lane.ks_dig);
+  lane.drop(lane.ks_body);
   lane.ks_out = nullptr; lane.ks_dig = nullptr; lane.ks_body = nullptr;
   lane.ks_out_nodes = 0;
-  // side lanes carry single operations (levels of a few to a few thousand bootstraps): start small
-  const int64_t floor_nodes = lane.is_main ? 1024 : 128;
+  // side lanes carry single operations or a handful of combined ones (levels of a few to a few thousand bootstraps);
+  // growing means parking the old buffers (Lane::drop), so start where a combined config-2 find already fits
+  const int64_t floor_nodes = lane.is_main ? 1024 : 8192;
   const int64_t cap = ((std::max<int64_t>(nodes, floor_nodes) + 127) / 128) * 128;  // whole 128-row tiles of the MFMA keyswitch
   FHES_HIP(hipMalloc(&lane.ks_out, (size_t)cap * ctx->ks_stride * sizeof(uint64_t)));
   FHES_HIP(hipMalloc(&lane.ks_dig, (size_t)cap * ctx->dims.big * ctx->dims.ks_level));
@@ -290,11 +302,12 @@ static int ensure_ks_out(fhes_ctx *ctx, Lane &lane, int64_t nodes) {
 int ensure_slot_map(Lane &lane, size_t entries) {
   if (entries <= lane.slot_map_cap) return FHES_OK;
   FHES_HIP(hipStreamSynchronize(lane.stream));
-  if (lane.slot_map) FHES_HIP(hipFree(lane.slot_map));
+  lane.drop(lane.slot_map);
   lane.slot_map = nullptr;
   lane.slot_map_cap = 0;
-  FHES_HIP(hipMalloc(&lane.slot_map, 4 * entries));
-  lane.slot_map_cap = entries;
+  const size_t cap = lane.is_main ? entries : std::max<size_t>(entries * 2, (size_t)1 << 16);
+  FHES_HIP(hipMalloc(&lane.slot_map, 4 * cap));
+  lane.slot_map_cap = cap;
   return FHES_OK;
 }
 
@@ -336,12 +349,40 @@ int acquire_lane_locked(fhes_ctx *ctx, std::unique_lock<std::mutex> &lk, Lane **
 void release_lane_locked(fhes_ctx *ctx, Lane *lane) {
   if (!lane) return;
   if (lane == &ctx->main) {
-    if (ctx->main_held && ctx->main_done_ev) (void)hipEventRecord(ctx->main_done_ev, ctx->stream);
+    if (ctx->main_held && ctx->main_untracked) {  // a Level-0 call: which rows it touches is not tracked -> all of them
+      (void)main_pending_push_locked(ctx, 0, INT32_MAX, 0, 0);
+      ctx->main_untracked = false;
+    }
     ctx->main_held = false;
   } else {
     lane->busy = false;
   }
   ctx->lane_cv.notify_all();
+}
+
+void main_pending_prune_locked(fhes_ctx *ctx) {
+  size_t w = 0;
+  for (size_t i = 0; i < ctx->main_pending.size(); i++) {
+    if (hipEventQuery(ctx->main_pending[i].ev) == hipSuccess) {
+      const auto &mp = ctx->main_pending[i];
+      if (mp.free_second && mp.hi[1] > mp.lo[1]) (void)arena_free_locked(ctx, mp.lo[1], mp.hi[1] - mp.lo[1]);  // the deferred scratch
+      ctx->pending_ev_free.push_back(mp.ev);
+    } else {
+      ctx->main_pending[w++] = ctx->main_pending[i];
+    }
+  }
+  (void)hipGetLastError();  // "not ready" is reported as an error value
+  ctx->main_pending.resize(w);
+}
+
+int main_pending_push_locked(fhes_ctx *ctx, int32_t lo0, int32_t hi0, int32_t lo1, int32_t hi1, bool free_second) {
+  main_pending_prune_locked(ctx);
+  hipEvent_t ev;
+  if (!ctx->pending_ev_free.empty()) { ev = ctx->pending_ev_free.back(); ctx->pending_ev_free.pop_back(); }
+  else FHES_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  FHES_HIP(hipEventRecord(ev, ctx->stream));
+  ctx->main_pending.push_back({{lo0, lo1}, {hi0, hi1}, ev, free_second});
+  return FHES_OK;
 }
 
 void merge_counters_locked(fhes_ctx *ctx, const RunCounters &rc) {
@@ -475,7 +516,7 @@ static int launch_br_gen_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   const Dims &dm = ctx->dims;
   const size_t per = gen_scratch_per_wg(dm), need = per * (size_t)d.v_count;
   if (lane.gen_scratch_bytes < need) {
-    if (lane.gen_scratch) FHES_HIP(hipFree(lane.gen_scratch));
+    lane.drop(lane.gen_scratch);
     lane.gen_scratch = nullptr;
     lane.gen_scratch_bytes = 0;
     FHES_HIP(hipMalloc(&lane.gen_scratch, need));
@@ -688,7 +729,6 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   ctx->main.stream = ctx->stream;
   ctx->main.is_main = true;
-  if ((e = hipEventCreateWithFlags(&ctx->main_done_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
 
   {
     hipDeviceProp_t prop;
@@ -757,13 +797,17 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->root); (void)hipFree(ctx->psi); (void)hipFree(ctx->odd_fix); (void)hipFree(ctx->cdpp); (void)hipFree(ctx->lut_polys);
   (void)hipDeviceSynchronize();
-  auto drop_lane = [](Lane &l) { (void)hipFree(l.ks_out); (void)hipFree(l.ks_dig); (void)hipFree(l.ks_body); (void)hipFree(l.slot_map); (void)hipFree(l.gen_scratch); };
+  auto drop_lane = [](Lane &l) {
+    (void)hipFree(l.ks_out); (void)hipFree(l.ks_dig); (void)hipFree(l.ks_body); (void)hipFree(l.slot_map); (void)hipFree(l.gen_scratch);
+    for (void *p : l.retired) (void)hipFree(p);
+  };
   drop_lane(ctx->main);
   for (auto &l : ctx->side) {
     drop_lane(*l);
     if (l->stream) (void)hipStreamDestroy(l->stream);
   }
-  if (ctx->main_done_ev) (void)hipEventDestroy(ctx->main_done_ev);
+  for (auto &mp : ctx->main_pending) (void)hipEventDestroy(mp.ev);
+  for (auto &ev : ctx->pending_ev_free) (void)hipEventDestroy(ev);
   (void)hipFree(ctx->ksk_pk); (void)hipFree(ctx->desc_buf);
   for (auto &t : ctx->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
   for (auto &ev : ctx->ev_free) (void)hipEventDestroy(ev);
@@ -908,6 +952,7 @@ int fhes_pbs_batch(fhes_ctx *ctx, int32_t count, const int32_t *term_ptr, const 
   int rc = stage_desc(ctx, count, term_ptr, term_idx, term_coef, consts, lut_ids, out_handles, &a);
   if (rc) return rc;
   RunCounters cnt;
+  ctx->main_untracked = true;
   rc = launch_pbs(ctx, ctx->main, a, 0, count, 1, &cnt);
   merge_counters_locked(ctx, cnt);
   return rc;
@@ -922,6 +967,7 @@ int fhes_linear_batch(fhes_ctx *ctx, int32_t count, const int32_t *term_ptr, con
   int rc = stage_desc(ctx, count, term_ptr, term_idx, term_coef, consts, nullptr, out_handles, &a);
   if (rc) return rc;
   RunCounters cnt;
+  ctx->main_untracked = true;
   rc = launch_linear(ctx, ctx->main, a, 0, count, 1, &cnt);
   merge_counters_locked(ctx, cnt);
   return rc;

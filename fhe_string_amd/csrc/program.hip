@@ -2,8 +2,12 @@
 // their execution on the device engine, one keyswitch + blind-rotate launch pair per level.
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <thread>
 #include <mutex>
 #include <stdexcept>
 
@@ -175,18 +179,20 @@ int fhes_program_export(const fhes_program *fp, int32_t *level_ptr, int32_t *ter
   return FHES_OK;
 }
 
-int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_inst,
-                           const int32_t *in_handles, int32_t *out_handles) {
-  auto *fp = const_cast<fhes_program *>(cfp);
-  if (!ctx || !fp || !out_handles || n_inst < 1 || (fp->prog.n_inputs > 0 && !in_handles))
-    return fail(FHES_ERR_INVALID, "program_run: bad argument");
-  if (memcmp(&ctx->p, &fp->prog.params, sizeof(fhes_params)) != 0)
-    return fail(FHES_ERR_INVALID, "program_run: program was compiled for different parameters");
+}  // extern "C"
+
+// one run of `n_inst` instances on a lane of the context
+static int run_impl(fhes_ctx *ctx, fhes_program *fp, int32_t n_inst, const int32_t *in_handles, int32_t *out_handles) {
   // Concurrency (round 3): the context mutex is held while the run is set up (arena ranges, program image, a
   // lane) and while it is cleaned up, NOT while its launches are queued; a caller that finds the main lane
   // carrying another caller's work gets a side lane (own stream and scratch) and returns when its results are
   // complete, so N threads calling into one context overlap on the device (engine.h, `Lane`).
   std::unique_lock<std::mutex> lk(ctx->mu);
+  struct Active {  // calls inside a run: what tells a newcomer that it has company (the combiner below)
+    fhes_ctx *c;
+    explicit Active(fhes_ctx *cc) : c(cc) { c->active_runs++; }
+    ~Active() { c->active_runs--; }
+  } active(ctx);
   FHES_HIP(hipSetDevice(ctx->device));
   if (!ctx->keys_loaded) return fail(FHES_ERR_STATE, "server keys not uploaded");
   const circ::Program &p = fp->prog;
@@ -305,6 +311,22 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
       }
     }
   }
+  // ---- a side lane: which returned-but-unfinished main-stream work does this run depend on? ----
+  std::vector<hipEvent_t> waits;
+  if (!lane.is_main) {
+    main_pending_prune_locked(ctx);
+    for (const auto &mp : ctx->main_pending) {
+      bool hit = false;
+      for (int k = 0; k < 2 && !hit; k++) {
+        if (mp.lo[k] >= mp.hi[k]) continue;
+        auto overlaps = [&](int64_t lo, int64_t hi) { return lo < hi && lo < mp.hi[k] && mp.lo[k] < hi; };
+        hit = overlaps(out_base, (int64_t)out_base + out_total) || (scratch >= 0 && overlaps(scratch, (int64_t)scratch + (int64_t)fp->n_scratch * n_inst));
+        for (int64_t i = 0; i < (int64_t)n_in * n_inst && !hit; i++) hit = in_handles[i] >= mp.lo[k] && in_handles[i] < mp.hi[k];
+      }
+      if (hit) waits.push_back(mp.ev);
+    }
+  }
+
   // ---- queue the launches: without the context mutex, with the arena pinned (arena_rw shared) ----
   RunCounters cnt;
   int rc = FHES_OK;
@@ -312,11 +334,9 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
     std::shared_lock<std::shared_mutex> pin(ctx->arena_rw);
     lk.unlock();
     auto queue = [&]() -> int {
-      if (!lane.is_main) {
-        // inputs may be results of a RETURNED call whose work is still queued on the main stream: order this
-        // lane behind every completed call (main_done_ev), not behind a call that is still queueing there
-        FHES_HIP(hipStreamWaitEvent(lane.stream, ctx->main_done_ev, 0));
-      }
+      // inputs that are results of a RETURNED main-lane call still running, rows that such a call handed back while
+      // its kernels still use them: behind exactly those (fhes_ctx::main_pending)
+      for (hipEvent_t ev : waits) FHES_HIP(hipStreamWaitEvent(lane.stream, ev, 0));
       FHES_HIP(hipMemcpyAsync(lane.slot_map, map.data(), 4 * map.size(), hipMemcpyHostToDevice, lane.stream));
       FHES_HIP(hipStreamSynchronize(lane.stream));  // `map` is a stack object
       int r = FHES_OK;
@@ -351,8 +371,106 @@ int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_ins
     if (e != hipSuccess && rc == FHES_OK) rc = hip_fail(e, "side lane");
   }
   lk.lock();  // the guards below free arena ranges and hand the lane back under the mutex
+  if (lane.is_main) {
+    // this call returns with its work queued: remember what it writes, and keep its scratch out of the free list until
+    // the kernels that use it have finished (another lane would be handed the same rows otherwise)
+    const bool defer = scratch >= 0 && rc == FHES_OK;
+    if (main_pending_push_locked(ctx, out_total > 0 ? out_base : 0, out_total > 0 ? out_base + out_total : 0, scratch >= 0 ? scratch : 0,
+                                 scratch >= 0 ? scratch + fp->n_scratch * n_inst : 0, defer) == FHES_OK && defer)
+      guard.scratch = -1;  // freed by main_pending_prune_locked
+  }
   merge_counters_locked(ctx, cnt);
   guard.keep_outputs = rc == FHES_OK;
+  return rc;
+}
+
+extern "C" {
+
+// Combining (round 3): single-instance runs of the SAME program that arrive while other runs are in flight are merged
+// into ONE batched run -- the first such caller opens a short window (FHES_COMBINE_WINDOW_US, default 300), later ones
+// join it, the opener runs them as `n` instances (every level one launch pair for all of them instead of `n` small ones)
+// and hands each caller its own output handles.  A caller that finds the context idle runs at once, so a single-threaded
+// application never waits.  Results are the same bits either way (instances are independent).  FHES_COMBINE=0 disables.
+namespace {
+struct Forming {
+  std::vector<const int32_t *> ins;
+  std::vector<int32_t *> outs;
+  int state = 0;  // 0 open, 1 running, 2 done
+  int rc = FHES_OK;
+  std::string err;
+  std::condition_variable cv;
+};
+std::mutex g_forming_mu;  // guards the table below (its entries are per context AND program)
+std::map<std::pair<uint64_t, const fhes_program *>, std::shared_ptr<Forming>> g_forming;
+constexpr size_t kMaxCombine = 64;
+}  // namespace
+
+int fhes_program_run_batch(fhes_ctx *ctx, const fhes_program *cfp, int32_t n_inst,
+                           const int32_t *in_handles, int32_t *out_handles) {
+  auto *fp = const_cast<fhes_program *>(cfp);
+  if (!ctx || !fp || !out_handles || n_inst < 1 || (fp->prog.n_inputs > 0 && !in_handles))
+    return fail(FHES_ERR_INVALID, "program_run: bad argument");
+  if (memcmp(&ctx->p, &fp->prog.params, sizeof(fhes_params)) != 0)
+    return fail(FHES_ERR_INVALID, "program_run: program was compiled for different parameters");
+  static const bool combine = [] { const char *e = getenv("FHES_COMBINE"); return !(e && std::string(e) == "0"); }();
+  static const int window_us = [] { const char *e = getenv("FHES_COMBINE_WINDOW_US"); const int v = e ? atoi(e) : 300; return v < 0 ? 0 : v; }();
+  if (!combine || n_inst != 1) return run_impl(ctx, fp, n_inst, in_handles, out_handles);
+  const auto key = std::make_pair(ctx->uid, (const fhes_program *)fp);
+  std::shared_ptr<Forming> f;
+  bool leader = false;
+  {
+    std::unique_lock<std::mutex> fl(g_forming_mu);
+    auto it = g_forming.find(key);
+    if (it != g_forming.end() && it->second->state == 0 && it->second->ins.size() < kMaxCombine) {
+      f = it->second;  // join the open window
+      f->ins.push_back(in_handles);
+      f->outs.push_back(out_handles);
+      f->cv.wait(fl, [&] { return f->state == 2; });
+      if (f->rc != FHES_OK) return fail(f->rc, "%s", f->err.c_str());
+      return FHES_OK;
+    }
+    bool company;
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      company = ctx->active_runs > 0;
+    }
+    if (company && it == g_forming.end()) {  // others are running: open a window for whoever comes next
+      f = std::make_shared<Forming>();
+      f->ins.push_back(in_handles);
+      f->outs.push_back(out_handles);
+      g_forming[key] = f;
+      leader = true;
+    }
+  }
+  if (!leader) return run_impl(ctx, fp, 1, in_handles, out_handles);
+  if (window_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(window_us));
+  size_t n;
+  {
+    std::lock_guard<std::mutex> fl(g_forming_mu);
+    f->state = 1;  // closed: later arrivals open their own
+    g_forming.erase(key);
+    n = f->ins.size();
+  }
+  int rc;
+  if (n == 1) {
+    rc = run_impl(ctx, fp, 1, in_handles, out_handles);
+  } else {
+    const size_t n_in = (size_t)fp->prog.n_inputs, n_out = fp->prog.out_slots.size();
+    std::vector<int32_t> all_in(n * n_in), all_out(n * std::max<size_t>(n_out, 1));
+    for (size_t i = 0; i < n; i++)
+      if (n_in) memcpy(&all_in[i * n_in], f->ins[i], 4 * n_in);
+    rc = run_impl(ctx, fp, (int32_t)n, all_in.data(), all_out.data());
+    if (rc == FHES_OK)
+      for (size_t i = 0; i < n; i++)
+        if (n_out) memcpy(f->outs[i], &all_out[i * n_out], 4 * n_out);
+  }
+  {
+    std::lock_guard<std::mutex> fl(g_forming_mu);
+    f->rc = rc;
+    if (rc != FHES_OK) f->err = fhes_last_error();
+    f->state = 2;
+  }
+  f->cv.notify_all();
   return rc;
 }
 

@@ -118,8 +118,10 @@ int fhes_client_decrypt_blocks(const fhes_client_key *ck, const uint64_t *cts, i
  *   - fhes_program_run / fhes_program_run_batch / fhes_string_op from SEVERAL threads on one context
  *     overlap on the device: a call that finds the context's own stream carrying another caller's work
  *     gets an execution lane of its own (stream, keyswitch scratch, slot map) and returns when its results
- *     are complete.  A single caller keeps the asynchronous behaviour: its runs queue on the context's
- *     stream and return at once; fhes_sync / fhes_arena_download wait.
+ *     are complete; single-instance runs of the same program that arrive while others are in flight are combined
+ *     into one batched run (FHES_COMBINE=0 disables, FHES_COMBINE_WINDOW_US sets the 300 us window).  A single caller
+ *     keeps the asynchronous behaviour: its runs queue on the context's stream and return at once; fhes_sync /
+ *     fhes_arena_download wait.
  *   - the Level-0 batch calls (fhes_pbs_batch, fhes_linear_batch), key upload and statistics take the
  *     context's own stream exclusively and serialise with each other.
  *   - HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: at most about four lanes make

@@ -2,12 +2,13 @@
 workers (`/root/reference/src/ciphertext/search.rs:34-40`, `compare.rs:27-42`, `mod.rs:292` `T: Sync`); here N
 host threads calling `fhes_program_run` on one `fhes_ctx` get an execution lane each (own HIP stream, keyswitch
 scratch and slot map, `csrc/engine.h`), so their levels of 5-7 bootstraps overlap on the 256 CUs instead of
-queueing behind one mutex.  Checked: 8 threads each running one config-2 `find`, outputs bit-identical to the
-sequential runs, wall-clock against one find.  Measured (profiles/r03_concurrent_callers.txt): 1 / 2 / 4 / 8
-callers 221 / 232 / 264 / 330-341 ms; the SAME 8 finds as one batched run (`fhes_program_run_batch`, every level
-merged into common launches) take 296 ms = 1.34 x: the four wide levels of a find (1319 of its 1664 bootstraps)
-are throughput-bound, 8 x 11 ms of the whole chip, and do not shrink by overlapping.  The verdict asked for
-< 1.5 x; the lanes land at 1.49-1.54 x box to box, 13 % above the batched floor, so the assertion is 1.6 x."""
+queueing behind one mutex, and single-instance runs of the SAME program that arrive while others are in flight
+are COMBINED into one batched run (`csrc/program.hip`: a 300 us window opened by the first caller that has company).
+Done-criterion of the verdict: 8 threads each running one config-2 `find` finish in < 1.5 x the single-find wall-clock
+with outputs bit-identical to the sequential runs.  Measured (profiles/r03_concurrent_callers.txt): 1 / 2 / 4 / 8 / 16
+callers 221 / 236 / 254 / 315 / 429 ms (1.43 x at 8); the same 8 finds as ONE batched run take 295 ms = 1.34 x -- the
+four wide levels of a find (1319 of its 1664 bootstraps) are throughput-bound, 8 x 11 ms of the whole chip, the floor
+for any interleaving.  (Round 2, one mutex and one stream: 8 x 221 ms.)"""
 import threading
 import time
 
@@ -89,7 +90,7 @@ def test_eight_threads_one_find_each_overlap_on_the_device(libs):
         assert np.array_equal(got, seq[k]), f"thread {k}: result differs from the sequential run"
     print(f"single find {t_single * 1e3:.1f} ms, {N_THREADS} concurrent finds {t_all * 1e3:.1f} ms "
           f"({t_all / t_single:.2f} x)")
-    assert t_all < 1.6 * t_single, (t_all, t_single)
+    assert t_all < 1.5 * t_single, (t_all, t_single)
     for hs in handles:
         check(w.lib.fhes_arena_free(ctx, int(hs[0]), len(hs)))
 
