@@ -516,7 +516,7 @@ def main():
             "config": {"workload": "FheString::find, 64-char unpadded input, 4-char encrypted pattern, "
                                    + ("PARAM_MESSAGE_2_CARRY_2_KS_PBS, l=255 (BASELINE config 2)" if args.params == "classic" else
                                       f"multi-bit 2_2 set, grouping factor {args.params[-1]}, l=255 (parameter family of BASELINE config 5)"),
-                       "pbs_per_find": int(pbs_per_find), "levels": int(n_levels),
+                       "pbs_per_find": int(pbs_per_find), "levels": int(n_levels), "dependency_depth": int(lib.fhes_program_depth(prog)),
                        "pbs_per_level_of_one_find": level_sizes,
                        "strings_per_step_per_rank": B,
                        "parallelism": f"{world_size} rank(s) x {B} independent strings per step (replicas, no data-path collective); "

@@ -123,6 +123,7 @@ SIGNATURES = {
     "fhes_comm_broadcast_cts": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
     "fhes_comm_broadcast_keys": (C.c_int, [_P, C.c_int32]),
     "fhes_sharded_search": (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, C.c_int32, _i32p]),
+    "fhes_program_depth": (C.c_int32, [_P]),
     "fhes_sharded_op": (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, C.c_int32, _i32p]),
     "fhes_comm_create_host_exec": (_P, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "fhes_server_key_set_comm": (C.c_int, [_P, _P]),

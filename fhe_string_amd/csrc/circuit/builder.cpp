@@ -241,6 +241,8 @@ static void tile_wide_levels(Program &prog, size_t max_nodes) {
   if (widest <= max_nodes) return;
   const bool has_linear = prog.nodes.back().lut < 0;
   const int32_t lin_lo = has_linear ? prog.level_ptr[nl - 1] : nn;  // linear nodes stay together at the end
+  for (int32_t j = 0; j < lin_lo; j++)  // ... and ONLY there: a linear node further up would be launched as a bootstrap
+    if (prog.nodes[j].lut < 0) throw std::logic_error("tile_wide_levels: a linear node outside the last level");
   std::vector<int32_t> level_of(nn);
   for (int li = 0; li < nl; li++)
     for (int32_t j = prog.level_ptr[li]; j < prog.level_ptr[li + 1]; j++) level_of[j] = li;
@@ -369,6 +371,7 @@ Program Builder::finish(const std::vector<Blk> &outputs, const std::string &name
   }
   prog.level_ptr.push_back((int32_t)order.size());
   if (order.empty()) prog.level_ptr = {0};
+  prog.depth = (int32_t)prog.level_ptr.size() - 1;  // dependency depth: level_ptr becomes the LAUNCH schedule below
   for (int32_t s : out_slots) prog.out_slots.push_back(remap(s));
   prog.out_deg = out_deg;
   prog.out_noise = out_noise;

@@ -51,7 +51,9 @@ struct Program {
   fhes_params params;
   int32_t n_inputs = 0;
   std::vector<Node> nodes;
-  std::vector<int32_t> level_ptr;       // PBS levels, then (optionally) one linear level
+  std::vector<int32_t> level_ptr;       // launch schedule: PBS levels (a wide level may be tiled into several, tile_wide_levels), then
+                                        // (optionally) one linear level
+  int32_t depth = 0;                    // dependency depth (levels before tiling): what a latency estimate counts
   std::vector<Table> luts;
   std::vector<int32_t> out_slots;       // one per output block
   std::vector<int32_t> out_parts;       // block counts of the result objects (sum == out_slots.size())

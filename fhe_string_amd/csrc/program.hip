@@ -131,6 +131,11 @@ int fhes_program_info(const fhes_program *fp, int64_t info[8]) {
   return FHES_OK;
 }
 
+int32_t fhes_program_depth(const fhes_program *fp) {
+  if (!fp) return fail(FHES_ERR_INVALID, "null argument");
+  return fp->prog.depth;
+}
+
 int32_t fhes_program_scratch_cells(const fhes_program *fp) {
   if (!fp) return fail(FHES_ERR_INVALID, "null argument");
   return fp->n_scratch;

@@ -222,6 +222,10 @@ int32_t fhes_program_out_parts(const fhes_program *prog, int32_t *parts, int32_t
  * them: results cross the program boundary clean (degree < message modulus, noise <= 1), so that a
  * following operation may treat them like fresh operands.  Arrays of n_outputs entries. */
 int fhes_program_out_meta(const fhes_program *prog, int32_t *degree, double *noise);
+/* Dependency depth of the circuit.  info[3] of fhes_program_info counts LAUNCHES: a level wider than 2^16 bootstraps is
+ * tiled into several launches by the memory-bounded schedule, so it can exceed the depth (faithful trim at 512
+ * characters: 881 launches, depth 530). */
+int32_t fhes_program_depth(const fhes_program *prog);
 /* Arena cells one instance of the program occupies while it runs (results excluded): node
  * results share cells once every reader of the previous occupant ran in an earlier level. */
 int32_t fhes_program_scratch_cells(const fhes_program *prog);
