@@ -125,6 +125,7 @@ SIGNATURES = {
     "fhes_sharded_search": (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, C.c_int32, _i32p]),
     "fhes_program_depth": (C.c_int32, [_P]),
     "fhes_sharded_op": (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, C.c_int32, _i32p]),
+    "fhes_sharded_op_ex": (C.c_int, [_P, C.c_char_p, _i32p, _i32p, C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_int32, _i32p, _i32p, C.c_int32, _i32p]),
     "fhes_comm_create_host_exec": (_P, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "fhes_server_key_set_comm": (C.c_int, [_P, _P]),
 }

@@ -149,8 +149,17 @@ struct S {
     return all(v);
   }
 
-  // search.rs:33-41
+  // search.rs:33-41.  `inject_found`: the position-sharded forms ("<op>.rest", csrc/comm.hip) hand in the per-position
+  // results that the ranks computed and gathered; the FIRST find_all of the operation -- always (self, pattern) --
+  // takes them instead of evaluating substr_eq itself.
+  const std::vector<Blk> *inject_found = nullptr;
   std::vector<Blk> find_all(const Str &a, const Str &s) {
+    if (inject_found) {
+      if (inject_found->size() + 1 != a.size()) throw std::logic_error("find_all: injected results do not match the string");
+      const std::vector<Blk> *f = inject_found;
+      inject_found = nullptr;
+      return *f;
+    }
     std::vector<Blk> f;
     for (size_t i = 0; i + 1 < a.size(); i++) f.push_back(substr_eq(a, i, s));
     return f;
@@ -1150,7 +1159,7 @@ const char *op_signature(const std::string &op_full) {
     if (op == e.name) return e.sig;
   if (op == "find_all_range") return "SSII";
   // stages of the position-sharded split (csrc/comm.hip): L = one BooleanBlock per element, one object
-  if (op == "split_head" || op == "rsplit_head" || op == "split_rest" || op == "rsplit_rest") return "SSL";
+  if (op == "split_head" || op == "rsplit_head") return "SSL";
   if (op == "split_is_some_range") return "LUUII";
   if (op == "split_tail" || op == "rsplit_tail") return "LLUUB";
   if (op == "any_of" || op == "index_of" || op == "rindex_of" || op == "sum_gt_zero") return "I";
@@ -1212,33 +1221,6 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
     out.push_back(h.pattern_empty);
     Program prog = b.finish(out, op_full);
     prog.out_parts = {(int32_t)h.matches.size(), Bu, Bu, 1};
-    return prog;
-  }
-  if (op == "split_rest" || op == "rsplit_rest") {  // shape {slots_a, slots_p}: a, p, found[slots_a - 1] -> the slices
-    // everything of split_opt behind find_all in ONE replicated program: what the sharded form runs when the log-depth
-    // forms are selected -- their barrel shifter (S::split_tail) is cheaper than the O(n^2) grid even when that is
-    // divided by the number of ranks, and it does not partition by output index
-    if (shape.size() != 2 || shape[0] < 1 || shape[1] < 1) throw std::invalid_argument(op + " needs {slots_a, slots_p}");
-    const int n_found = shape[0] - 1;
-    Builder b(p, (shape[0] + shape[1]) * Bc + n_found);
-    Ops o(b);
-    S s{o, Bc, Bu, fast};
-    Str sa, sb;
-    int32_t next = 0;
-    for (int c = 0; c < shape[0]; c++) { Radix ch; for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1)); sa.push_back(ch); }
-    for (int c = 0; c < shape[1]; c++) { Radix ch; for (int k = 0; k < Bc; k++) ch.push_back(b.input(next++, msg_mod - 1)); sb.push_back(ch); }
-    std::vector<Blk> found;
-    for (int i = 0; i < n_found; i++) found.push_back(b.input(next++, 1));
-    S::SplitHead h = s.split_head(sa, sb, op == "rsplit_rest", &found);
-    std::vector<S::Slice> v = s.split_tail(h.matches, h.p_len, h.self_len, h.pattern_empty, (size_t)shape[0] + 1, false, nullptr);
-    if (op == "rsplit_rest") std::reverse(v.begin(), v.end());
-    std::vector<Blk> out;
-    for (auto &e : v) out.push_back(e.is_some);
-    for (auto &e : v) push_all(out, e.start);
-    for (auto &e : v) push_all(out, e.end);
-    Program prog = b.finish(out, op_full);
-    const int n = (int)v.size();
-    prog.out_parts = {n, n * Bu, n * Bu};
     return prog;
   }
   if (op == "split_is_some_range") {  // shape {n, lo, hi}: matches[n], len(p), len(a) -> is_some[lo, hi)
@@ -1321,9 +1303,17 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
     return prog;
   }
 
+  // "<op>.rest": the operation with its find_all(self, pattern) handed in -- one more operand behind the operation's own,
+  // found[slots(self) - 1] BooleanBlocks (no shape entry: the count follows from the first string)
+  bool rest = false;
+  {
+    static const std::string tail = ".rest";
+    if (op.size() > tail.size() && op.compare(op.size() - tail.size(), tail.size(), tail) == 0) { rest = true; op.resize(op.size() - tail.size()); }
+  }
   const char *sig = op_signature(op);
   if (!sig) throw std::invalid_argument("unknown operation '" + op + "'");
   const std::string sg = sig;
+  if (rest && std::count(sg.begin(), sg.end(), 'S') < 2) throw std::invalid_argument("'" + op + ".rest': only operations on (self, pattern) have a find_all to hand in");
   size_t need = 0;
   for (char c : sg) need += (c == 'S' || c == 'I' || c == 'V');
   if (shape.size() != need)
@@ -1340,6 +1330,7 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
       else { if (shape[k] < 0) throw std::invalid_argument("negative integer argument"); k++; }
     }
   }
+  if (rest) n_inputs += shape[0] - 1;
   Builder b(p, n_inputs);
   Ops o(b);
   S s{o, Bc, Bu, fast};
@@ -1349,6 +1340,7 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
   std::vector<Radix> chars;
   std::vector<Blk> bools;
   std::vector<S::Slice> vec;
+  std::vector<Blk> injected;
   {
     int32_t next = 0;
     size_t k = 0;
@@ -1379,6 +1371,10 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
         for (int e = 0; e < n; e++) for (int q = 0; q < Bu; q++) vec[e].start.push_back(b.input(next++, msg_mod - 1));
         for (int e = 0; e < n; e++) for (int q = 0; q < Bu; q++) vec[e].end.push_back(b.input(next++, msg_mod - 1));
       } else ints.push_back(shape[k++]);
+    }
+    if (rest) {
+      for (int i = 0; i + 1 < shape[0]; i++) injected.push_back(b.input(next++, 1));
+      s.inject_found = &injected;
     }
   }
 

@@ -459,7 +459,7 @@ int fhes_sharded_op(fhes_comm *c, const char *op_in, int32_t a_first, int32_t a_
       // per-index gathers is cheaper than the grid divided by the ranks and does not partition by index
       std::vector<int32_t> in2(ab);
       in2.insert(in2.end(), found.begin(), found.end());
-      run_prog(o == "split" ? "split_rest" : "rsplit_rest", {a_slots, p_slots}, in2, result);
+      run_prog((o + ".rest").c_str(), {a_slots, p_slots}, in2, result);
     } else {
       // ---- split / rsplit (split.rs:238-333) ----
       // stage 2 (replicated): non-overlapping matches, len(p), len(self), pattern_empty
@@ -505,6 +505,104 @@ int fhes_sharded_op(fhes_comm *c, const char *op_in, int32_t a_first, int32_t a_
     for (int k = 0; k < n_final; k++) out_handles[k] = result[0] + k;
     *n_out = n_final;
   }
+  return FHES_OK;
+}
+
+// Every operation whose circuit starts with find_all(self, pattern) (search.rs:33-41) -- rfind, the split family, split_once,
+// strip_suffix, replace / replacen -- shards that part the same way: found[] per rank + one all-gather, then the operation's
+// "<op>.rest" program (circuit/strings.cpp: the same circuit with find_all handed in) replicated.  Operands are the operation's
+// ciphertext operands in signature order (fhes_op_signature: S / U / C / B), as first handle + block count; the first two S
+// operands are (self, pattern).  Results: one contiguous range, its parts as fhes_program_out_parts reports them.
+int fhes_sharded_op_ex(fhes_comm *c, const char *op_in, const int32_t *operand_first, const int32_t *operand_blocks, int32_t n_operands,
+                       const int64_t *iargs, int32_t n_iargs, int32_t bu, int32_t *out_first, int32_t *parts, int32_t max_parts, int32_t *n_parts) {
+  if (!c || (!c->ctx && !c->has_exec) || !op_in || !operand_first || !operand_blocks || n_operands < 2 || !out_first || !parts || !n_parts || (n_iargs > 0 && !iargs))
+    return fail(FHES_ERR_INVALID, "sharded_op_ex: bad argument");
+  const char *sig = fhes_op_signature(op_in);
+  if (!sig) return fail(FHES_ERR_INVALID, "sharded_op_ex: unknown operation '%s'", op_in);
+  std::string o = op_in, suffix;
+  {
+    static const std::string ld = "_logdepth";
+    if (o.size() > ld.size() && o.compare(o.size() - ld.size(), ld.size(), ld) == 0) { suffix = ld; o.resize(o.size() - ld.size()); }
+  }
+  static const char *kHasFindAll[] = {"rfind", "split", "rsplit", "split_inclusive", "split_terminator", "rsplit_terminator", "splitn", "rsplitn",
+                                      "split_once", "rsplit_once", "strip_suffix", "replace", "replacen", "find", "contains"};
+  bool known = false;
+  for (const char *k : kHasFindAll) known = known || o == k;
+  if (!known) return fail(FHES_ERR_INVALID, "sharded_op_ex: '%s' has no find_all(self, pattern) to shard", op_in);
+  std::lock_guard<std::mutex> lk(c->mu);
+  X x{c};
+  const int msg_mod = 1 << c->params.message_bits;
+  int bc = 0;
+  for (int v = 1; v < 128; v *= msg_mod) bc++;
+  // shape of the operation and the handles of (self, pattern)
+  std::vector<int32_t> shape, all_in, str_first, str_slots;
+  int ai = 0, ii = 0;
+  for (const char *q = sig; *q; ++q) {
+    if (*q == 'I') {
+      if (ii >= n_iargs || iargs[ii] < 0 || iargs[ii] > INT32_MAX) return fail(FHES_ERR_INVALID, "sharded_op_ex: integer argument %d missing or out of range", ii);
+      shape.push_back((int32_t)iargs[ii++]);
+      continue;
+    }
+    if (ai >= n_operands) return fail(FHES_ERR_INVALID, "sharded_op_ex: '%s' (signature %s) needs more operands", op_in, sig);
+    const int32_t first = operand_first[ai], blocks = operand_blocks[ai];
+    const int32_t want = *q == 'U' ? bu : *q == 'C' ? bc : *q == 'B' ? 1 : -1;
+    if (first < 0 || blocks < 1 || (want > 0 && blocks != want) || (*q == 'S' && blocks % bc) || (*q != 'S' && want < 0))
+      return fail(FHES_ERR_INVALID, "sharded_op_ex: operand %d does not fit signature %s", ai, sig);
+    if (*q == 'S') { shape.push_back(blocks / bc); str_first.push_back(first); str_slots.push_back(blocks / bc); }
+    for (int k = 0; k < blocks; k++) all_in.push_back(first + k);
+    ai++;
+  }
+  if (ai != n_operands || ii != n_iargs || str_first.size() < 2) return fail(FHES_ERR_INVALID, "sharded_op_ex: wrong operand count for '%s' (signature %s)", op_in, sig);
+  const int32_t a_slots = str_slots[0], p_slots = str_slots[1];
+  const int64_t n_pos = a_slots - 1;
+  int64_t lo = 0, hi = 0;
+  int rc = fhes_shard_range(n_pos, c->world, c->rank, &lo, &hi);
+  if (rc) return rc;
+  const int32_t chunk = (int32_t)((n_pos + c->world - 1) / c->world);
+  std::vector<std::pair<int32_t, int32_t>> owned;
+  auto run_prog = [&](const std::string &name, const std::vector<int32_t> &shp, const std::vector<int32_t> &in, std::vector<int32_t> &out, fhes_program **used) {
+    if (rc != FHES_OK) return;
+    fhes_program *pr = comm_program(c, name.c_str(), shp, bu);
+    if (used) *used = pr;
+    if (!pr) { rc = FHES_ERR_INVALID; return; }
+    int64_t info[8];
+    fhes_program_info(pr, info);
+    out.assign((size_t)std::max<int64_t>(info[1], 1), -1);
+    if ((int64_t)in.size() != info[0]) { rc = fail(FHES_ERR_STATE, "internal: %s takes %lld inputs, %zu given", name.c_str(), (long long)info[0], in.size()); return; }
+    rc = x.run(pr, in.data(), out.data());
+  };
+  std::vector<int32_t> ab, local;
+  for (int k = 0; k < a_slots * bc; k++) ab.push_back(str_first[0] + k);
+  for (int k = 0; k < p_slots * bc; k++) ab.push_back(str_first[1] + k);
+  if (hi > lo) run_prog("find_all_range", {a_slots, p_slots, (int32_t)lo, (int32_t)hi}, ab, local, nullptr);
+  if (rc == FHES_OK && hi > lo) owned.push_back({local[0], (int32_t)(hi - lo)});
+  int32_t G = -1;
+  if (n_pos > 0) {
+    G = x.alloc(chunk * c->world);
+    if (G < 0) { if (rc == FHES_OK) rc = G; }
+    else {
+      owned.push_back({G, chunk * c->world});
+      if (hi > lo && rc == FHES_OK) rc = x.copy_rows(G + (int32_t)lo, local[0], (int32_t)(hi - lo));
+      const int cr = x.all_gather_rows(G, chunk);
+      if (cr && rc == FHES_OK) rc = cr;
+    }
+  }
+  std::vector<int32_t> in2(all_in), result;
+  for (int64_t i = 0; i < n_pos; i++) in2.push_back(G + (int32_t)i);
+  fhes_program *rest = nullptr;
+  run_prog(o + ".rest" + suffix, shape, in2, result, &rest);
+  for (auto &r : owned) x.release(r.first, r.second);
+  int64_t info[8] = {0};
+  if (rest) fhes_program_info(rest, info);
+  rc = commit(c, rc, op_in);
+  if (rc) {
+    if (!result.empty() && result[0] >= 0) x.release(result[0], (int32_t)info[1]);
+    return rc;
+  }
+  const int32_t np = fhes_program_out_parts(rest, parts, max_parts);
+  if (np < 1 || np > max_parts) { x.release(result[0], (int32_t)info[1]); return fail(FHES_ERR_INVALID, "sharded_op_ex: need room for %d parts", np); }
+  *n_parts = np;
+  *out_first = result[0];
   return FHES_OK;
 }
 

@@ -497,6 +497,42 @@ int fhes_string_op(fhes_server_key *sk, const char *op_in, fhes_ct *const *args,
     *n_outs = n_parts;
     return FHES_OK;
   }
+  // every other operation that starts with find_all(self, pattern): that part sharded, the rest replicated (fhes_sharded_op_ex)
+  if (sk->comm && fhes_comm_world(sk->comm) > 1) {
+    static const char *kSharded[] = {"rfind", "split_inclusive", "split_terminator", "rsplit_terminator", "splitn", "rsplitn", "split_once",
+                                     "rsplit_once", "strip_suffix", "replace", "replacen"};
+    bool hit = false;
+    for (const char *k : kSharded) hit = hit || base_name == k;
+    if (hit) {
+      std::vector<int32_t> firsts, blocks;
+      for (int i = 0; i < n_args; i++) {
+        if (!args[i]) return fail(FHES_ERR_INVALID, "operand %d is NULL", i);
+        int rc = ensure_device(sk, args[i]);
+        if (rc) return rc;
+        firsts.push_back(args[i]->handle);
+        blocks.push_back(args[i]->n_blocks);
+      }
+      int32_t first = -1, parts[16], n_parts = 0;
+      int rc = fhes_sharded_op_ex(sk->comm, op, firsts.data(), blocks.data(), n_args, iargs, n_iargs, sk->nb_usize, &first, parts, 16, &n_parts);
+      if (rc) return rc;
+      if (n_parts > max_outs) return fail(FHES_ERR_INVALID, "need room for %d results", n_parts);
+      const Dims d(sk->p);
+      int32_t off = 0;
+      for (int32_t k = 0; k < n_parts; k++) {
+        auto *c = new fhes_ct;
+        c->n_blocks = parts[k];
+        c->ct_words = d.ct_words();
+        c->ctx = sk->ctx;
+        c->handle = first + off;
+        c->degree.assign((size_t)c->n_blocks, (uint8_t)(sk->msg_mod - 1));
+        c->noise.assign((size_t)c->n_blocks, 1);
+        off += parts[k];
+        outs[k] = c;
+      }
+      *n_outs = n_parts;
+      return FHES_OK;
+    }
+  }
   std::vector<int32_t> shape;
   std::string key = op;
   int ai = 0, ii = 0;

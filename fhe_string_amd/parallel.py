@@ -118,6 +118,17 @@ class Comm:
         check(_lib.load().fhes_sharded_op(self._h, op.encode(), a_first, a_slots, p_first, p_slots, bu, out, 32, C.byref(n)))
         return [int(out[i]) for i in range(n.value)]
 
+    def sharded_op_ex(self, op, operands, iargs, bu):
+        """fhes_sharded_op_ex: `operands` = [(first handle, blocks), ...] in signature order, `iargs` the clear integers;
+        returns (first handle of the result range, [blocks of each result part])"""
+        n = len(operands)
+        firsts = (C.c_int32 * n)(*[int(o[0]) for o in operands])
+        blocks = (C.c_int32 * n)(*[int(o[1]) for o in operands])
+        ia = (C.c_int64 * max(len(iargs), 1))(*[int(v) for v in iargs])
+        first, parts, n_parts = C.c_int32(), (C.c_int32 * 16)(), C.c_int32()
+        check(_lib.load().fhes_sharded_op_ex(self._h, op.encode(), firsts, blocks, n, ia, len(iargs), bu, C.byref(first), parts, 16, C.byref(n_parts)))
+        return first.value, [int(parts[i]) for i in range(n_parts.value)]
+
     @staticmethod
     def host_exec(params, executor, dist=None, rank=None, world=None):
         """fhes_comm_create_host_exec: the shipped planner over an executor that keeps ciphertext rows in host memory

@@ -381,6 +381,15 @@ int fhes_comm_broadcast_keys(fhes_comm *comm, int32_t root);
 int fhes_sharded_op(fhes_comm *comm, const char *op, int32_t a_first, int32_t a_slots, int32_t p_first,
                     int32_t p_slots, int32_t num_blocks_usize, int32_t *out_handles, int32_t max_out,
                     int32_t *n_out);
+/* The same for EVERY operation whose circuit starts with find_all(self, pattern): rfind, split / rsplit / split_inclusive /
+ * split_terminator / rsplit_terminator / splitn / rsplitn, split_once / rsplit_once, strip_suffix, replace / replacen (and find /
+ * contains).  found[] is computed per rank and all-gathered, the rest of the operation ("<op>.rest": the same circuit with its
+ * find_all handed in) runs replicated.  Operands: the operation's ciphertext operands in the order of fhes_op_signature (S / U / C /
+ * B letters), each as first handle + block count; `iargs` its I operands.  Result: one contiguous handle range starting at
+ * *out_first, split into `parts` as fhes_program_out_parts lays the operation's results out. */
+int fhes_sharded_op_ex(fhes_comm *comm, const char *op, const int32_t *operand_first, const int32_t *operand_blocks, int32_t n_operands,
+                       const int64_t *iargs, int32_t n_iargs, int32_t num_blocks_usize, int32_t *out_first, int32_t *parts,
+                       int32_t max_parts, int32_t *n_parts);
 /* the search subset of fhes_sharded_op under its round-1 name */
 int fhes_sharded_search(fhes_comm *comm, const char *op, int32_t a_first, int32_t a_slots, int32_t p_first,
                         int32_t p_slots, int32_t num_blocks_usize, int32_t *out_handles, int32_t max_out,

@@ -33,6 +33,10 @@ int fhes_sharded_search(fhes_comm *, const char *, int32_t, int32_t, int32_t, in
 int fhes_sharded_op(fhes_comm *, const char *, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t *, int32_t, int32_t *) {
   return fail(FHES_ERR_NO_DEVICE, "sanitizer harness");
 }
+int fhes_sharded_op_ex(fhes_comm *, const char *, const int32_t *, const int32_t *, int32_t, const int64_t *, int32_t, int32_t, int32_t *, int32_t *,
+                       int32_t, int32_t *) {
+  return fail(FHES_ERR_NO_DEVICE, "sanitizer harness");
+}
 }
 namespace fhes {
 bool ctx_is_live(fhes_ctx *) { return false; }

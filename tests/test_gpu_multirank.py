@@ -93,12 +93,16 @@ def _worker(rank, world_size, port, q):
         api_contains = ck.decrypt_bool(A.contains(sk, P))
         api_miss = ck.decrypt_bool(A.contains(sk, api.FheString.new(ck, "zebra")))
         api_split = A.split(sk, api.FheString.new(ck, " ")).decrypt(ck)
+        # fhes_sharded_op_ex: every operation that starts with find_all(self, pattern)
+        rep = text.replace(pat, "_")
+        api_more = (A.rfind(sk, P).decrypt(ck), A.replace(sk, P, api.FheString.new(ck, "_"), len(rep)).decrypt(ck),
+                    A.split_once(sk, P).decrypt(ck), A.strip_suffix(sk, P).decrypt(ck))
         sk.set_comm(None)
         comm2.close()
         sk.close()
         q.put((rank, decode_result("find", w.decrypt(f), bu), bool(w.decrypt(c)[0] & 1), bool(np.array_equal(f, ref)),
                f[:, :8].tobytes() + c[:, :8].tobytes() + sp[:, :4].tobytes() + rs[:, :4].tobytes(),
-               (api_find, api_contains, api_miss), split_dec, rsplit_dec, api_split))
+               (api_find, api_contains, api_miss), split_dec, rsplit_dec, api_split, api_more))
     finally:
         dist.destroy_process_group()
 
@@ -116,11 +120,14 @@ def test_two_ranks_one_gpu_host_transport(libs):
         p.join(timeout=120)
         assert p.exitcode == 0
     text = "the quick brown fox jumps over the lazy dog, twice over"
-    for rank, found, contains, same_bits, _, level2, split_dec, rsplit_dec, api_split in results:
+    for rank, found, contains, same_bits, _, level2, split_dec, rsplit_dec, api_split, api_more in results:
         assert found == text.find("over"), rank
         assert contains is True
         assert same_bits, f"rank {rank}: sharded find differs from the unsharded program"
         assert level2 == (text.find("over"), True, False), (rank, level2)
         assert split_dec == api_split == text.split(" "), rank
         assert rsplit_dec == list(reversed(text.rsplit(" "))), rank
+        i = text.find("over")
+        assert api_more[0] == text.rfind("over") and api_more[1] == text.replace("over", "_"), (rank, api_more)
+        assert list(api_more[2]) == [text[:i], text[i + 4:]] and api_more[3] == text[:-4], (rank, api_more)
     assert results[0][4] == results[1][4], "the two ranks hold different ciphertexts"

@@ -21,7 +21,7 @@ import torch.multiprocessing as mp
 from fhe_string_amd._lib import FheError
 from fhe_string_amd.parallel import Comm, shard_range
 from tests.helpers import World
-from tests.progs import Prog, decode_result, num_blocks_usize, string_blocks
+from tests.progs import Prog, decode_generic, decode_result, num_blocks_usize, string_blocks
 
 
 class OracleRowExecutor:
@@ -77,12 +77,12 @@ TEXT, PAT, MISS, SEP = "abcabcxabc", "cx", "zz", "bc"
 
 def _encrypt_inputs(w):
     return [w.encrypt(string_blocks(TEXT, 12)), w.encrypt(string_blocks(PAT)), w.encrypt(string_blocks(MISS)),
-            w.encrypt(string_blocks(SEP, 3))]
+            w.encrypt(string_blocks(SEP, 3)), w.encrypt(string_blocks("Z"))]
 
 
 def _run_all(comm, ex, bu, cts):
     """every sharded operation once on the given input ciphertexts; returns {name: output rows}"""
-    a, b, m, sp = [ex.put(c) for c in cts]
+    a, b, m, sp = [ex.put(c) for c in cts[:4]]
     sa = 13
     out = {}
     for name, op, pat, slots in (("find", "find", b, 3), ("rfind_last", "rfind_last", b, 3), ("contains", "contains", b, 3),
@@ -91,6 +91,12 @@ def _run_all(comm, ex, bu, cts):
         hs = comm.sharded_op(op, a, sa, pat, slots, bu)
         n = (sa + 1) * (1 + 2 * bu) if "split" in op else len(hs)
         out[name] = ex.arena[hs[0]:hs[0] + n].copy()
+    # the generic form: any operation that starts with find_all(self, pattern), extra operands and clear integers included
+    sub = ex.put(cts[4])
+    for name, op, operands, iargs in (("rfind", "rfind", [(a, sa * 4), (b, 12)], []), ("split_inclusive", "split_inclusive_logdepth", [(a, sa * 4), (sp, 16)], []),
+                                      ("replace", "replace", [(a, sa * 4), (sp, 16), (sub, 8)], [12]), ("strip_suffix", "strip_suffix", [(a, sa * 4), (sp, 16)], [])):
+        first, parts = comm.sharded_op_ex(op, operands, iargs, bu)
+        out[name] = ex.arena[first:first + sum(parts)].copy()
     return out
 
 
@@ -117,6 +123,7 @@ def _worker(rank, world_size, port, q):
         ref_rfind, _ = Prog(w.p, "rindex_of", [12], bu).run_oracle(
             w, Prog(w.p, "find_all_range", [13, 3, 0, 12], bu).run_oracle(w, np.concatenate([a_cts, b_cts]))[0])
         dec = lambda name, op: decode_result(op, w.decrypt(got[name]), bu, TEXT)
+        gen = lambda name, op, parts: decode_generic(op, w.decrypt(got[name]), parts, bu, TEXT)
         q.put({"rank": rank,
                "find_bits": bool(np.array_equal(got["find"], ref_find)),
                "rfind_bits": bool(np.array_equal(got["rfind_last"], ref_rfind)),
@@ -124,6 +131,8 @@ def _worker(rank, world_size, port, q):
                "find": dec("find", "find"), "find_ld": dec("find_ld", "find"), "rfind_last": dec("rfind_last", "rfind"),
                "contains": bool(w.decrypt(got["contains"])[0] & 1), "miss": bool(w.decrypt(got["miss"])[0] & 1),
                "split": dec("split", "split"), "rsplit": dec("rsplit", "rsplit"), "split_ld": dec("split_ld", "split"),
+               "rfind": dec("rfind", "rfind"), "split_inclusive": dec("split_inclusive", "split_inclusive"),
+               "replace": gen("replace", "replace", [13 * 4]), "strip_suffix": gen("strip_suffix", "strip_suffix", [1, 13 * 4]),
                "digest": {k: int(np.bitwise_xor.reduce(v.ravel())) for k, v in got.items()}})
     finally:
         dist.destroy_process_group()
@@ -184,6 +193,10 @@ def test_sharded_operations_two_gloo_ranks_through_the_c_planner(libs):
         assert r["contains"] is True and r["miss"] is False
         assert r["split"] == r["split_ld"] == TEXT.split(SEP)
         assert r["rsplit"] == list(reversed(TEXT.rsplit(SEP)))
+        assert r["rfind"] == TEXT.rfind(PAT)
+        assert r["split_inclusive"] == [x + SEP for x in TEXT.split(SEP)[:-1]] + ([TEXT.split(SEP)[-1]] if TEXT.split(SEP)[-1] else [])
+        assert r["replace"] == TEXT.replace(SEP, "Z")
+        assert r["strip_suffix"] == (TEXT[:-len(SEP)] if TEXT.endswith(SEP) else None)
         # find / split stages are deterministic functions of the gathered rows: two ranks == one rank, bit for bit
         # (contains differs by construction: partial any + all-reduce instead of one any over all positions)
         for k, same in r["same_as_world1"].items():
