@@ -471,3 +471,41 @@ def test_staged_split_equals_the_monolithic_program(libs):
                     raw, _ = _staged_split_plain(op, a, a_pad, p, p_pad, cut, suffix)
                     assert list(raw % 4) == list(mono_raw % 4), (a, a_pad, p, p_pad, op, suffix, cut)
                     assert decode_result(op, raw, bu, a) == mono, (a, p, op, suffix, cut)
+
+
+def test_rest_programs_equal_the_monolithic_programs(libs):
+    """`"<op>.rest"` -- the operation with its find_all(self, pattern) handed in (what `fhes_sharded_op_ex` runs replicated
+    behind the sharded find_all) -- against the operation itself, every output block, faithful and log-depth forms"""
+    import numpy as np
+    bu = num_blocks_usize(255)
+    rnd = random.Random(9)
+    ops = [("rfind", []), ("find", []), ("contains", []), ("split", []), ("rsplit", []), ("split_inclusive", []), ("split_terminator", []),
+           ("rsplit_terminator", []), ("split_once", []), ("rsplit_once", []), ("strip_suffix", []), ("replace", ["sub", "l"]),
+           ("replacen", ["sub", "u", "l"]), ("splitn", ["u_mid"]), ("rsplitn", ["u_mid"])]
+    for trial in range(6):
+        a = "".join(rnd.choice("abx") for _ in range(rnd.randint(1, 8)))
+        pt = "".join(rnd.choice("abx") for _ in range(rnd.randint(0, 2)))
+        a_pad, p_pad = rnd.choice([None, len(a) + 2]), rnd.choice([None, len(pt) + 1])
+        A, P, SUB = string_blocks(a, a_pad), string_blocks(pt, p_pad), string_blocks("Z")
+        U = np.array([2, 0, 0, 0], dtype=np.int64)
+        sa, sp = len(A) // 4, len(P) // 4
+        found = prog("find_all_range", [sa, sp, 0, sa - 1], bu).run_plain(np.concatenate([A, P]).astype("int64"))
+        for op, extra in ops:
+            if extra == ["u_mid"]:          # signature SUS: (self, n, pattern)
+                shape, ins = [sa, sp], [A, U, P]
+            else:
+                shape, ins = [sa, sp], [A, P]
+                for x in extra:
+                    if x == "sub":
+                        shape.append(len(SUB) // 4)
+                        ins.append(SUB)
+                    elif x == "u":
+                        ins.append(U)
+                    else:
+                        shape.append(len(a) + 4)
+            for suffix in ("", "_logdepth"):
+                mono = prog(op + suffix, shape, bu).run_plain(np.concatenate(ins).astype("int64"))
+                rest = prog(op + ".rest" + suffix, shape, bu).run_plain(np.concatenate(ins + [found]).astype("int64"))
+                assert list(mono % 4) == list(rest % 4), (a, a_pad, pt, p_pad, op, suffix)
+    with pytest.raises(Exception):
+        prog("len.rest", [4], bu)       # no (self, pattern): nothing to hand in
