@@ -45,15 +45,20 @@ void host_fft_tables(int N, std::vector<double> &twist, std::vector<double> &tw)
     twist[2 * j] = (double)cosl(a);
     twist[2 * j + 1] = (double)sinl(a);
   }
+  // exactly symmetric under quarter turns: tw[t + M/4] = -i * tw[t] = (tw[t].im, -tw[t].re) bit for bit;
+  // the kernels derive those entries from their partners instead of loading them.  Exact values at the trivial angles.
   for (int t = 0; t < M / 2; t++) {
+    if (M >= 4 && t >= M / 4) {
+      tw[2 * t] = tw[2 * (t - M / 4) + 1];
+      tw[2 * t + 1] = -tw[2 * (t - M / 4)];
+      continue;
+    }
     long double a = -2.0L * pi * (long double)t / (long double)M;
     tw[2 * t] = (double)cosl(a);
     tw[2 * t + 1] = (double)sinl(a);
+    if (t == 0) { tw[0] = 1.0; tw[1] = 0.0; }
   }
-  // exact values at the trivial angles
   twist[0] = 1.0; twist[1] = 0.0;
-  tw[0] = 1.0; tw[1] = 0.0;
-  if (M >= 4) { tw[2 * (M / 4)] = 0.0; tw[2 * (M / 4) + 1] = -1.0; }
 }
 
 // Tables of the forward transform (same values as the oracle: cosl / sinl in long double, exact entries at
@@ -68,15 +73,18 @@ void host_fwd_tables(int N, std::vector<double> &root, std::vector<double> &psi,
   while ((1 << logm) < M) logm++;
   root.assign((size_t)4 * N, 0.0);
   const long double pi = 3.14159265358979323846264338327950288L;
+  // root[t + N/2] = i * root[t] = (-root[t].im, root[t].re), bit for bit: only the first quadrant comes from cosl / sinl
   for (int t = 0; t < 2 * N; t++) {
+    if (t >= N / 2) {
+      root[2 * t] = -root[2 * (t - N / 2) + 1];
+      root[2 * t + 1] = root[2 * (t - N / 2)];
+      continue;
+    }
     const long double a = pi * (long double)t / (long double)N;
     root[2 * t] = (double)cosl(a);
     root[2 * t + 1] = (double)sinl(a);
+    if (t == 0) { root[0] = 1.0; root[1] = 0.0; }
   }
-  root[0] = 1.0; root[1] = 0.0;
-  root[2 * (N / 2)] = 0.0; root[2 * (N / 2) + 1] = 1.0;
-  root[2 * N] = -1.0; root[2 * N + 1] = 0.0;
-  root[2 * (3 * N / 2)] = 0.0; root[2 * (3 * N / 2) + 1] = -1.0;
   auto slot_exp = [&](int m) {
     int f = 0;
     for (int b = 0; b < logm; b++) f |= ((m >> b) & 1) << (logm - 1 - b);

@@ -847,15 +847,25 @@ __device__ __forceinline__ void fft_butterflies_reg(double2 (&x)[8], const doubl
 // the 7 forward twiddles of the 3-bit pass that owns index bits [LO, LO+3) from a table laid out like psi
 // (T[2^l + b]); h = q >> LO are the index bits above the pass.  Pass A (LO = LOGM-3) has h = 0 for every
 // thread: uniform addresses.
-template <int LOGM, int LO>
+// -i * w as a value: (w.y, -w.x).  The tables are exactly symmetric under quarter turns, so a twiddle whose
+// angle is a quarter turn behind a loaded one is this -- the negation rides on the FMA's source modifier.
+__device__ __forceinline__ double2 mul_neg_i(double2 w) { return make_double2(w.y, -w.x); }
+
+// Four loads instead of seven (round 3): the twiddle of block 2b+1 is -i times the twiddle of block 2b (their exponents
+// differ by N/2: E(m) = 1 - 4 bitrev(m), the block's lowest index bit becomes the highest bit of the reversed index).
+// DERIVE = false loads all seven (the multi-bit kernel: measured 1.9 % slower with the derived form, its limit is the key
+// stream, not the LDS pipe; same values either way).
+template <int LOGM, int LO, bool DERIVE = true>
 __device__ __forceinline__ void load_fwd_twiddles(double2 (&w)[7], int q, const double2 *T) {
   constexpr int L0 = LOGM - 3 - LO;
   const int h = q >> LO;
   w[0] = T[(1 << L0) + h];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) w[1 + k] = T[(2 << L0) + 2 * h + k];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) w[3 + k] = T[(4 << L0) + 4 * h + k];
+  w[1] = T[(2 << L0) + 2 * h];
+  w[2] = DERIVE ? mul_neg_i(w[1]) : T[(2 << L0) + 2 * h + 1];
+  w[3] = T[(4 << L0) + 4 * h];
+  w[4] = DERIVE ? mul_neg_i(w[3]) : T[(4 << L0) + 4 * h + 1];
+  w[5] = T[(4 << L0) + 4 * h + 2];
+  w[6] = DERIVE ? mul_neg_i(w[5]) : T[(4 << L0) + 4 * h + 3];
 }
 
 template <int LOGM, int LO>
@@ -887,6 +897,9 @@ __device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t rs, unsign
 // the 7 twiddles of a 3-bit INVERSE pass from the LDS stage tables T[2^beta + j] = tw[j << (LOGM-1-beta)]
 // (same values and order as load_pass_twiddles): issued BEFORE the barrier that precedes the pass, so that
 // only the data reads remain on the critical path after it
+// Four loads instead of seven (round 3): setting the pass's second register bit moves a twiddle index by M/4, a quarter turn,
+// for the top stage (w[2] = -i w[0], w[3] = -i w[1]), setting its first register bit does the same for the middle stage
+// (w[5] = -i w[4]); the tables are exactly symmetric (mul_neg_i).  `wtop`: entries 0 and 1 are used.
 template <int LOGM, int LO>
 __device__ __forceinline__ void load_pass_twiddles_tab(double2 (&w)[7], int q, const double2 *T, const double2 (&wtop)[4]) {
 #pragma unroll
@@ -894,7 +907,9 @@ __device__ __forceinline__ void load_pass_twiddles_tab(double2 (&w)[7], int q, c
     const int fb = k < 4 ? 2 : (k < 6 ? 1 : 0);
     const int e = k < 4 ? k : (k < 6 ? (k - 4) : 0);
     const int beta = LO + fb;
-    if (beta == LOGM - 1) w[k] = wtop[e & 3];
+    if (k == 2 || k == 3) w[k] = mul_neg_i(w[k - 2]);
+    else if (k == 5) w[k] = mul_neg_i(w[4]);
+    else if (beta == LOGM - 1) w[k] = wtop[e & 3];
     else w[k] = T[(1 << beta) + (fft_point<LOGM, LO, 3>(q, e) & ((1 << beta) - 1))];
   }
 }
@@ -1172,9 +1187,9 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     double2 twi[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) twi[e] = buf_load_d2(rs_ti, voff_q, (unsigned)(e * TP * 16));
-    double2 wtop[4];
+    double2 wtop[4] = {};  // entries 2 and 3 are quarter turns of 0 and 1 (load_pass_twiddles_tab derives them)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wtop[e] = buf_load_d2(rs_twg, voff_q, (unsigned)(e * TP * 16));
+    for (int e = 0; e < 2; ++e) wtop[e] = buf_load_d2(rs_twg, voff_q, (unsigned)(e * TP * 16));
 
     if (PRIO != 5) fft_stage_bit0_dpp(x, sgn);
     if (NP == 3) {
@@ -1276,7 +1291,7 @@ __device__ __forceinline__ void fft_butterflies_tab_all(double2 (&x)[8], int q, 
 template <int LOGM, int LO>
 __device__ __forceinline__ void fft_fwd_butterflies_tab(double2 (&x)[8], int q, const double2 *TF) {
   double2 w[7];
-  load_fwd_twiddles<LOGM, LO>(w, q, TF);
+  load_fwd_twiddles<LOGM, LO, false>(w, q, TF);
   fft_butterflies_reg<true>(x, w);
 }
 

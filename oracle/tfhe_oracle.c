@@ -165,16 +165,22 @@ oracle_ctx *oracle_ctx_create(const oracle_params *p) {
     c->twist[j].re = (double)cosl(a);
     c->twist[j].im = (double)sinl(a);
   }
+  /* Tables are EXACTLY symmetric under quarter turns (round 3): tw[t + M/4] = -i * tw[t] = (tw[t].im, -tw[t].re)
+   * as doubles, bit for bit -- only the first quarter comes from cosl / sinl --, so that an implementation may derive
+   * those entries from their partners instead of loading them.  Exact values at the trivial angles, so that
+   * "multiply by 1 / by -i" may be skipped without changing a numeric value. */
   for (int t = 0; t < c->M / 2; t++) {
+    if (c->M >= 4 && t >= c->M / 4) {
+      c->tw[t].re = c->tw[t - c->M / 4].im;
+      c->tw[t].im = -c->tw[t - c->M / 4].re;
+      continue;
+    }
     long double a = -2.0L * pi * (long double)t / (long double)c->M;
     c->tw[t].re = (double)cosl(a);
     c->tw[t].im = (double)sinl(a);
+    if (t == 0) { c->tw[0].re = 1.0; c->tw[0].im = 0.0; }
   }
-  /* exact values at the trivial angles, so that "multiply by 1 / by -i" may be
-   * skipped by an implementation without changing a single bit */
   c->twist[0].re = 1.0; c->twist[0].im = 0.0;
-  c->tw[0].re = 1.0; c->tw[0].im = 0.0;
-  if (c->M >= 4) { c->tw[c->M / 4].re = 0.0; c->tw[c->M / 4].im = -1.0; }
   c->g = p->grouping_factor > 1 ? p->grouping_factor : 1;
   if (c->g > 3 || c->n % c->g) { oracle_ctx_destroy(c); return NULL; }
   c->psi = (cplx *)calloc(c->M, sizeof(cplx));
@@ -186,15 +192,18 @@ oracle_ctx *oracle_ctx_create(const oracle_params *p) {
    * spectrum root[(slot_exp[m] * d) mod 2N] with root[t] = exp(i pi t / N). */
   c->root = (cplx *)malloc(sizeof(cplx) * 2 * c->N);
   c->slot_exp = (int32_t *)malloc(sizeof(int32_t) * c->M);
+  /* root[t + N/2] = i * root[t] = (-root[t].im, root[t].re), bit for bit: only the first quadrant comes from cosl / sinl */
   for (int t = 0; t < 2 * c->N; t++) {
+    if (t >= c->N / 2) {
+      c->root[t].re = -c->root[t - c->N / 2].im;
+      c->root[t].im = c->root[t - c->N / 2].re;
+      continue;
+    }
     long double a = pi * (long double)t / (long double)c->N;
     c->root[t].re = (double)cosl(a);
     c->root[t].im = (double)sinl(a);
+    if (t == 0) { c->root[0].re = 1.0; c->root[0].im = 0.0; }
   }
-  c->root[0].re = 1.0; c->root[0].im = 0.0;
-  c->root[c->N / 2].re = 0.0; c->root[c->N / 2].im = 1.0;
-  c->root[c->N].re = -1.0; c->root[c->N].im = 0.0;
-  c->root[3 * c->N / 2].re = 0.0; c->root[3 * c->N / 2].im = -1.0;
   int logm = 0;
   while ((1 << logm) < c->M) logm++;
   for (int m = 0; m < c->M; m++) {
