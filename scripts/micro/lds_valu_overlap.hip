@@ -16,6 +16,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define FMA8 asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b))
 #define WR(off) asm volatile("ds_write_b128 %0, %1 offset:" #off :: "v"(addr), "v"(wv) : "memory")
+#define WR64(off) asm volatile("ds_write_b64 %0, %1 offset:" #off "\n ds_write_b64 %0, %2 offset:" #off "+8" :: "v"(addr), "v"(wlo), "v"(whi) : "memory")
 #define RD(dst, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
 
 #define RDALL if (NR >= 1) RD(r0, 0); if (NR >= 2) RD(r1, 8192); if (NR >= 3) RD(r2, 16384); if (NR >= 4) RD(r3, 24576); \
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(512) void k(unsigned long long *stamps, double *sin
   const unsigned addr = threadIdx.x * 16u;  // 512 threads x 16 B = 8 KB per "row"; offsets step 8 KB
   u32x4 wv = {threadIdx.x, 1u, 2u, 3u};
   u32x4 r0 = {}, r1 = {}, r2 = {}, r3 = {};
+  const unsigned long long wlo = threadIdx.x, whi = threadIdx.x * 3ull;
   const bool do_fma = MODE == 0 || MODE == 2 || MODE == 4 || (MODE == 3 && threadIdx.x < 256);
   const bool do_lds = MODE == 1 || MODE == 2 || MODE == 4 || (MODE == 3 && threadIdx.x >= 256);
   __syncthreads();
@@ -61,6 +63,9 @@ __global__ __launch_bounds__(512) void k(unsigned long long *stamps, double *sin
       if (NR >= 8) RD(r3, 57344);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __syncthreads();
+    } else if (MODE == 7) {  // LDS only, every 16-byte store as two ds_write_b64 (same bytes as mode 1 with NW stores, no loads)
+      WR64(0); WR64(8192); WR64(16384); WR64(24576); WR64(32768); WR64(40960); WR64(49152); WR64(57344);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else if (MODE == 3) {
       if (threadIdx.x < 256) { FMA8; FMA8; FMA8; FMA8; FMA8; FMA8; FMA8; FMA8; }
       else { WRALL; RDALL; }
@@ -172,6 +177,7 @@ int main() {
   run<4, 8, 8, 20>(d_st, d_sink, n_cu);
   run<5, 8, 8, 20>(d_st, d_sink, n_cu);
   run<6, 8, 8, 20>(d_st, d_sink, n_cu);
+  run<7, 8, 0>(d_st, d_sink, n_cu);
   run<1, 8, 0>(d_st, d_sink, n_cu);
   run<2, 8, 0>(d_st, d_sink, n_cu);
   run<1, 0, 8>(d_st, d_sink, n_cu);
