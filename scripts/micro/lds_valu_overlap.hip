@@ -28,6 +28,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
               if (NW >= 5) WR(32768); if (NW >= 6) WR(40960); if (NW >= 7) WR(49152); if (NW >= 8) WR(57344); \
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+#define RDRAW if (NR >= 1) RD(r0, 0); if (NR >= 2) RD(r1, 8192); if (NR >= 3) RD(r2, 16384); if (NR >= 4) RD(r3, 24576); \
+              if (NR >= 5) RD(r0, 32768); if (NR >= 6) RD(r1, 40960); if (NR >= 7) RD(r2, 49152); if (NR >= 8) RD(r3, 57344); \
+              if (NR >= 9) RD(r0, 4096); if (NR >= 10) RD(r1, 12288); if (NR >= 11) RD(r2, 20480); if (NR >= 12) RD(r3, 28672); \
+              if (NR >= 13) RD(r0, 36864); if (NR >= 14) RD(r1, 45056)
+#define WRRAW if (NW >= 1) WR(0); if (NW >= 2) WR(8192); if (NW >= 3) WR(16384); if (NW >= 4) WR(24576); \
+              if (NW >= 5) WR(32768); if (NW >= 6) WR(40960); if (NW >= 7) WR(49152); if (NW >= 8) WR(57344)
+
+#define FMAH _Pragma("unroll") for (int f = 0; f < NF / 2; ++f) { FMA8; }
 template <int MODE, int NW, int NR, int NF = 8>
 __global__ __launch_bounds__(512) void k(unsigned long long *stamps, double *sink, int iters, double a, double b) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -36,7 +44,7 @@ __global__ __launch_bounds__(512) void k(unsigned long long *stamps, double *sin
   u32x4 wv = {threadIdx.x, 1u, 2u, 3u};
   u32x4 r0 = {}, r1 = {}, r2 = {}, r3 = {};
   const unsigned long long wlo = threadIdx.x, whi = threadIdx.x * 3ull;
-  const bool do_fma = MODE == 0 || MODE == 2 || MODE == 4 || (MODE == 3 && threadIdx.x < 256);
+  const bool do_fma = MODE == 0 || MODE == 2 || MODE == 4 || MODE == 8 || (MODE == 3 && threadIdx.x < 256);
   const bool do_lds = MODE == 1 || MODE == 2 || MODE == 4 || (MODE == 3 && threadIdx.x >= 256);
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -66,6 +74,26 @@ __global__ __launch_bounds__(512) void k(unsigned long long *stamps, double *sin
     } else if (MODE == 7) {  // LDS only, every 16-byte store as two ds_write_b64 (same bytes as mode 1 with NW stores, no loads)
       WR64(0); WR64(8192); WR64(16384); WR64(24576); WR64(32768); WR64(40960); WR64(49152); WR64(57344);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (MODE == 8) {
+      // ONE wave per SIMD carrying TWO independent streams A and B half a step apart (software pipeline): every store
+      // burst gets half an arithmetic block to drain before the barrier that publishes it, every load burst half a
+      // block (plus the other stream's store issue) to land before its first use.  Work per iteration and wave: 2 x NF
+      // FMA8, 2 x NW stores, 2 x NR loads -- what TWO waves do in mode 4.
+      // LDS queue of a wave (in order): ... La | Sb | Lb | Sa | La | ...
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // La landed (Sb may be in flight)
+      FMAH;                                                // Va.1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // Sb complete
+      __builtin_amdgcn_s_barrier();
+      RDRAW;                                               // Lb
+      FMAH;                                                // Va.2
+      WRRAW;                                               // Sa
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // Lb landed
+      FMAH;                                                // Vb.1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // Sa complete
+      __builtin_amdgcn_s_barrier();
+      RDRAW;                                               // La
+      FMAH;                                                // Vb.2
+      WRRAW;                                               // Sb
     } else if (MODE == 3) {
       if (threadIdx.x < 256) { FMA8; FMA8; FMA8; FMA8; FMA8; FMA8; FMA8; FMA8; }
       else { WRALL; RDALL; }
@@ -73,7 +101,6 @@ __global__ __launch_bounds__(512) void k(unsigned long long *stamps, double *sin
       // two teams (waves 0-3 / 4-7) half a phase apart, every barrier shared: in each interval one team reads and
       // runs the first half of its arithmetic while the other runs its second half and writes.
       // MODE 6: same stream, both teams in phase (R, V, W together): the lockstep reference with the same barriers.
-#define FMAH _Pragma("unroll") for (int f = 0; f < NF / 2; ++f) { FMA8; }
       if (MODE == 6 || threadIdx.x < 256) {
         RDALL; FMAH;
         __builtin_amdgcn_s_barrier();
@@ -130,7 +157,7 @@ static void run(unsigned long long *d_st, double *d_sink, int n_cu) {
   float ms = 0;
   for (int rep = 0; rep < 3; rep++) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(n_cu), dim3(512), 65536, 0, d_st, d_sink, iters, 1.0000001, 1e-9);
+    hipLaunchKernelGGL(kern, dim3(n_cu), dim3(MODE == 8 ? 256 : 512), 65536, 0, d_st, d_sink, iters, 1.0000001, 1e-9);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
@@ -144,7 +171,7 @@ static void run(unsigned long long *d_st, double *d_sink, int n_cu) {
   std::sort(hi.begin(), hi.end());
   printf("{\"mode\": %d, \"writes_b128\": %d, \"reads_b128\": %d, \"fma_f64\": %d, \"cycles_per_iter_waves0_3\": %.1f, "
          "\"cycles_per_iter_waves4_7\": %.1f, \"wall_ms\": %.3f}\n",
-         MODE, NW, NR, MODE == 0 || MODE == 4 || MODE == 5 || MODE == 6 ? NF * 8 : 64, lo[lo.size() / 2], hi[hi.size() / 2], ms);
+         MODE, NW, NR, MODE == 8 ? NF * 16 : (MODE == 0 || MODE == 4 || MODE == 5 || MODE == 6 ? NF * 8 : 64), lo[lo.size() / 2], hi[hi.size() / 2], ms);
   fflush(stdout);
 }
 
@@ -177,6 +204,10 @@ int main() {
   run<4, 8, 8, 20>(d_st, d_sink, n_cu);
   run<5, 8, 8, 20>(d_st, d_sink, n_cu);
   run<6, 8, 8, 20>(d_st, d_sink, n_cu);
+  // software pipeline of two streams in one wave per SIMD (mode 8) against the burst structure with two waves per SIMD (mode 4)
+  run<8, 8, 14, 20>(d_st, d_sink, n_cu);
+  run<8, 8, 8, 20>(d_st, d_sink, n_cu);
+  run<8, 8, 8, 8>(d_st, d_sink, n_cu);
   run<7, 8, 0>(d_st, d_sink, n_cu);
   run<1, 8, 0>(d_st, d_sink, n_cu);
   run<2, 8, 0>(d_st, d_sink, n_cu);
