@@ -1019,6 +1019,11 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
   if (v < 0 || (v > 10 && v != 12)) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
+  if (v == 9 || v == 10) {  // timing-only ablations compute WRONG results: a developer has to ask for them by name
+    const char *e = getenv("FHES_DEV_ABLATIONS");
+    if (!e || std::string(e) != "1")
+      return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variants 9 / 10 are timing-only ablations with wrong results (set FHES_DEV_ABLATIONS=1)");
+  }
   ctx->br_variant = v;
   return FHES_OK;
 }

@@ -168,7 +168,8 @@ int fhes_reset_stats(fhes_ctx *ctx);
 int fhes_set_timing(fhes_ctx *ctx, int32_t enabled);
 /* blind-rotate kernel selection for A/B benchmarking: 0 = auto (variant 5), 1 = simple kernel, 5 = throughput
  * kernel, 6 / 7 = 5 with other wave-priority policies (all produce the same bits; multi-bit sets: 2 = latency
- * build, 3 = throughput build) */
+ * build, 3 = throughput build; 12 = the generic kernel on a 2_2 set.  9 / 10 are timing-only ablations with WRONG
+ * results and are refused unless FHES_DEV_ABLATIONS=1 is in the environment) */
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t br_variant);
 /* test hooks: Fourier BSK in the oracle's canonical order [n][L][k+1][k+1][N/2][2];
  * FFT tables twist[N/2][2], twiddle[N/4][2]. */

@@ -1,5 +1,6 @@
 """GPU parity of the Level-0 kernels against the CPU oracle (bit-exact), through the C ABI."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -168,6 +169,10 @@ def test_all_blind_rotate_variants_agree(libs):
                 first = res
             else:
                 assert np.array_equal(res, first), f"variant {variant} differs from variant 1"
+        # the timing-only ablation builds (wrong results by construction) are refused unless a developer asks by name
+        if os.environ.get("FHES_DEV_ABLATIONS") != "1":
+            for variant in (9, 10):
+                assert w.lib.fhes_set_kernel_variant(ctx, variant) != 0
     finally:
         check(w.lib.fhes_set_kernel_variant(ctx, 0))
     check(w.lib.fhes_arena_free(ctx, h_in, count))
