@@ -95,6 +95,7 @@ struct fhes_ctx {
   double2 *bsk_e = nullptr;  // engine layout for blind-rotate variants 2/3 and multi-bit: [n_ggsw][2][2][8][M/8]
   double2 *twist = nullptr, *tw = nullptr;
   double2 *twist_inv = nullptr;  // twist * (2/N): untwist factors with the inverse-FFT scale folded in
+  double2 *twist_inv64 = nullptr;  // the same * 2^-64 (variant 5: torus_from_f64_pair takes y * 2^-64)
   double2 *root = nullptr;       // exp(i*pi*t/N), t < 2N (multi-bit: Fourier image of a monomial)
   double2 *psi = nullptr;        // [M] forward twiddles: psi[2^l + b] = block b of the stage with 2^l blocks
   double2 *odd_fix = nullptr;    // [M] odd slots: factor applied to the Fourier key (see dev::fwd_butterfly_last)

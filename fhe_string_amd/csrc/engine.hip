@@ -509,7 +509,7 @@ static int launch_br_v5(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena,
                      ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
-                     ctx->lut_polys, ctx->twist_inv, ctx->tw, ctx->psi, ctx->cdpp);
+                     ctx->lut_polys, ctx->twist_inv64, ctx->tw, ctx->psi, ctx->cdpp);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
@@ -772,6 +772,9 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
     for (auto &v : ti) v *= 1.0 / (double)d.M;  // power of two: exact
     if ((e = hipMalloc(&ctx->twist_inv, ti.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(twist_inv)");
     if ((e = hipMemcpy(ctx->twist_inv, ti.data(), ti.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy twist_inv");
+    for (auto &v : ti) v *= 0x1p-64;  // variant 5 rounds y * 2^-64 to the torus (torus_from_f64_pair): exact as well
+    if ((e = hipMalloc(&ctx->twist_inv64, ti.size() * 8)) != hipSuccess) return bail(e, "hipMalloc(twist_inv64)");
+    if ((e = hipMemcpy(ctx->twist_inv64, ti.data(), ti.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "copy twist_inv64");
   }
   {  // forward-transform tables; root also gives the Fourier images of monomials (multi-bit)
     std::vector<double> root, psi, odd_fix, cdpp;
@@ -803,7 +806,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
-  (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->root); (void)hipFree(ctx->psi); (void)hipFree(ctx->odd_fix); (void)hipFree(ctx->cdpp); (void)hipFree(ctx->lut_polys);
+  (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->twist_inv64); (void)hipFree(ctx->root); (void)hipFree(ctx->psi); (void)hipFree(ctx->odd_fix); (void)hipFree(ctx->cdpp); (void)hipFree(ctx->lut_polys);
   (void)hipDeviceSynchronize();
   auto drop_lane = [](Lane &l) {
     (void)hipFree(l.ks_out); (void)hipFree(l.ks_dig); (void)hipFree(l.ks_body); (void)hipFree(l.slot_map); (void)hipFree(l.gen_scratch);

@@ -954,16 +954,20 @@ __device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b) {  // one inst
   asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-// rint(y) mod 2^64 as in torus_from_f64_fast, returned so that ONE 64-bit add consumes it
-__device__ __forceinline__ uint64_t torus_from_f64_pair(double y) {
-  const double C0 = 0x1.8p116, C1 = 0x1.8p84, C2 = 0x1.8p52;
-  const double h0 = (y + C0) - C0;
-  const double z = y - h0;
+// rint(y) mod 2^64 as in torus_from_f64_fast, returned so that ONE 64-bit add consumes it.  The argument is
+// ys = y * 2^-64 (the scale rides in the untwist factors: a power of two, every product and FMA scales exactly), which
+// makes the reduction mod 2^64 "ys - rint(ys)" (v_rndne_f64: the same nearest multiple, ties to even, as the
+// (y + 1.5*2^116) - 1.5*2^116 of the unscaled form) -- 6 f64 operations instead of 7 -- and the three integer
+// operations of the borrow one: with t2 = rem + 1.5*2^-12 the high dword of t2 is 0x3F380000 (rem >= 0) or 0x3F37FFFF
+// (rem < 0: borrow one from the high word), so adding it to the low mantissa dword of t1 = z + (1.5*2^20 + K * 2^-32),
+// K = -0x3F380000 mod 2^32, gives the high word directly (K is even: ties of t1 round as before).
+__device__ __forceinline__ uint64_t torus_from_f64_pair(double ys) {
+  const double C1 = 0x1.8p20 + 3234332672.0 /* 0xC0C80000 */ * 0x1p-32, C2 = 0x1.8p-12;
+  const double z = ys - __builtin_rint(ys);  // exact, |z| <= 1/2
   const double t1 = z + C1;
   const double rem = z - (t1 - C1);
   const double t2 = rem + C2;
-  // high dword: low mantissa dword of t1 + (0 or -1 from the sign of rem); low dword: that of t2
-  uint32_t hi = (uint32_t)__double2loint(t1) + (((uint32_t)__double2hiint(t2) & 0xFFFFFu) - 0x80000u);
+  uint32_t hi = (uint32_t)__double2loint(t1) + (uint32_t)__double2hiint(t2);
   asm("" : "+v"(hi));  // opaque: keeps the compiler from spreading (a + b) << 32 over several 64-bit adds
   return ((uint64_t)hi << 32) | (uint64_t)(uint32_t)__double2loint(t2);
 }
@@ -992,7 +996,7 @@ template <int LOGN, int BL, int PRIO>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v5_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
     int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
-    const double2 *__restrict__ twist_inv /* twist / M */, const double2 *__restrict__ tw,
+    const double2 *__restrict__ twist_inv /* twist / (M * 2^64): torus_from_f64_pair */, const double2 *__restrict__ tw,
     const double2 *__restrict__ psi /* forward twiddles [M] */, const double2 *__restrict__ cdpp /* [8][M/8] */) {
   constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
   constexpr int NP = (LOGM - 1) / 3;
@@ -1014,7 +1018,9 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   // keyswitch output through the scalar cache, one iteration ahead)
 
   const int tid = threadIdx.x;
-  const int r = tid / TP;
+  // the half (output polynomial) of this thread; with TP >= 64 a wave lies inside one half: r in an SGPR, the two
+  // forms of the multiply-accumulate behind a scalar branch (left as a vector value the compiler turned them into 64 selects)
+  const int r = TP >= 64 ? __builtin_amdgcn_readfirstlane(tid / TP) : tid / TP;
   const int q = tid % TP;
   const double sgn = (q & 1) ? -1.0 : 1.0;
   const int vidx = d.v0 + blockIdx.x;
@@ -1079,11 +1085,19 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_REG_HW_ID.WAVE_ID: slot inside the SIMD
     if (slot & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
   }
+  auto modswitch_of = [&](uint64_t w) __attribute__((always_inline)) {
+    return (int)((((w >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  };
   int a_next = modswitch(0);
   for (int i = 0; i < n_small; ++i) {
     const int a = a_next;
-    a_next = modswitch(i + 1);  // requested one iteration ahead: off the critical path (the row has n+1 words)
-    if (a == 0) continue;
+    // the next mask word is requested one iteration ahead (the row has n+1 words) and turned into a_next just before
+    // barrier B1, where the wave waits for its LDS operations anyway: left to itself the compiler kept the raw word and
+    // re-used its registers for the result at the head of the next iteration -- a scalar-load round trip (a
+    // write-after-write wait) in front of every iteration's first instruction.
+    // a == 0 is not skipped (one iteration in 2N): the digits of X^0 acc - acc are all zero, every transform of zeros
+    // is zero and the accumulator receives rint(0) -- the same bits as the oracle's skip, and the loop stays one block.
+    const uint64_t ks_next = ks[i + 1];
 
     double2 x[8];
     {
@@ -1096,21 +1110,30 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       // fswz XORs index bits 4..6 into bits 1..3: byte-offset bits 8..10 into 5..7.  With TP >= 128 the points of
       // a thread differ in index bits >= 7 only, so the term is the same for all of them
       const unsigned swz_all = (sb >> 3) & 0xE0u;
+      // all sixteen rotated reads go out as ONE burst before the first digit is formed (round 3: the compiler's own
+      // order was read, wait, use, pair by pair -- eight exposed LDS round trips at the head of every iteration)
+      uint64_t va[8], vb[8];
+      int hmv[8], m0v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const unsigned se = sb + (unsigned)(e * TP * 16);
         const unsigned swz = TP >= 128 ? swz_all : ((se >> 3) & 0xE0u);
-        const int hm = __builtin_amdgcn_sbfe(se, LOGM + 4, 1);       // -1 when h = 0 reads the upper component
-        const unsigned off0 = ((se & (unsigned)((M - 1) << 4)) ^ swz) | ((unsigned)hm & 8u);
-        const uint64_t va = *reinterpret_cast<const uint64_t *>(ybytes + off0);
-        const uint64_t vb = *reinterpret_cast<const uint64_t *>(ybytes + (off0 ^ 8u));
-        const int m0 = __builtin_amdgcn_sbfe(se, LOGM + 5, 1);       // h = 0: 0 take image, -1 take -image
-        const int m1 = m0 ^ hm;                                      // h = 1: adding M carries into the wrap bit iff hm
+        hmv[e] = __builtin_amdgcn_sbfe(se, LOGM + 4, 1);             // -1 when h = 0 reads the upper component
+        m0v[e] = __builtin_amdgcn_sbfe(se, LOGM + 5, 1);             // h = 0: 0 take image, -1 take -image
+        const unsigned off0 = ((se & (unsigned)((M - 1) << 4)) ^ swz) | ((unsigned)hmv[e] & 8u);
+        va[e] = *reinterpret_cast<const uint64_t *>(ybytes + off0);
+        vb[e] = *reinterpret_cast<const uint64_t *>(ybytes + (off0 ^ 8u));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m0 = m0v[e];
+        const int m1 = m0 ^ hmv[e];                                  // h = 1: adding M carries into the wrap bit iff hm
         uint64_t dd[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int m32 = h == 0 ? m0 : m1;
-          const uint64_t v = h == 0 ? va : vb;
+          const uint64_t v = h == 0 ? va[e] : vb[e];
           const uint64_t mm = ((uint64_t)(uint32_t)m32 << 32) | (uint64_t)(uint32_t)m32;  // both dwords: m32 is 0 or -1
           const uint64_t kk = ROUND | (uint64_t)(uint32_t)(m32 & 1);   // carry of the negation + rounding bit of the digit
           dd[h] = add64(add64(v ^ mm, h == 0 ? nlo[e] : nhi[e]), kk);
@@ -1137,6 +1160,8 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       for (int e = 0; e < 8; ++e) x_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))] = x[e];
     }
     load_fwd_twiddles<LOGM, LO_B>(w, q, TF);
+    a_next = modswitch_of(ks_next);
+    asm volatile("" : "+s"(a_next));  // materialised here, not at the head of the next iteration
     __syncthreads();  // B1 (also: every rotated read of Y is done)
     if (PRIO == 0) __builtin_amdgcn_s_setprio(0);
     // constants of the lane-pair stage: requested here, consumed after the remaining register passes
@@ -1147,6 +1172,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     if (PRIO != 4) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = x_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+      __builtin_amdgcn_sched_barrier(0);  // all eight reads of the exchange go out before the first butterfly
     }
     FHES_PASS(true, x, w);
     if (NP == 3) {
@@ -1159,6 +1185,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       if (PRIO != 4) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
+        __builtin_amdgcn_sched_barrier(0);  // all eight reads of the exchange go out before the first butterfly
       }
       FHES_PASS(true, x, w);
     }
@@ -1177,12 +1204,26 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     if (PRIO == 4) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], x[e], g0[e], g1[e]);
-    } else if (r == 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], x_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], g0[e], g1[e]);
     } else {
+      // the other half's spectrum as ONE burst of reads (left to the compiler: read two, wait, multiply, four times over),
+      // inside each form: hoisted above the branch, the two forms are merged behind register shuffles or selects
+      if (r == 0) {
+        double2 oth[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))], x[e], g0[e], g1[e]);
+        for (int e = 0; e < 8; ++e) oth[e] = x_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], oth[e], g0[e], g1[e]);
+        asm volatile("; end of form r = 0");  // two DIFFERENT closing statements: nothing above them can be sunk into a common tail
+      } else {
+        double2 oth[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) oth[e] = x_o[fswz(fft_point<LOGM, LO_C, 3>(q, e))];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = ext_mac(oth[e], x[e], g0[e], g1[e]);
+        asm volatile("; end of form r = 1");
+      }
     }
     double2 twi[8];
 #pragma unroll
@@ -1203,6 +1244,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       if (PRIO != 4) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_B, 3>(q, e))];
+        __builtin_amdgcn_sched_barrier(0);  // all eight reads of the exchange go out before the first butterfly
       }
       FHES_PASS(false, x, w);
     } else {
@@ -1220,6 +1262,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     if (PRIO != 4) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = y_r[fswz(fft_point<LOGM, LO_A, 3>(q, e))];
+      __builtin_amdgcn_sched_barrier(0);  // all eight reads of the exchange go out before the first butterfly
     }
     FHES_PASS(false, x, w);
 
