@@ -992,6 +992,7 @@ __device__ __forceinline__ int image_word(int j) {
 // 4 = without the LDS exchanges between the passes (rotated reads, table reads and the image write-back stay),
 // 5 = without the butterfly passes and lane-pair stages (every LDS operation stays).
 #define FHES_PASS(FWD, x, w) do { if (PRIO != 5) fft_butterflies_reg<FWD>(x, w); } while (0)
+typedef const uint64_t __attribute__((address_space(3))) *lds_u64_ptr;
 template <int LOGN, int BL, int PRIO>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2) void blind_rotate_v5_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
@@ -1017,6 +1018,9 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   // (no room for anything else: 2 x 80 KB fill the CU's LDS; the switched mask a~_i is read from the
   // keyswitch output through the scalar cache, one iteration ahead)
 
+  // byte address of the dynamic LDS block (0: the kernel has no static LDS; the rotated reads OR it into their offsets)
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
+  if (lds0 & (unsigned)(2 * N * 8 - 1)) __builtin_trap();  // the OR needs the block on a multiple of the image size
   const int tid = threadIdx.x;
   // the half (output polynomial) of this thread; with TP >= 64 a wave lies inside one half: r in an SGPR, the two
   // forms of the multiply-accumulate behind a scalar branch (left as a vector value the compiler turned them into 64 selects)
@@ -1075,7 +1079,6 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   double2 *x_r = xbuf + (size_t)r * SLOTS;
   const double2 *x_o = xbuf + (size_t)(1 - r) * SLOTS;
   double2 *y_r = ybuf + (size_t)r * M;
-  const unsigned char *ybytes = smem_raw + (size_t)r * M * 16;  // image of polynomial r
 
   // closest-representable digit of x with the rounding bit already added to x:
   // (int)hi >> (32 - BL)
@@ -1097,8 +1100,6 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
     // write-after-write wait) in front of every iteration's first instruction.
     // a == 0 is not skipped (one iteration in 2N): the digits of X^0 acc - acc are all zero, every transform of zeros
     // is zero and the accumulator receives rint(0) -- the same bits as the oracle's skip, and the loop stays one block.
-    const uint64_t ks_next = ks[i + 1];
-
     double2 x[8];
     {
       // rotated coefficient s = (p - a) mod 2N of the own point p = q + e*TP (h = 0) and of p + M (h = 1): both
@@ -1109,7 +1110,9 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       const unsigned sb = ((unsigned)(q - a) << 4) ^ (1u << (LOGM + 5));
       // fswz XORs index bits 4..6 into bits 1..3: byte-offset bits 8..10 into 5..7.  With TP >= 128 the points of
       // a thread differ in index bits >= 7 only, so the term is the same for all of them
-      const unsigned swz_all = (sb >> 3) & 0xE0u;
+      // ... and the byte offset of this half's image rides along (bit LOGM+4 and up: outside the slot mask)
+      const unsigned img_base = (unsigned)r * (unsigned)(M * 16) + lds0;
+      const unsigned swz_all = ((sb >> 3) & 0xE0u) | img_base;
       // all sixteen rotated reads go out as ONE burst before the first digit is formed (round 3: the compiler's own
       // order was read, wait, use, pair by pair -- eight exposed LDS round trips at the head of every iteration)
       uint64_t va[8], vb[8];
@@ -1117,12 +1120,13 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const unsigned se = sb + (unsigned)(e * TP * 16);
-        const unsigned swz = TP >= 128 ? swz_all : ((se >> 3) & 0xE0u);
+        const unsigned swz = TP >= 128 ? swz_all : (((se >> 3) & 0xE0u) | img_base);
         hmv[e] = __builtin_amdgcn_sbfe(se, LOGM + 4, 1);             // -1 when h = 0 reads the upper component
         m0v[e] = __builtin_amdgcn_sbfe(se, LOGM + 5, 1);             // h = 0: 0 take image, -1 take -image
         const unsigned off0 = ((se & (unsigned)((M - 1) << 4)) ^ swz) | ((unsigned)hmv[e] & 8u);
-        va[e] = *reinterpret_cast<const uint64_t *>(ybytes + off0);
-        vb[e] = *reinterpret_cast<const uint64_t *>(ybytes + (off0 ^ 8u));
+        // LDS addresses as integers: through `smem_raw + off` every address pays an add of the (zero) link-time base
+        va[e] = *(lds_u64_ptr)(uintptr_t)(off0);
+        vb[e] = *(lds_u64_ptr)(uintptr_t)(off0 ^ 8u);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1144,6 +1148,8 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    // requested behind the rotated reads: a scalar load in flight turns every counted wait on the LDS reads into "wait for all"
+    const uint64_t ks_next = ks[i + 1];
     double2 g0[8], g1[8];
     {
       const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
