@@ -1231,12 +1231,13 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
         asm volatile("; end of form r = 1");
       }
     }
-    double2 twi[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) twi[e] = buf_load_d2(rs_ti, voff_q, (unsigned)(e * TP * 16));
+    // vmcnt counts in order: what is needed first (the top-stage twiddles of inverse pass A) is requested first
     double2 wtop[4] = {};  // entries 2 and 3 are quarter turns of 0 and 1 (load_pass_twiddles_tab derives them)
 #pragma unroll
     for (int e = 0; e < 2; ++e) wtop[e] = buf_load_d2(rs_twg, voff_q, (unsigned)(e * TP * 16));
+    double2 twi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) twi[e] = buf_load_d2(rs_ti, voff_q, (unsigned)(e * TP * 16));
 
     if (PRIO != 5) fft_stage_bit0_dpp(x, sgn);
     if (NP == 3) {
