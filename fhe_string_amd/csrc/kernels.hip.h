@@ -1321,10 +1321,10 @@ __device__ __forceinline__ double2 cfma(double2 g, double2 w, double2 acc) {
   return make_double2(re, im);
 }
 
-// INVERSE butterflies of a 3-bit pass, every stage's twiddles from the LDS stage tables (T[M] entries)
-template <int LOGM, bool FWD, int LO>
-__device__ __forceinline__ void fft_butterflies_tab_all(double2 (&x)[8], int q, const double2 *T) {
-  static_assert(!FWD, "forward passes: fft_fwd_butterflies_tab");
+// INVERSE butterflies of a 3-bit pass, every stage's twiddles read from the LDS stage tables (T[M] entries) at the point
+// of use (the pipelined multi-bit build: no registers to hold them across a barrier)
+template <int LOGM, int LO>
+__device__ __forceinline__ void fft_inv_butterflies_tab_all(double2 (&x)[8], int q, const double2 *T) {
 #pragma unroll
   for (int st = 0; st < 3; ++st) {
     const int fb = st;
@@ -1337,12 +1337,17 @@ __device__ __forceinline__ void fft_butterflies_tab_all(double2 (&x)[8], int q, 
     }
   }
 }
-// FORWARD butterflies of a 3-bit pass, twiddles from the LDS copy of psi
+// the 7 twiddles of an INVERSE 3-bit pass from the LDS stage tables with M entries (every stage; the order of
+// fft_butterflies_reg<false>): requested ahead of the barrier in front of the pass, like variant 5 does
 template <int LOGM, int LO>
-__device__ __forceinline__ void fft_fwd_butterflies_tab(double2 (&x)[8], int q, const double2 *TF) {
-  double2 w[7];
-  load_fwd_twiddles<LOGM, LO, false>(w, q, TF);
-  fft_butterflies_reg<true>(x, w);
+__device__ __forceinline__ void load_inv_twiddles_tab_all(double2 (&w)[7], int q, const double2 *T) {
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int fb = k < 4 ? 2 : (k < 6 ? 1 : 0);
+    const int e = k < 4 ? k : (k < 6 ? (k - 4) : 0);
+    const int beta = LO + fb;
+    w[k] = T[(1 << beta) + (fft_point<LOGM, LO, 3>(q, e) & ((1 << beta) - 1))];
+  }
 }
 
 // LAT = true: the latency build -- one workgroup per CU (512 registers per lane), pass twiddles and
@@ -1543,21 +1548,30 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = make_double2(digit1_f64<BL>(own_lo[e]), digit1_f64<BL>(own_hi[e]));
 
-    // ---- forward FFT ----
+    // ---- forward FFT ----  (round 3, EARLY: the twiddles of a pass are requested ahead of the barrier in front of it and
+    // the reads of an exchange go out as one burst before the first butterfly -- left to itself the compiler waits read by
+    // read.  The pipelined throughput build (g = 3) has the next bundle in flight and no registers for that: it keeps the
+    // order "reads, twiddles, butterflies" and the compiler's interleaving)
+    constexpr bool EARLY = LAT || !PIPE;
+    double2 w[7];
     fft_butterflies_reg<true>(x, wfa);
 #pragma unroll
     for (int e = 0; e < 8; ++e) bufA[e * SA] = x[e];
+    if (EARLY) load_fwd_twiddles<LOGM, LO_B, false>(w, q, TF);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = bufB[e * SB];
-    fft_fwd_butterflies_tab<LOGM, LO_B>(x, q, TF);
+    if (EARLY) __builtin_amdgcn_sched_barrier(0); else load_fwd_twiddles<LOGM, LO_B, false>(w, q, TF);
+    fft_butterflies_reg<true>(x, w);
     if (NP == 3) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) bufB[e * SB] = x[e];
+      if (EARLY) load_fwd_twiddles<LOGM, LO_C, false>(w, q, TF);
       __builtin_amdgcn_wave_barrier();  // B -> C stays inside a wave (q >> 6 is index bit LOGM-1 in both layouts)
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = bufC[e * SC];
-      fft_fwd_butterflies_tab<LOGM, LO_C>(x, q, TF);
+      if (EARLY) __builtin_amdgcn_sched_barrier(0); else load_fwd_twiddles<LOGM, LO_C, false>(w, q, TF);
+      fft_butterflies_reg<true>(x, w);
     }
     {
       double2 cd[8];  // constants of the lane-pair stage (latency build: registers; otherwise the LDS copy)
@@ -1571,13 +1585,32 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
     for (int e = 0; e < 8; ++e) bufC[e * SC] = x[e];
     __builtin_amdgcn_sched_barrier(0);
     if (PIPE) bundle_consume(NBATCH - 1);  // last batch of this group's bundle
+    if (EARLY && !LAT) load_inv_twiddles_tab_all<LOGM, LO_C>(w, q, T);  // first inverse pass (LO_C == LO_B when there are two)
     __syncthreads();
-    if (r == 0) {
+    if (!EARLY) {
+      if (r == 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], bufCo[e * SC], b0[e], b1[e]);
+        for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], bufCo[e * SC], b0[e], b1[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = ext_mac(bufCo[e * SC], x[e], b0[e], b1[e]);
+      }
+    } else if (r == 0) {
+      double2 oth[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) oth[e] = bufCo[e * SC];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(x[e], oth[e], b0[e], b1[e]);
+      asm volatile("; end of form r = 0");  // two DIFFERENT closing statements: the forms are not merged behind register shuffles
     } else {
+      double2 oth[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ext_mac(bufCo[e * SC], x[e], b0[e], b1[e]);
+      for (int e = 0; e < 8; ++e) oth[e] = bufCo[e * SC];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ext_mac(oth[e], x[e], b0[e], b1[e]);
+      asm volatile("; end of form r = 1");
     }
     double2 twi[8];
 #pragma unroll
@@ -1591,24 +1624,32 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
     // ---- inverse FFT ----
     fft_stage_bit0_dpp(x, sgn);
     if (NP == 3) {
-      if (LAT) fft_butterflies_reg<false>(x, wC); else fft_butterflies_tab_all<LOGM, false, LO_C>(x, q, T);
+      if (!EARLY) fft_inv_butterflies_tab_all<LOGM, LO_C>(x, q, T); else fft_butterflies_reg<false>(x, LAT ? wC : w);
 #pragma unroll
       for (int e = 0; e < 8; ++e) bufC[e * SC] = x[e];
+      if (EARLY && !LAT) load_inv_twiddles_tab_all<LOGM, LO_B>(w, q, T);
       if (PIPE) bundle_advance(jn, QB, QB);
       __builtin_amdgcn_wave_barrier();  // C -> B stays inside a wave
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = bufB[e * SB];
+      if (EARLY) __builtin_amdgcn_sched_barrier(0);
     } else {
       if (PIPE) bundle_advance(jn, QB, QB);
     }
-    if (LAT) fft_butterflies_reg<false>(x, wB); else fft_butterflies_tab_all<LOGM, false, LO_B>(x, q, T);
+    if (!EARLY) fft_inv_butterflies_tab_all<LOGM, LO_B>(x, q, T); else fft_butterflies_reg<false>(x, LAT ? wB : w);
 #pragma unroll
     for (int e = 0; e < 8; ++e) bufB[e * SB] = x[e];
+    if (EARLY && !LAT) load_inv_twiddles_tab_all<LOGM, LO_A>(w, q, T);
     if (PIPE) bundle_advance(jn, 2 * QB, QB);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = bufA[e * SA];
-    if (LAT) fft_butterflies_reg<false>(x, wA); else fft_butterflies_tab_all<LOGM, false, LO_A>(x, q, T);
+    if (EARLY) {
+      __builtin_amdgcn_sched_barrier(0);
+      fft_butterflies_reg<false>(x, LAT ? wA : w);
+    } else {
+      fft_inv_butterflies_tab_all<LOGM, LO_A>(x, q, T);
+    }
     if (PIPE) bundle_advance(jn, 3 * QB, NBATCH - 3 * QB);
 
     // ---- untwist, round to the torus: the new accumulator ----

@@ -210,7 +210,7 @@ if br and br[0] in sq:
     # scripts/micro/lds_valu_overlap.hip confirms the prices on this chip (8 stores + 8 loads by 8 waves:
     # 1021 cycles against 1088 predicted) and that a barrier-separated phase pays VALU + LDS, not max.
     if "multibit" not in extra and clock and wave_iters:
-        mix = {"ds_write_b128": 48, "ds_read_b128": 60, "ds_read_b64": 16}   # 75 loads before the quarter-turn twiddles were derived (round 3)
+        mix = {"ds_write_b128": 48, "ds_read_b128": 58, "ds_read_b64": 16}   # 40 exchange + 18 twiddle reads (73 before the quarter-turn twiddles were derived, round 3)
         conflicts = c.get("SQ_LDS_BANK_CONFLICT", 0) / wave_iters
         lds_cyc = mix["ds_write_b128"] * 13 + mix["ds_read_b128"] * 4 + mix["ds_read_b64"] * 2 + conflicts
         comp["lds_pipe"] = {"instr_per_wave_iter_static": mix, "instr_per_wave_iter_measured": comp["lds_instr_per_wave_iter"],
