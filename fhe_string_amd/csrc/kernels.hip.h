@@ -1549,10 +1549,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
     for (int e = 0; e < 8; ++e) x[e] = make_double2(digit1_f64<BL>(own_lo[e]), digit1_f64<BL>(own_hi[e]));
 
     // ---- forward FFT ----  (round 3, EARLY: the twiddles of a pass are requested ahead of the barrier in front of it and
-    // the reads of an exchange go out as one burst before the first butterfly -- left to itself the compiler waits read by
-    // read.  The pipelined throughput build (g = 3) has the next bundle in flight and no registers for that: it keeps the
-    // order "reads, twiddles, butterflies" and the compiler's interleaving)
-    constexpr bool EARLY = LAT || !PIPE;
+    // the reads of an exchange go out as one burst before the first butterfly -- the latency build only: 2.50 against
+    // 2.52 ms per bootstrap.  The throughput builds keep "reads, twiddles at the point of use, butterflies" and the
+    // compiler's interleaving: g = 2 measured 125.5 against 121.2 ms per 16 384 with EARLY, g = 3 has no registers for it)
+    constexpr bool EARLY = LAT;
     double2 w[7];
     fft_butterflies_reg<true>(x, wfa);
 #pragma unroll
