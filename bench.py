@@ -482,7 +482,7 @@ def main():
                                                    "valu_issue_cycles_per_wave_cmux": round(cr["issue_cycles_per_pbs_iteration_per_cu"], 1),
                                                    "serial_sum_pbs_per_s": round(cr["serial_sum_pbs_per_s"], 1),
                                                    "frac_of_serial_sum": round(br_rate / cr["serial_sum_pbs_per_s"], 4),
-                                                   "note": "48 ds_write_b128 (13 LDS-pipe cycles each: the VGPR -> LDS transfer), 75 ds_read_b128 (4), 16 "
+                                                   "note": "48 ds_write_b128 (13 LDS-pipe cycles each: the VGPR -> LDS transfer), 58 ds_read_b128 (4), 16 "
                                                            "ds_read_b64 (2) per wave and CMUX + measured conflict cycles; the four waves of a PBS share the "
                                                            "CU's one LDS pipe.  The two pipes need about the same cycles per CMUX; phases separated by "
                                                            "barriers pay their SUM (scripts/micro/lds_valu_overlap.hip, profiles/r03_lds_valu_overlap.jsonl), "
