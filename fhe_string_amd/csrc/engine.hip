@@ -555,8 +555,10 @@ static int launch_br_gen(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   }
 }
 
-// variant: 0 = auto (variant 5), 1 = the simple kernel, 5 = the throughput kernel, 6 / 7 = 5 with other
-// wave-priority policies; all produce the same bits.  (Variants 2-4 of earlier rounds are gone.)
+// variant: 0 = auto (variant 7), 1 = the simple kernel, 5 / 6 / 7 = the throughput kernel with three wave-priority
+// policies (5: head of an iteration at high priority, 6: static by wave slot, 7: no hints -- the default since the
+// schedule trims of round 3: 0.1 / 0.5 / 1.2 % ahead of 5 at 16 384 / 5 120 / 1 536 ciphertexts in alternating runs);
+// all produce the same bits.  (Variants 2-4 of earlier rounds are gone.)
 static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   if (ctx->dims.g > 1) {
     // multi-bit parameter sets: one kernel in three builds -- latency (launches of at most one
@@ -570,7 +572,7 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   }
   if (!fast_shape(ctx->p) || ctx->br_variant == 12) return launch_br_gen(ctx, lane, d);  // 12: the generic kernel on a 2_2 set (tests)
   int variant = ctx->br_variant;
-  if (variant == 0) variant = 5;  // every launch size
+  if (variant == 0) variant = 7;  // every launch size
   if (variant != 1 && (variant < 5 || variant > 10 || variant == 8))
     return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d does not exist (1, 5, 6, 7; 9 and 10 are timing-only ablations)", variant);
   if (ctx->dims.pbs_base_log != 23 && variant == 1)

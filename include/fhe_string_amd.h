@@ -166,8 +166,8 @@ int fhes_get_stats(fhes_ctx *ctx, fhes_stats *out);
 int fhes_reset_stats(fhes_ctx *ctx);
 /* enable per-launch HIP-event timing (used by bench.py for the roofline object) */
 int fhes_set_timing(fhes_ctx *ctx, int32_t enabled);
-/* blind-rotate kernel selection for A/B benchmarking: 0 = auto (variant 5), 1 = simple kernel, 5 = throughput
- * kernel, 6 / 7 = 5 with other wave-priority policies (all produce the same bits; multi-bit sets: 2 = latency
+/* blind-rotate kernel selection for A/B benchmarking: 0 = auto (variant 7), 1 = simple kernel, 5 / 6 / 7 = throughput
+ * kernel with three wave-priority policies (all produce the same bits; multi-bit sets: 2 = latency
  * build, 3 = throughput build; 12 = the generic kernel on a 2_2 set.  9 / 10 are timing-only ablations with WRONG
  * results and are refused unless FHES_DEV_ABLATIONS=1 is in the environment) */
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t br_variant);
