@@ -61,6 +61,23 @@ def config3_input():
     return "".join(chars)
 
 
+@pytest.mark.skipif(os.environ.get("FHES_FULLSIZE_FAITHFUL") != "1",
+                    reason="seven minutes of oracle time on 16 cores: opt in with FHES_FULLSIZE_FAITHFUL=1 "
+                           "(run once per round, log under profiles/)")
+def test_config3_split_256_faithful_every_output_word_against_oracle(libs):
+    """config 3 with the reference's own serial circuits (split.rs:238-341 as written): 152 k bootstraps in
+    thousands of dependent levels, every output word against the oracle"""
+    w = world("default", l=256)
+    bu = num_blocks_usize(256)
+    s = config3_input()
+    p = Prog(w.p, "split", [257, 2], bu)
+    cts = w.encrypt(np.concatenate([string_blocks(s), string_blocks(",")]))
+    dev = run_on_device(w, p, cts)
+    assert decode_result("split", w.decrypt(dev), bu, s) == s.split(",")
+    ref, _ = p.run_oracle(w, cts, threads=effective_cores())
+    assert_same_words(dev, ref, f"split 256/1, faithful ({p.n_pbs} PBS, {p.n_levels} levels)")
+
+
 def test_config3_split_256_logdepth_every_output_word_against_oracle(libs):
     """config 3: split of a 256-character input on a 1-character encrypted separator, l = 256 (5 usize
     blocks), the log-depth form (14.3 k bootstraps; the faithful circuit's 152 k would take the oracle
