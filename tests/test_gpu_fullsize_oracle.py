@@ -67,6 +67,18 @@ def config3_input():
 def test_config3_split_256_faithful_every_output_word_against_oracle(libs):
     """config 3 with the reference's own serial circuits (split.rs:238-341 as written): 152 k bootstraps in
     thousands of dependent levels, every output word against the oracle"""
+    import threading
+    import time
+    stop = threading.Event()
+
+    def heartbeat():   # seven silent minutes look like a hang to the GPU pool's watchdog
+        t0 = time.time()
+        while not stop.wait(60):
+            if os.path.isdir("gpurun_out"):
+                with open("gpurun_out/heartbeat.txt", "a") as f:
+                    f.write(f"faithful config 3: {time.time() - t0:.0f} s\n")
+
+    threading.Thread(target=heartbeat, daemon=True).start()
     w = world("default", l=256)
     bu = num_blocks_usize(256)
     s = config3_input()
@@ -75,6 +87,7 @@ def test_config3_split_256_faithful_every_output_word_against_oracle(libs):
     dev = run_on_device(w, p, cts)
     assert decode_result("split", w.decrypt(dev), bu, s) == s.split(",")
     ref, _ = p.run_oracle(w, cts, threads=effective_cores())
+    stop.set()
     assert_same_words(dev, ref, f"split 256/1, faithful ({p.n_pbs} PBS, {p.n_levels} levels)")
 
 
