@@ -518,11 +518,20 @@ static int launch_br_v5(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
 static size_t gen_scratch_per_wg(const Dims &d) {
   return (size_t)(d.k + 1) * d.N * 8 + (size_t)(d.k + 1) * d.L * d.M * 16;
 }
+// LDS-resident form: accumulator + digit spectra next to the exchange buffers when they fit (kGenLdsBudget leaves room for
+// the runtime's own use of the 160 KB); otherwise the global scratch
+constexpr size_t kGenLdsBudget = 156 * 1024;
+static size_t gen_lds_bytes(const Dims &d, bool resident) {
+  const size_t base = (size_t)(d.k + 1) * d.M * 16 + (size_t)((d.n + 1 + 3) & ~3) * 4;
+  return resident ? base + gen_scratch_per_wg(d) : base;
+}
+static bool gen_lds_resident(const Dims &d) { return gen_lds_bytes(d, true) <= kGenLdsBudget; }
 template <int LOGN>
 static int launch_br_gen_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const Dims &dm = ctx->dims;
-  const size_t per = gen_scratch_per_wg(dm), need = per * (size_t)d.v_count;
+  const bool resident = gen_lds_resident(dm) && !getenv("FHES_GEN_GLOBAL_SCRATCH");  // developer knob: the global-scratch form
+  const size_t per = gen_scratch_per_wg(dm), need = resident ? 0 : per * (size_t)d.v_count;
   if (lane.gen_scratch_bytes < need) {
     lane.drop(lane.gen_scratch);
     lane.gen_scratch = nullptr;
@@ -530,16 +539,27 @@ static int launch_br_gen_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
     FHES_HIP(hipMalloc(&lane.gen_scratch, need));
     lane.gen_scratch_bytes = need;
   }
-  const size_t lds = (size_t)(dm.k + 1) * M * 16 + (size_t)((dm.n + 1 + 3) & ~3) * 4;
-  auto kern = dev::blind_rotate_gen_kernel<LOGN>;
-  const unsigned bit = 1u << (2 + (LOGN - 8));  // bits 2..7
-  if (!(ctx->attr_done & bit)) {
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ctx->attr_done |= bit;
+  const size_t lds = gen_lds_bytes(dm, resident);
+  const unsigned bit = 1u << (2 + (LOGN - 8));  // bits 2..7 (bit 29: the LDS-resident form, one shape per context)
+  if (resident) {
+    auto kern = dev::blind_rotate_gen_kernel<LOGN, true>;
+    if (!(ctx->attr_done & (1u << 29))) {
+      FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ctx->attr_done |= 1u << 29;
+    }
+    hipLaunchKernelGGL(kern, dim3(d.v_count), dim3((dm.k + 1) * (M / 8)), lds, lane.stream, d, ctx->arena, ctx->ct_stride,
+                       lane.ks_out, ctx->ks_stride, dm.n, dm.k, dm.L, dm.pbs_base_log, ctx->bsk_f, ctx->lut_polys, ctx->twist,
+                       ctx->tw, ctx->psi, (unsigned char *)nullptr, per);
+  } else {
+    auto kern = dev::blind_rotate_gen_kernel<LOGN, false>;
+    if (!(ctx->attr_done & bit)) {
+      FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ctx->attr_done |= bit;
+    }
+    hipLaunchKernelGGL(kern, dim3(d.v_count), dim3((dm.k + 1) * (M / 8)), lds, lane.stream, d, ctx->arena, ctx->ct_stride,
+                       lane.ks_out, ctx->ks_stride, dm.n, dm.k, dm.L, dm.pbs_base_log, ctx->bsk_f, ctx->lut_polys, ctx->twist,
+                       ctx->tw, ctx->psi, lane.gen_scratch, per);
   }
-  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3((dm.k + 1) * (M / 8)), lds, lane.stream, d, ctx->arena, ctx->ct_stride,
-                     lane.ks_out, ctx->ks_stride, dm.n, dm.k, dm.L, dm.pbs_base_log, ctx->bsk_f, ctx->lut_polys, ctx->twist,
-                     ctx->tw, ctx->psi, lane.gen_scratch, per);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }

@@ -647,7 +647,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
 //   LDS: fbuf double2[k + 1][M] | at u32[n + 1]
 //   scratch per workgroup: acc u64[k + 1][N] | D double2[(k + 1) * L][M]
 // ------------------------------------------------------------------------------------------
-template <int LOGN>
+// LDSRES (round 3): accumulator and digit spectra in LDS instead of the global scratch, for the shapes whose working set
+// fits next to the exchange buffers (everything but N = 8192 / N = 4096 with several levels): same code, same bits.
+//   LDS with LDSRES: fbuf | at | acc u64[k + 1][N] | D double2[(k + 1) * L][M]
+template <int LOGN, bool LDSRES = false>
 __global__ __launch_bounds__(((4 << LOGN) / 16) > 1024 ? 1024 : ((4 << LOGN) / 16)) void blind_rotate_gen_kernel(  // (k + 1) <= 4 groups of N / 16 threads
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride,
     int n_small, int k, int L, int BL, const double2 *__restrict__ bsk_f, const uint64_t *__restrict__ lut_polys,
@@ -659,7 +662,9 @@ __global__ __launch_bounds__(((4 << LOGN) / 16) > 1024 ? 1024 : ((4 << LOGN) / 1
   const int kp1 = k + 1;
   double2 *fbuf = reinterpret_cast<double2 *>(smem_raw);                                  // [kp1][M]
   uint32_t *at = reinterpret_cast<uint32_t *>(smem_raw + (size_t)kp1 * M * 16);           // [n + 1]
-  uint64_t *acc = reinterpret_cast<uint64_t *>(scratch + (size_t)blockIdx.x * scratch_per_wg);  // [kp1][N]
+  const size_t at_bytes = (size_t)((n_small + 1 + 3) & ~3) * 4;                           // keeps what follows 16-byte aligned
+  uint64_t *acc = LDSRES ? reinterpret_cast<uint64_t *>(smem_raw + (size_t)kp1 * M * 16 + at_bytes)
+                         : reinterpret_cast<uint64_t *>(scratch + (size_t)blockIdx.x * scratch_per_wg);  // [kp1][N]
   double2 *D = reinterpret_cast<double2 *>(acc + (size_t)kp1 * N);                        // [kp1 * L][M]
 
   const int tid = threadIdx.x;
