@@ -140,7 +140,10 @@ static bool kernels_support(const fhes_params &p, std::string *why) {
   }
   if (fast_shape(p)) return true;
   if (p.glwe_dim > 3 || p.pbs_level > 3) { *why = "the generic blind rotate serves glwe_dim <= 3 and pbs_level <= 3"; return false; }
-  if ((p.glwe_dim + 1) * (p.poly_size / 16) > 1024) { *why = "the generic blind rotate needs (glwe_dim + 1) * poly_size / 16 <= 1024 threads"; return false; }
+  if ((p.glwe_dim + 1) * (p.poly_size / 16) > 1024 || (p.poly_size >= 4096 && p.glwe_dim > 1)) {
+    *why = "the generic blind rotate needs (glwe_dim + 1) * poly_size / 16 <= 1024 threads, and glwe_dim 1 from poly_size 4096";
+    return false;
+  }
   if ((size_t)(p.glwe_dim + 1) * p.poly_size * 8 + (size_t)(p.lwe_dim + 4) * 4 > 160 * 1024) { *why = "the generic blind rotate needs (glwe_dim + 1) * poly_size * 8 bytes of LDS"; return false; }
   if (p.pbs_base_log * p.pbs_level > 62) { *why = "PBS decomposition wider than 62 bits"; return false; }
   return true;

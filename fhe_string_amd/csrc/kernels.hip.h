@@ -651,7 +651,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
 // fits next to the exchange buffers (everything but N = 8192 / N = 4096 with several levels): same code, same bits.
 //   LDS with LDSRES: fbuf | at | acc u64[k + 1][N] | D double2[(k + 1) * L][M]
 template <int LOGN, bool LDSRES = false>
-__global__ __launch_bounds__(((4 << LOGN) / 16) > 1024 ? 1024 : ((4 << LOGN) / 16)) void blind_rotate_gen_kernel(  // (k + 1) <= 4 groups of N / 16 threads
+__global__ __launch_bounds__((((LOGN >= 12 ? 2 : 4) << LOGN) / 16) > 1024 ? 1024 : (((LOGN >= 12 ? 2 : 4) << LOGN) / 16)) void blind_rotate_gen_kernel(  // (k + 1) <= 4 groups of N / 16 threads; N >= 4096: glwe_dim 1 only (two groups: 256 instead of 128 registers at N = 4096)
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride,
     int n_small, int k, int L, int BL, const double2 *__restrict__ bsk_f, const uint64_t *__restrict__ lut_polys,
     const double2 *__restrict__ twist, const double2 *__restrict__ tw, const double2 *__restrict__ psi,
