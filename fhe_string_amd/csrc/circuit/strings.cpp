@@ -600,7 +600,7 @@ struct S {
   //      of (K - emitted(c')), a non-decreasing function -- an order-preserving compaction, which a
   //      butterfly network routes without collisions when the offset digits are consumed least significant
   //      first (base 4: Bu stages of one 4-way selection per slot and payload block).
-  // Preconditions that only public sizes decide (else the faithful loop is used): no n_max, max_len(p) <= 7
+  // Preconditions that only public sizes decide (else the faithful loop is used): max_len(p) <= 7
   // (automaton states in one block), max_len(s) <= 4, and l + slots(self) <= msg_mod^Bu so that the
   // reference's own pointer arithmetic never wraps.  The one case the automaton cannot express -- an EMPTY
   // pattern with a non-empty replacement, where the loop never advances and emits s forever -- is computed
@@ -635,10 +635,17 @@ struct S {
   bool replace_fast_applies(const Str &a, const Str &p, const Str &sub, const Radix *n_max, size_t l) const {
     const size_t T = usize_modulus();
     // (the transducer's tables pack a state and a symbol count into one lookup input: 4 bits of plaintext space)
-    return fast && o.b.space() >= 16 && !n_max && max_len(p) <= 7 && max_len(sub) <= 4 && T != 0 && l + a.size() <= T && l >= 1;
+    if (!(fast && o.b.space() >= 16 && max_len(p) <= 7 && max_len(sub) <= 4 && T != 0 && l + a.size() <= T && l >= 1)) return false;
+    // replacen: min(n_max, l) * len(s) (the shift of the degenerate case) has to stay below the modulus as well
+    return !n_max || ((int)n_max->size() == Bu && (l + 1) * std::max<size_t>(max_len(sub), 1) + a.size() <= T);
   }
 
-  Str replace_logdepth(const Str &a, const Str &p, const Str &sub, size_t l) {
+  // n_max (replacen, replace.rs:23-33): the loop accepts `found[c] && n < n_max` -- the FIRST n_max occurrences of the
+  // unbounded greedy sequence, everything behind them is copied.  With cnt(c) = accepted occurrences before c (an
+  // exclusive prefix sum): accepted'(c) = accepted(c) & [cnt(c) < n_max]; a position covered by an occurrence is
+  // covered by the LAST accepted one before it, which was the cnt(c)-th: covered'(c) = covered(c) & [cnt(c) <= n_max];
+  // whatever loses its role is copied.
+  Str replace_logdepth(const Str &a, const Str &p, const Str &sub, size_t l, const Radix *n_max = nullptr) {
     Builder &b = o.b;
     const size_t slots = a.size(), n_pos = slots - 1, Pmax = max_len(p), Smax = max_len(sub);
     const size_t K = std::max<size_t>(Smax, 1), T = usize_modulus();
@@ -678,6 +685,30 @@ struct S {
           copy[c] = mext[c].trivial() ? (mext[c].cst ? o.trivial_bool(false) : o.bitnot_(covered[c]))
                                       : b.bivar(st, mext[c], 1, [](uint64_t x, uint64_t y) { return (x == 0 && !y) ? 1 : 0; });
         }
+      }
+    }
+    if (n_max) {
+      std::vector<Radix> inc(slots);
+      for (size_t c = 0; c < slots; c++) inc[c] = usize_from_bool(acc[c]);
+      for (size_t span = 1; span < slots; span <<= 1)
+        for (size_t i = 0; i < slots; i++)
+          if ((i / span) & 1) inc[i] = lazy_add(inc[i], inc[(i / span) * span - 1]);
+      for (size_t c = 0; c < slots; c++) {
+        const Radix cnt = c == 0 ? usize(0) : normalize(inc[c - 1]);
+        const bool acc_never = acc[c].trivial() && acc[c].cst == 0, cov_never = covered[c].trivial() && covered[c].cst == 0;
+        Blk lost = o.trivial_bool(false);  // had a role in the unbounded run, has none now: copied
+        if (!acc_never) {
+          Blk ok = o.cmp(cnt, *n_max, Cmp::LT);
+          lost = o.bitand_(acc[c], o.bitnot_(ok));
+          acc[c] = o.bitand_(acc[c], ok);
+        }
+        if (!cov_never) {
+          Blk okc = o.cmp(cnt, *n_max, Cmp::LE);
+          Blk lost_c = o.bitand_(covered[c], o.bitnot_(okc));
+          covered[c] = o.bitand_(covered[c], okc);
+          lost = acc_never ? lost_c : o.bitor_(lost, lost_c);  // exclusive roles
+        }
+        if (!(acc_never && cov_never)) copy[c] = o.bitor_(copy[c], lost);
       }
     }
     // 2. gap(c) = K - emitted(c): K when skipped, K - 1 when copied, K - max(len(s), 1) when accepted
@@ -800,10 +831,20 @@ struct S {
       Blk dg = o.bitand_(p_zero, o.bitnot_(s_zero));
       std::vector<Blk> s_is;
       for (size_t d = 1; d <= Smax; d++) s_is.push_back(o.scalar_eq(s_len, d));
+      // replacen: the loop stops inserting after n_max rounds and copies self from its start:
+      // v[i] = i < R ? s[i mod len(s)] : self[i - R],  R = min(n_max, l) * len(s)  (l rounds fill every output anyway)
+      Radix shift;
+      std::vector<Radix> self_shifted;
+      if (n_max) {
+        Radix n_eff = o.if_then_else(o.scalar_cmp(*n_max, (uint64_t)l, Cmp::LT), *n_max, usize((uint64_t)l));
+        shift = o.mul(n_eff, s_len);
+        self_shifted = rotate_logdepth(a, shift, T, true, l);
+      }
       for (size_t i = 0; i < l; i++) {
         std::vector<Radix> terms;
         for (size_t d = 1; d <= Smax; d++) terms.push_back(o.zero_unless(s_is[d - 1], sub[i % d]));
         Radix deg_c = sum_exclusive(terms, Bc);
+        if (n_max) deg_c = o.if_then_else(o.scalar_cmp(shift, (uint64_t)i, Cmp::GT), deg_c, self_shifted[i]);
         v.push_back(o.if_then_else(dg, deg_c, vmain[i]));
       }
     } else {
@@ -818,7 +859,7 @@ struct S {
   // replace.rs:37-104
   Str replace_opt(const Str &a, const Str &p, const Str &sub, const Radix *n_max, size_t l, size_t max_len_key) {
     l = std::min(l, max_len_key);
-    if (replace_fast_applies(a, p, sub, n_max, l)) return replace_logdepth(a, p, sub, l);
+    if (replace_fast_applies(a, p, sub, n_max, l)) return replace_logdepth(a, p, sub, l, n_max);
     std::vector<Blk> found = find_all(a, p);
     Radix p_len = len(p), s_len = len(sub);
     Radix len_diff = o.sub(p_len, s_len);

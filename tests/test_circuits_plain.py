@@ -417,6 +417,41 @@ def test_logdepth_replace_equals_the_references_loop(libs):
     assert fast.n_levels * 10 < ref.n_levels and fast.n_pbs * 2 < ref.n_pbs, (fast.n_pbs, ref.n_pbs, fast.n_levels, ref.n_levels)
 
 
+def test_logdepth_replacen_equals_the_references_loop(libs):
+    """replacen_logdepth: the first n_max occurrences of the unbounded greedy sequence (a prefix count masks the
+    automaton's roles) against the faithful loop of replace.rs:65-99 with `n < n_max` on every output block -- n_max
+    0, small, equal to and beyond the number of occurrences, empty pattern (n_max rounds of the replacement, then
+    self from its start), empty replacement, padded operands, outputs cut at l"""
+    from fhe_string_amd import _lib
+    from tests.progs import build_inputs
+    rnd = random.Random(0x5EED + 7)
+    bu = num_blocks_usize(255)
+    seen = {"empty_p": 0, "empty_s": 0, "n0": 0, "n_small": 0, "n_big": 0}
+    for trial in range(200):
+        la = rnd.randint(0, 8)
+        a = "".join(rnd.choice("xa") for _ in range(la))
+        p = "".join(rnd.choice("xa") for _ in range(rnd.randint(0, 3)))
+        r = "".join(rnd.choice("yz") for _ in range(rnd.randint(0, 3)))
+        a_pad = rnd.choice([None, la + rnd.randint(0, 3)])
+        p_pad = rnd.choice([None, len(p) + rnd.randint(0, 3)])
+        r_pad = rnd.choice([None, len(r) + rnd.randint(0, 1)])
+        l = rnd.randint(1, 14)
+        n = rnd.choice([0, 1, 1, 2, 2, 3, 5, 200, 255])
+        seen["empty_p"] += p == ""
+        seen["empty_s"] += r == ""
+        seen["n0"] += n == 0
+        seen["n_small"] += 0 < n <= 3
+        seen["n_big"] += n > 3
+        args = [S(a, a_pad), S(p, p_pad), S(r, r_pad), {"u": n}, {"i": l}]
+        shape, digits = build_inputs(_lib.load(), "replacen", args, bu)
+        ref = prog("replacen", shape, bu).run_plain(digits.astype("int64"))
+        fast = prog("replacen_logdepth", shape, bu).run_plain(digits.astype("int64"))
+        assert [int(v) % 4 for v in ref] == [int(v) % 4 for v in fast], (a, a_pad, p, p_pad, r, r_pad, n, l)
+    assert min(seen.values()) > 5, seen
+    ref, fast = prog("replacen", [65, 4, 2, 60], bu), prog("replacen_logdepth", [65, 4, 2, 60], bu)
+    assert fast.n_levels * 10 < ref.n_levels and fast.n_pbs * 2 < ref.n_pbs, (fast.n_pbs, ref.n_pbs, fast.n_levels, ref.n_levels)
+
+
 def test_find_pred_scans(libs):
     """find_pred_unchecked / rfind_pred_unchecked (search.rs:196-213): the index scan over the closure's results"""
     rnd = random.Random(11)

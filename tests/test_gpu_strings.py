@@ -410,6 +410,26 @@ def test_config5_multibit3_find_rfind_and_cli_shaped_padded_pattern(libs):
 
 
 @pytest.mark.gpu
+def test_replacen_logdepth_on_gpu(keys):
+    """replacen with the log-depth transducer (round 3: the first n_max occurrences by a prefix count over the
+    automaton's accepted positions) on real ciphertexts: equal to str.replace(p, s, n) and to the faithful loop"""
+    ck, sk = keys
+    text = "one fish two fish red fish blue fish"
+    A = api.FheString.new(ck, text, 40)
+    P, R = api.FheString.new(ck, "fish", 6), api.FheString.new(ck, "ox")
+    sk.set_logdepth(True)
+    try:
+        for n in (0, 1, 3, 200):
+            want = text.replace("fish", "ox", n)
+            assert A.replacen(sk, P, R, api.FheUsize.new(ck, n), 44).decrypt(ck) == want, n
+        grow = api.FheString.new(ck, "a-b-c").replacen(sk, api.FheString.new(ck, "-"), api.FheString.new(ck, "+++"), api.FheUsize.new(ck, 1), 12)
+        assert grow.decrypt(ck) == "a+++b-c"
+    finally:
+        sk.set_logdepth(False)
+    assert A.replacen(sk, P, R, api.FheUsize.new(ck, 1), 44).decrypt(ck) == text.replace("fish", "ox", 1)   # the faithful loop
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("which", ["classic", "multibit2"])
 def test_chained_operations_start_from_clean_blocks(which, libs):
     """results of one operation feed the next.  substr_from / trim build every output
