@@ -963,8 +963,20 @@ struct S {
     }
   }
 
-  // split.rs:86-113
+  // split.rs:86-113.  Log-depth form: n before entry k is the exclusive prefix count of the ORIGINAL is_some flags
+  // (Sklansky over lazily normalised radixes), one comparison per entry
   void truncate_slices(std::vector<Slice> &v, const Radix &i) {
+    if (fast && !v.empty() && usize_modulus() > v.size()) {
+      std::vector<Radix> inc(v.size());
+      for (size_t k = 0; k < v.size(); k++) inc[k] = usize_from_bool(v[k].is_some);
+      for (size_t span = 1; span < v.size(); span <<= 1)
+        for (size_t k = 0; k < v.size(); k++)
+          if ((k / span) & 1) inc[k] = lazy_add(inc[k], inc[(k / span) * span - 1]);
+      std::vector<Blk> keep(v.size());
+      for (size_t k = 0; k < v.size(); k++) keep[k] = o.cmp(k == 0 ? usize(0) : normalize(inc[k - 1]), i, Cmp::LT);
+      for (size_t k = 0; k < v.size(); k++) v[k].is_some = o.bitand_(keep[k], v[k].is_some);
+      return;
+    }
     Radix n = usize(0);
     for (Slice &vi : v) {
       Blk n_lt_i = o.cmp(n, i, Cmp::LT);

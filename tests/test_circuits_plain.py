@@ -325,8 +325,14 @@ def test_logdepth_equals_faithful_on_random_inputs(libs):
         a = "".join(rnd.choice("xa") for _ in range(rnd.randint(1, 7)))
         p = "".join(rnd.choice("xa") for _ in range(rnd.randint(1, 2)))
         n = rnd.randint(0, 3)
-        for op in ("splitn", "rsplitn"):
+        for op in ("splitn", "rsplitn"):   # truncate (split.rs:86-113) as a prefix count: every block of every slice
             assert run_ext(op + "_logdepth", [S(a), {"u": n}, S(p)])[0] == run_ext(op, [S(a), {"u": n}, S(p)])[0], (op, a, p, n)
+            from fhe_string_amd import _lib as _l
+            from tests.progs import build_inputs as _bi
+            shape, digits = _bi(_l.load(), op, [S(a, len(a) + trial % 3), {"u": n}, S(p)], num_blocks_usize(255))
+            ref = prog(op, shape, num_blocks_usize(255)).run_plain(digits.astype("int64"))
+            fast = prog(op + "_logdepth", shape, num_blocks_usize(255)).run_plain(digits.astype("int64"))
+            assert [int(v) % 4 for v in ref] == [int(v) % 4 for v in fast], (op, a, p, n)
         w = "".join(rnd.choice("a b\t") for _ in range(rnd.randint(0, 7)))
         for op in ("trim", "trim_start", "trim_end", "split_ascii_whitespace"):
             assert run_ext(op + "_logdepth", [S(w)])[0] == run_ext(op, [S(w)])[0], (op, w)

@@ -410,7 +410,7 @@ def test_config5_multibit3_find_rfind_and_cli_shaped_padded_pattern(libs):
 
 
 @pytest.mark.gpu
-def test_replacen_logdepth_on_gpu(keys):
+def test_replacen_and_splitn_logdepth_on_gpu(keys):
     """replacen with the log-depth transducer (round 3: the first n_max occurrences by a prefix count over the
     automaton's accepted positions) on real ciphertexts: equal to str.replace(p, s, n) and to the faithful loop"""
     ck, sk = keys
@@ -424,6 +424,13 @@ def test_replacen_logdepth_on_gpu(keys):
             assert A.replacen(sk, P, R, api.FheUsize.new(ck, n), 44).decrypt(ck) == want, n
         grow = api.FheString.new(ck, "a-b-c").replacen(sk, api.FheString.new(ck, "-"), api.FheString.new(ck, "+++"), api.FheUsize.new(ck, 1), 12)
         assert grow.decrypt(ck) == "a+++b-c"
+        # splitn / rsplitn: truncate (split.rs:86-113) as a prefix count over the is_some flags
+        B, C = api.FheString.new(ck, "a,b,,c,d", 10), api.FheString.new(ck, ",")
+        for n in (0, 1, 2, 4, 9):
+            want = [] if n == 0 else "a,b,,c,d".split(",", n - 1)
+            assert B.splitn(sk, api.FheUsize.new(ck, n), C).decrypt(ck) == want, n
+            rwant = [] if n == 0 else list(reversed("a,b,,c,d".rsplit(",", n - 1)))
+            assert B.rsplitn(sk, api.FheUsize.new(ck, n), C).decrypt(ck) == rwant, n
     finally:
         sk.set_logdepth(False)
     assert A.replacen(sk, P, R, api.FheUsize.new(ck, 1), 44).decrypt(ck) == text.replace("fish", "ox", 1)   # the faithful loop
