@@ -995,7 +995,26 @@ struct S {
   // split.rs:46-83, as written: the fold OVERWRITES acc.is_some in every step (so the result is
   // Some only when the element asked for is the last entry of the vector) and takes the entry's
   // position j, not its stored start, as the start of the slice.
+  // Log-depth form: n before entry j is the exclusive prefix count of the is_some flags; at most ONE entry has
+  // [i == n_j] & is_some_j (the count grows by one at every Some entry), so the fold's last-writer-wins selections are
+  // sums of mutually exclusive terms, and acc_some is the last entry's flag, as in the fold.
   std::pair<Blk, Str> slices_get(const std::vector<Slice> &v, const Str &src, const Radix &i) {
+    if (fast && !v.empty() && usize_modulus() > v.size()) {
+      std::vector<Radix> inc(v.size());
+      for (size_t j = 0; j < v.size(); j++) inc[j] = usize_from_bool(v[j].is_some);
+      for (size_t span = 1; span < v.size(); span <<= 1)
+        for (size_t j = 0; j < v.size(); j++)
+          if ((j / span) & 1) inc[j] = lazy_add(inc[j], inc[(j / span) * span - 1]);
+      std::vector<Radix> starts, ends;
+      Blk last = o.trivial_bool(false);
+      for (size_t j = 0; j < v.size(); j++) {
+        Blk hit = o.bitand_(o.eq(i, j == 0 ? usize(0) : normalize(inc[j - 1])), v[j].is_some);
+        starts.push_back(o.zero_unless(hit, usize(j)));
+        ends.push_back(o.zero_unless(hit, v[j].end));
+        last = hit;
+      }
+      return {last, substr_end(src, sum_exclusive(starts, Bu), sum_exclusive(ends, Bu))};
+    }
     Radix n = usize(0);
     Blk acc_some = o.trivial_bool(false);
     Radix acc_start = usize(0), acc_end = usize(0);

@@ -245,10 +245,12 @@ def test_slice_vector_methods_and_repeat(libs):
         assert run_ext("slices_len", [V])[0] == rm.slices_len(v)
         i = rnd.randint(0, 3)
         assert run_ext("slices_truncate", [V, {"u": i}])[0] == [(int(x[0]), x[1], x[2]) for x in rm.slices_truncate(v, i)]
+        assert run_ext("slices_truncate_logdepth", [V, {"u": i}])[0] == [(int(x[0]), x[1], x[2]) for x in rm.slices_truncate(v, i)]
         assert run_ext("slices_reverse", [V])[0] == [(int(x[0]), x[1], x[2]) for x in reversed(v)]
         for i in range(0, rm.slices_len(v) + 1):
             got = run_ext("slices_get", [V, S(a, a_pad), {"u": i}])[0]
             assert got == rm.slices_get(v, a, a_pad, i), (op, a, a_pad, p, i)
+            assert run_ext("slices_get_logdepth", [V, S(a, a_pad), {"u": i}])[0] == got, (op, a, a_pad, p, i)   # prefix-count form
             n_some += got is not None
     assert n_some > 0
     for trial in range(10):
