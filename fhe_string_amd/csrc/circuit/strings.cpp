@@ -529,6 +529,11 @@ struct S {
   // mod.rs:198-213
   Str substr_end(const Str &a, const Radix &start, const Radix &end) {
     Str v;
+    if (fast && (int)start.size() == Bu && usize_modulus() >= a.size()) {  // char_at(self, start + i) for all i: one rotation
+      Str rot = rotate_left_logdepth(a, start, usize_modulus());
+      for (size_t i = 0; i < a.size(); i++) v.push_back(if_then_else_zero(o.cmp(o.scalar_add(start, i), end, Cmp::LT), rot[i]));
+      return v;
+    }
     for (size_t i = 0; i < a.size(); i++) {
       Radix t = o.scalar_add(start, i);
       Blk lt_end = o.cmp(t, end, Cmp::LT);
@@ -912,10 +917,20 @@ struct S {
     Radix b_len = len(bstr);
     Radix index_add_blen = o.add(index, b_len);
     Str v;
+    // log-depth mode: char_at(b, i - index) and char_at(self, i - len(b)) for all i are RIGHT rotations of the zero-extended
+    // strings (the subtraction wraps modulo msg_mod^Bu exactly like the reference's FheUsize arithmetic): two barrel
+    // shifters instead of l * (slots(self) + slots(b)) one-hot selections
+    const size_t T = usize_modulus();
+    const bool shifters = fast && (int)index.size() == Bu && T != 0 && T >= a.size() && T >= bstr.size() && T >= l;
+    std::vector<Radix> b_rot, a_rot;
+    if (shifters) {
+      b_rot = rotate_logdepth(bstr, index, T, true, l);
+      a_rot = rotate_logdepth(a, b_len, T, true, l);
+    }
     for (size_t i = 0; i < l; i++) {
       Blk i_lt = o.scalar_cmp(index_add_blen, i, Cmp::GT);
-      Radix b_at = char_at(bstr, o.sub(usize(i), index));
-      Radix a_at = char_at(a, o.sub(usize(i), b_len));
+      Radix b_at = shifters ? b_rot[i] : char_at(bstr, o.sub(usize(i), index));
+      Radix a_at = shifters ? a_rot[i] : char_at(a, o.sub(usize(i), b_len));
       Radix c2 = o.if_then_else(i_lt, b_at, a_at);
       Blk c0 = o.scalar_cmp(index, i, Cmp::GT);
       v.push_back(o.if_then_else(c0, a[i % a.size()], c2));

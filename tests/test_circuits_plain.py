@@ -350,7 +350,10 @@ def test_logdepth_equals_faithful_on_random_inputs(libs):
         i, j = rnd.choice([rnd.randint(0, 12), rnd.randint(0, 255), 255, 250]), rnd.randint(0, 14)
         for op, args in (("substr_from", [S(a, pad), {"u": i}]), ("substr_end", [S(a, pad), {"u": i % 13}, {"u": j}]),
                          ("strip_prefix", [S(a, pad), S(a[:rnd.randint(0, 2)])]), ("split_once", [S(a, pad), S(rnd.choice(["a", "c ", "x"]))]),
-                         ("rsplit_once", [S(a, pad), S(rnd.choice(["a", "c ", "x"]))]), ("strip_suffix", [S(a, pad), S(a[la - rnd.randint(0, 2):] if la else "")])):
+                         ("rsplit_once", [S(a, pad), S(rnd.choice(["a", "c ", "x"]))]), ("strip_suffix", [S(a, pad), S(a[la - rnd.randint(0, 2):] if la else "")]),
+                         # insert / add: char_at(b, i - index) and char_at(self, i - len(b)) as right rotations (round 3)
+                         ("insert", [S(a, pad), {"u": rnd.choice([0, la, rnd.randint(0, 12), 255])}, S(rnd.choice(["", "Q", "QRS"]), rnd.choice([None, 4]))]),
+                         ("add", [S(a, pad), S(rnd.choice(["", "Q", "QRS"]), rnd.choice([None, 4]))])):
             shape, digits = build_inputs(_lib.load(), op, args, bu)
             ref = prog(op, shape, bu).run_plain(digits.astype("int64"))
             fast = prog(op + "_logdepth", shape, bu).run_plain(digits.astype("int64"))

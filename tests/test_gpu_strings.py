@@ -424,6 +424,10 @@ def test_replacen_and_splitn_logdepth_on_gpu(keys):
             assert A.replacen(sk, P, R, api.FheUsize.new(ck, n), 44).decrypt(ck) == want, n
         grow = api.FheString.new(ck, "a-b-c").replacen(sk, api.FheString.new(ck, "-"), api.FheString.new(ck, "+++"), api.FheUsize.new(ck, 1), 12)
         assert grow.decrypt(ck) == "a+++b-c"
+        # insert / add / substr_end: barrel shifters instead of slots^2 one-hot selections
+        assert A.insert(sk, api.FheUsize.new(ck, 4), api.FheString.new(ck, "big ", 6)).decrypt(ck) == text[:4] + "big " + text[4:]
+        assert A.add(sk, api.FheString.new(ck, "!!")).decrypt(ck) == text + "!!"
+        assert A.substr_end(sk, api.FheUsize.new(ck, 4), api.FheUsize.new(ck, 8)).decrypt(ck) == text[4:8]
         # splitn / rsplitn: truncate (split.rs:86-113) as a prefix count over the is_some flags
         B, C = api.FheString.new(ck, "a,b,,c,d", 10), api.FheString.new(ck, ",")
         for n in (0, 1, 2, 4, 9):
