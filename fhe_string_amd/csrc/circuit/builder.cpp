@@ -200,9 +200,15 @@ Blk Builder::clean(const Blk &a) {
   return pbs(a, [m](uint64_t v) { return v % m; });
 }
 
+// A block whose degree bound reaches the message modulus may hold a value that does (a packed length, an automaton
+// state): it is refreshed with the IDENTITY lookup, value intact.  `clean` (value mod msg_mod) is for digits only --
+// round 3 found a packed length of 4 turned into 0 here (strings.cpp: low_value).
 Blk Builder::tame(const Blk &a, int64_t coef) {
   if (a.trivial()) return a;
-  if (a.noise * (double)(coef * coef) > noise_cap_ / 2) return clean(a);
+  if (a.noise * (double)(coef * coef) > noise_cap_ / 2) {
+    if (a.deg < (uint32_t)msg_mod()) return clean(a);
+    return pbs(a, [](uint64_t v) { return v; });
+  }
   return a;
 }
 

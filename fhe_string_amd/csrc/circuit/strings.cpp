@@ -661,6 +661,14 @@ struct S {
     auto low_value = [&](const Radix &r, uint32_t bound) {  // a length <= bound <= 7 as ONE block
       Blk v = r.size() > 1 ? b.add(b.tame(r[0], 1), b.scale(b.tame(r[1], o.M), o.M)) : b.tame(r[0], 1);
       v.deg = std::min<uint32_t>(v.deg, bound);
+      // a value that can reach the message modulus must not meet Builder::tame with noise to shed: tame re-bootstraps
+      // modulo msg_mod (it is meant for digits) -- a length of 4 or 5 became 0 or 1 inside the bivariate lookup below
+      // when max_len(p) was 4 or 5 (found in round 3 with a 4-character pattern; round 2 tested patterns up to 3).
+      // One identity lookup hands on a fresh block with the value intact.
+      if (bound >= (uint32_t)o.M && !v.trivial()) {
+        v = b.pbs(v, [](uint64_t x) { return x; });
+        v.deg = bound;
+      }
       return v;
     };
     // cover = max(len(p) + [len(s) == 0] - 1, 0) <= Pmax

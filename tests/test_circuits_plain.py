@@ -306,10 +306,14 @@ def test_logdepth_equals_faithful_on_random_inputs(libs):
     automaton's window of 7, empty pattern, matches at the ends)"""
     import numpy as np
     rnd = random.Random(0x10D)
-    for trial in range(70):
-        la = rnd.randint(0, 9)
+    for trial in range(90):
+        la = rnd.randint(0, 9) if trial < 70 else rnd.randint(7, 12)
         a = "".join(rnd.choice("xa") for _ in range(la))
         p = "".join(rnd.choice("xa") for _ in range(rnd.randint(0, 3)))
+        if trial >= 70:    # occurring patterns of 4 .. 7 characters (the automaton's window goes to 7)
+            lp = rnd.randint(4, 7)
+            i0 = rnd.randint(0, la - lp)
+            p = a[i0:i0 + lp]
         a_pad = rnd.choice([None, la + rnd.randint(0, 3)])
         p_pad = rnd.choice([None, len(p) + rnd.randint(0, 5)])
         for op in ("find", "rfind", "lt", "ge", "split", "rsplit", "split_inclusive", "split_terminator", "rsplit_terminator"):
@@ -404,11 +408,16 @@ def test_logdepth_replace_equals_the_references_loop(libs):
     from tests.progs import build_inputs
     rnd = random.Random(0x5EED)
     bu = num_blocks_usize(255)
-    seen = {"empty_p": 0, "empty_s": 0, "grow": 0, "shrink": 0}
-    for trial in range(150):
-        la = rnd.randint(0, 8)
+    seen = {"empty_p": 0, "empty_s": 0, "grow": 0, "shrink": 0, "long_p": 0}
+    for trial in range(190):
+        la = rnd.randint(0, 8) if trial < 150 else rnd.randint(6, 11)
         a = "".join(rnd.choice("xa") for _ in range(la))
         p = "".join(rnd.choice("xa") for _ in range(rnd.randint(0, 3)))
+        if trial >= 150:   # patterns of 4 .. 7 characters that DO occur (round 3: a length >= msg_mod was lost, see low_value)
+            lp = rnd.randint(4, 7)
+            i0 = rnd.randint(0, la - lp) if la >= lp else 0
+            p = a[i0:i0 + lp] if la >= lp else "xaxa"
+        seen["long_p"] += len(p) >= 4
         r = "".join(rnd.choice("yz") for _ in range(rnd.randint(0, 3)))
         a_pad = rnd.choice([None, la + rnd.randint(0, 3)])
         p_pad = rnd.choice([None, len(p) + rnd.randint(0, 3)])
@@ -437,11 +446,16 @@ def test_logdepth_replacen_equals_the_references_loop(libs):
     from tests.progs import build_inputs
     rnd = random.Random(0x5EED + 7)
     bu = num_blocks_usize(255)
-    seen = {"empty_p": 0, "empty_s": 0, "n0": 0, "n_small": 0, "n_big": 0}
-    for trial in range(200):
-        la = rnd.randint(0, 8)
+    seen = {"empty_p": 0, "empty_s": 0, "n0": 0, "n_small": 0, "n_big": 0, "long_p": 0}
+    for trial in range(240):
+        la = rnd.randint(0, 8) if trial < 200 else rnd.randint(6, 11)
         a = "".join(rnd.choice("xa") for _ in range(la))
         p = "".join(rnd.choice("xa") for _ in range(rnd.randint(0, 3)))
+        if trial >= 200:   # patterns of 4 .. 7 characters that occur
+            lp = rnd.randint(4, 7)
+            i0 = rnd.randint(0, la - lp) if la >= lp else 0
+            p = a[i0:i0 + lp] if la >= lp else "xaxa"
+        seen["long_p"] += len(p) >= 4
         r = "".join(rnd.choice("yz") for _ in range(rnd.randint(0, 3)))
         a_pad = rnd.choice([None, la + rnd.randint(0, 3)])
         p_pad = rnd.choice([None, len(p) + rnd.randint(0, 3)])

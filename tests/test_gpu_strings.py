@@ -422,6 +422,10 @@ def test_replacen_and_splitn_logdepth_on_gpu(keys):
         for n in (0, 1, 3, 200):
             want = text.replace("fish", "ox", n)
             assert A.replacen(sk, P, R, api.FheUsize.new(ck, n), 44).decrypt(ck) == want, n
+        # an UNPADDED 4-character pattern: max_len(p) = 4 = the message modulus (round 3: its packed length was lost)
+        P4 = api.FheString.new(ck, "fish")
+        assert A.replace(sk, P4, R, 44).decrypt(ck) == text.replace("fish", "ox")
+        assert A.replacen(sk, P4, R, api.FheUsize.new(ck, 2), 44).decrypt(ck) == text.replace("fish", "ox", 2)
         grow = api.FheString.new(ck, "a-b-c").replacen(sk, api.FheString.new(ck, "-"), api.FheString.new(ck, "+++"), api.FheUsize.new(ck, 1), 12)
         assert grow.decrypt(ck) == "a+++b-c"
         # insert / add / substr_end: barrel shifters instead of slots^2 one-hot selections
