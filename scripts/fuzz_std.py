@@ -1,0 +1,66 @@
+"""Developer fuzz (CPU, plaintext model): the SERIAL circuits (the default) against Python's str on inputs longer than the
+unit tests' -- only where the reference's behaviour is std's (non-empty occurring or random patterns, no empty-pattern
+split / replace).  Prints every disagreement; exit code 1 if there is one.
+    python scripts/fuzz_std.py [trials] [seed]"""
+import random
+import sys
+
+sys.path.insert(0, ".")
+from tests.test_circuits_plain import S, run_ext  # noqa: E402
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+
+
+def check(op, args, want, ctx):
+    global bad
+    got = run_ext(op, args)[0]
+    if got != want:
+        bad += 1
+        print("MISMATCH", op, ctx, "circuit:", got, "std:", want, flush=True)
+
+
+for t in range(trials):
+    la = rnd.randint(6, 32)
+    alpha = rnd.choice(["ab", "abc", "ab ", "xy,"])
+    a = "".join(rnd.choice(alpha) for _ in range(la))
+    lp = rnd.randint(1, 6)
+    i0 = rnd.randint(0, la - lp)
+    p = a[i0:i0 + lp] if rnd.random() < 0.8 else "".join(rnd.choice(alpha) for _ in range(lp))
+    a_pad = rnd.choice([None, la + rnd.randint(0, 3)])
+    p_pad = rnd.choice([None, lp + rnd.randint(0, 2)])
+    r = "".join(rnd.choice("QR") for _ in range(rnd.randint(1, 3)))
+    n = rnd.choice([0, 1, 2, 5])
+    ctx = (a, a_pad, p, p_pad, r, n)
+    A, P, R = S(a, a_pad), S(p, p_pad), S(r)
+    i = a.find(p)
+    check("find", [A, P], None if i < 0 else i, ctx)
+    i = a.rfind(p)
+    check("rfind", [A, P], None if i < 0 else i, ctx)
+    check("contains", [A, P], p in a, ctx)
+    check("starts_with", [A, P], a.startswith(p), ctx)
+    check("split", [A, P], a.split(p), ctx)
+    # rsplit / rsplitn with a pattern of more than one character follow the REFERENCE, not std: its
+    # rfind_all_non_overlapping drops every match at a position k with k + 1 < len(p) and never suppresses overlaps
+    # (search.rs:136-149; tests/ref_model.py restates it, tests/test_circuits_plain.py pins it)
+    if len(p) == 1:
+        check("rsplit", [A, P], list(reversed(a.rsplit(p))), ctx)
+        check("rsplitn", [A, {"u": n}, P], [] if n == 0 else list(reversed(a.rsplit(p, n - 1))), ctx)
+    check("splitn", [A, {"u": n}, P], [] if n == 0 else a.split(p, n - 1), ctx)
+    rep = a.replace(p, r)
+    check("replace", [A, P, R, {"i": len(rep) + 2}], rep, ctx)
+    repn = a.replace(p, r, n)
+    check("replacen", [A, P, R, {"u": n}, {"i": len(repn) + 2}], repn, ctx)
+    check("lt", [A, P], a < p, ctx)
+    check("ge", [A, P], a >= p, ctx)
+    check("eq", [A, S(a, a_pad)], True, ctx)
+    check("len", [A], len(a), ctx)
+    w = "".join(rnd.choice("a b\t") for _ in range(rnd.randint(0, 24)))
+    check("trim", [S(w, rnd.choice([None, len(w) + 2]))], w.strip(" \t"), (w,))
+    check("split_ascii_whitespace", [S(w)], w.split(), (w,))
+    k = rnd.randint(0, la)
+    check("insert", [A, {"u": k}, R], a[:k] + r + a[k:], ctx + (k,))
+    check("add", [A, R], a + r, ctx)
+    print(f"trial {t + 1}/{trials}: {bad} mismatch(es) so far", flush=True)
+sys.exit(1 if bad else 0)

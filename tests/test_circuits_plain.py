@@ -477,6 +477,18 @@ def test_logdepth_replacen_equals_the_references_loop(libs):
     assert fast.n_levels * 10 < ref.n_levels and fast.n_pbs * 2 < ref.n_pbs, (fast.n_pbs, ref.n_pbs, fast.n_levels, ref.n_levels)
 
 
+def test_fuzzers_on_longer_inputs(libs):
+    """a few trials of the two developer fuzzers (inputs up to 40 characters, occurring patterns of 1..7 characters):
+    log-depth forms against serial forms, serial forms against Python's str where the reference behaves like std"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script, seed in (("scripts/fuzz_logdepth.py", "11"), ("scripts/fuzz_std.py", "12")):
+        r = subprocess.run([sys.executable, script, "3", seed], cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_find_pred_scans(libs):
     """find_pred_unchecked / rfind_pred_unchecked (search.rs:196-213): the index scan over the closure's results"""
     rnd = random.Random(11)
