@@ -410,6 +410,46 @@ def test_config5_multibit3_find_rfind_and_cli_shaped_padded_pattern(libs):
 
 
 @pytest.mark.gpu
+def test_logdepth_fuzz_with_longer_inputs_on_gpu(keys):
+    """the log-depth mode on real ciphertexts with inputs of 12-24 characters and OCCURRING patterns of 3-6 characters
+    (round 3: the unit tests' patterns of up to 3 characters had hidden a lost pattern length): decrypted results equal
+    to Python's str"""
+    import random
+    ck, sk = keys
+    rnd = random.Random(0xF4E5F033)
+    E = lambda s, pad=None: api.FheString.new(ck, s, pad)
+    U = lambda v: api.FheUsize.new(ck, v)
+    sk.set_logdepth(True)
+    try:
+        for trial in range(5):
+            la = rnd.randint(12, 24)
+            a = "".join(rnd.choice("ab ,") for _ in range(la))
+            lp = rnd.randint(3, 6)
+            i0 = rnd.randint(0, la - lp)
+            p = a[i0:i0 + lp]
+            pad, p_pad = rnd.choice([None, la + 2]), rnd.choice([None, lp + 1])
+            A, P = E(a, pad), E(p, p_pad)
+            ctx = (a, pad, p, p_pad)
+            assert A.find(sk, P).decrypt(ck) == a.find(p), ctx
+            assert A.rfind(sk, P).decrypt(ck) == a.rfind(p), ctx
+            assert A.split(sk, P).decrypt(ck) == a.split(p), ctx
+            n = rnd.randint(0, 3)
+            assert A.splitn(sk, U(n), P).decrypt(ck) == (a.split(p, n - 1) if n else []), ctx + (n,)
+            r = rnd.choice(["y", "zzz"])   # (an EMPTY replacement follows the reference's loop, not std: tests/test_circuits_plain.py)
+            res, resn = a.replace(p, r), a.replace(p, r, n)
+            assert A.replace(sk, P, E(r), len(res) + 1).decrypt(ck) == res, ctx + (r,)
+            assert A.replacen(sk, P, E(r), U(n), len(resn) + 1).decrypt(ck) == resn, ctx + (r, n)
+            k = rnd.randint(0, la)
+            assert A.insert(sk, U(k), E("QR")).decrypt(ck) == a[:k] + "QR" + a[k:], ctx + (k,)
+            assert A.substr_end(sk, U(i0), U(i0 + lp)).decrypt(ck) == p, ctx
+            assert A.trim(sk).decrypt(ck) == a.strip(" "), ctx
+            i = a.find(p)
+            assert A.split_once(sk, P).decrypt(ck) == (a[:i], a[i + lp:]), ctx
+    finally:
+        sk.set_logdepth(False)
+
+
+@pytest.mark.gpu
 def test_replacen_and_splitn_logdepth_on_gpu(keys):
     """replacen with the log-depth transducer (round 3: the first n_max occurrences by a prefix count over the
     automaton's accepted positions) on real ciphertexts: equal to str.replace(p, s, n) and to the faithful loop"""
