@@ -258,7 +258,7 @@ struct S {
   // gathered find_all)
   std::vector<Blk> suppress_overlaps(const std::vector<Blk> &matches, const Str &s) {
     Radix s_len = len(s);
-    if (fast && o.b.space() >= 16 && max_len(s) >= 1 && max_len(s) - 1 <= 7) return suppress_overlaps_logdepth(matches, s_len, max_len(s) - 1);
+    if (fast && o.b.space() >= 16 && max_len(s) >= 1 && max_len(s) - 1 <= automaton_window()) return suppress_overlaps_logdepth(matches, s_len, max_len(s) - 1);
     if (fast && max_len(s) == 0) return matches;  // the empty pattern suppresses nothing (j < 0 never holds)
     Blk in_match = o.trivial_bool(false);
     Radix j = usize(0);
@@ -510,6 +510,11 @@ struct S {
     return v;
   }
   // msg_mod^Bu when it is small enough for the shifter networks, else 0
+  // Largest state the overlap automaton may carry: states up to 7 are gated by a boolean in ONE lookup on 8 * c + x, whose
+  // input variance is 64 x the boolean's -- fine under the classic sets' cap of 256 units, impossible under the multi-bit
+  // sets' 34 (round 3: such programs failed to compile with "input noise exceeds the cap"); those sets keep the 2-bit
+  // states (window 3) and run longer patterns through the reference's serial loop.
+  size_t automaton_window() const { return o.b.noise_cap() >= 64.0 + 8.0 ? 7 : 3; }
   size_t usize_modulus() const {
     size_t T = 1;
     for (int t = 0; t < Bu; t++) {
@@ -640,7 +645,7 @@ struct S {
   bool replace_fast_applies(const Str &a, const Str &p, const Str &sub, const Radix *n_max, size_t l) const {
     const size_t T = usize_modulus();
     // (the transducer's tables pack a state and a symbol count into one lookup input: 4 bits of plaintext space)
-    if (!(fast && o.b.space() >= 16 && max_len(p) <= 7 && max_len(sub) <= 4 && T != 0 && l + a.size() <= T && l >= 1)) return false;
+    if (!(fast && o.b.space() >= 16 && max_len(p) <= automaton_window() && max_len(sub) <= 4 && T != 0 && l + a.size() <= T && l >= 1)) return false;
     // replacen: min(n_max, l) * len(s) (the shift of the degenerate case) has to stay below the modulus as well
     return !n_max || ((int)n_max->size() == Bu && (l + 1) * std::max<size_t>(max_len(sub), 1) + a.size() <= T);
   }

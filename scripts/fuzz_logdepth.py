@@ -1,12 +1,21 @@
 """Developer fuzz (CPU, plaintext model of the compiled circuits): every operation's log-depth form against its serial
 form on random inputs that are LONGER than the unit tests' (inputs up to 40 characters, occurring patterns of 1..7
 characters, paddings, n_max).  Prints every disagreement; exit code 1 if there is one.
-    python scripts/fuzz_logdepth.py [trials] [seed]"""
+    python scripts/fuzz_logdepth.py [trials] [seed] [multibit2|multibit3]"""
 import random
 import sys
 
 sys.path.insert(0, ".")
+import tests.test_circuits_plain as tcp  # noqa: E402
 from tests.test_circuits_plain import S, run_ext  # noqa: E402
+
+if len(sys.argv) > 3:   # parameter set: "multibit2" / "multibit3" compile the same circuits under a noise cap of 34 instead of 256
+    import ctypes as C
+    from fhe_string_amd._lib import Params, check, load
+    _p = Params()
+    check(load(strict=False).fhes_params_multibit(C.byref(_p), int(sys.argv[3][-1])))
+    tcp.default_params = lambda: _p
+    tcp._cache.clear()
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

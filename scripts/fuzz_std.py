@@ -1,12 +1,21 @@
 """Developer fuzz (CPU, plaintext model): the SERIAL circuits (the default) against Python's str on inputs longer than the
 unit tests' -- only where the reference's behaviour is std's (non-empty occurring or random patterns, no empty-pattern
 split / replace).  Prints every disagreement; exit code 1 if there is one.
-    python scripts/fuzz_std.py [trials] [seed]"""
+    python scripts/fuzz_std.py [trials] [seed] [multibit2|multibit3]"""
 import random
 import sys
 
 sys.path.insert(0, ".")
+import tests.test_circuits_plain as tcp  # noqa: E402
 from tests.test_circuits_plain import S, run_ext  # noqa: E402
+
+if len(sys.argv) > 3:   # parameter set: "multibit2" / "multibit3" compile the same circuits under a noise cap of 34 instead of 256
+    import ctypes as C
+    from fhe_string_amd._lib import Params, check, load
+    _p = Params()
+    check(load(strict=False).fhes_params_multibit(C.byref(_p), int(sys.argv[3][-1])))
+    tcp.default_params = lambda: _p
+    tcp._cache.clear()
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

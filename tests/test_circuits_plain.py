@@ -484,9 +484,25 @@ def test_fuzzers_on_longer_inputs(libs):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for script, seed in (("scripts/fuzz_logdepth.py", "11"), ("scripts/fuzz_std.py", "12")):
-        r = subprocess.run([sys.executable, script, "3", seed], cwd=root, capture_output=True, text=True, timeout=600)
+    for script, seed, extra in (("scripts/fuzz_logdepth.py", "11", []), ("scripts/fuzz_std.py", "12", []),
+                                ("scripts/fuzz_logdepth.py", "13", ["multibit2"])):   # the multi-bit sets: noise cap 34 instead of 256
+        r = subprocess.run([sys.executable, script, "3", seed] + extra, cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_every_logdepth_form_compiles_under_the_multibit_noise_cap(libs):
+    """round 3: with patterns of 4 and more characters the automaton's 3-bit states need a lookup on 8 * c + x -- 64 x the
+    boolean's variance, more than the multi-bit sets' cap of 34 allows; those programs used to fail with "input noise
+    exceeds the cap".  Every operation must compile for every pattern width under both multi-bit sets (wide patterns
+    take the serial loop there)."""
+    from fhe_string_amd.api import multibit_params
+    bu = num_blocks_usize(255)
+    for g in (2, 3):
+        params = multibit_params(g)
+        for op in ("replace", "replacen", "split", "rsplit", "splitn", "split_inclusive", "split_once", "strip_suffix", "find"):
+            for p_slots in (2, 4, 5, 6, 8, 10):
+                shape = [21, p_slots, 3, 20] if op.startswith("replace") else [21, p_slots]
+                Prog(params, op + "_logdepth", shape, bu)
 
 
 def test_find_pred_scans(libs):
