@@ -1,7 +1,7 @@
 """Developer fuzz (CPU, REAL encryption on the oracle, toy parameter set): compiled programs of the log-depth forms added
 or changed in round 3 run on the oracle; every decrypted output block must equal the plaintext model's -- the check that
 the builder's noise / degree bookkeeping holds under real noise, not only that the circuits compute the right function.
-    python scripts/fuzz_oracle.py [trials] [seed]"""
+    python scripts/fuzz_oracle.py [trials] [seed] [toy | toy_multibit2 | toy_multibit3]"""
 import random
 import sys
 
@@ -14,7 +14,7 @@ from tests.progs import Prog, build_inputs, num_blocks_usize  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-w = world("toy")
+w = world(sys.argv[3] if len(sys.argv) > 3 else "toy")
 bu = num_blocks_usize(255)
 lib = _lib.load()
 bad = 0
