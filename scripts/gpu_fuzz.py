@@ -56,6 +56,31 @@ for t in range(trials):
         check("insert", A.insert(sk, U(k), E("QR")).decrypt(ck), a[:k] + "QR" + a[k:], ctx + (k,))
         check("lt", ck.decrypt_bool(A.lt(sk, P)), a < p, ctx)
         check("len", A.len(sk).decrypt(ck), la, ctx)
+        if t % 2 == 1:   # every other trial: the rest of the API whose behaviour is std's
+            B = ck.decrypt_bool
+            check("le/gt/ge", (B(A.le(sk, P)), B(A.gt(sk, P)), B(A.ge(sk, P))), (a <= p, a > p, a >= p), ctx)
+            check("eq/ne", (B(A.eq(sk, E(a, la + 1))), B(A.ne(sk, P))), (True, a != p), ctx)
+            check("starts_with", B(A.starts_with(sk, P)), a.startswith(p), ctx)
+            i = a.find(p)
+            check("split_once", A.split_once(sk, P).decrypt(ck), (a[:i], a[i + len(p):]) if i >= 0 else None, ctx)
+            j = a.rfind(p)
+            check("rsplit_once", A.rsplit_once(sk, P).decrypt(ck), (a[:j], a[j + len(p):]) if j >= 0 else None, ctx)
+            check("strip_prefix", A.strip_prefix(sk, P).decrypt(ck), a[len(p):] if a.startswith(p) else None, ctx)
+            parts = a.split(p)
+            check("split_inclusive", A.split_inclusive(sk, P).decrypt(ck),
+                  [x + p for x in parts[:-1]] + ([parts[-1]] if parts[-1] else []), ctx)
+            check("split_terminator", A.split_terminator(sk, P).decrypt(ck), parts[:-1] if parts[-1] == "" else parts, ctx)
+            check("split_ascii_whitespace", A.split_ascii_whitespace(sk).decrypt(ck), a.split(), ctx)
+            check("trim_start/end", (A.trim_start(sk).decrypt(ck), A.trim_end(sk).decrypt(ck)), (a.lstrip(" "), a.rstrip(" ")), ctx)
+            check("upper/lower", (A.to_uppercase(sk).decrypt(ck), E(a.upper(), pad).to_lowercase(sk).decrypt(ck)), (a.upper(), a.lower()), ctx)
+            x, y = sorted((rnd.randint(0, la), rnd.randint(0, la)))
+            check("substr_from/to/end", (A.substr_from(sk, U(x)).decrypt(ck), A.substr_to(sk, U(y)).decrypt(ck),
+                                         A.substr_end(sk, U(x), U(y)).decrypt(ck)), (a[x:], a[:y], a[x:y]), ctx + (x, y))
+            check("add", A.add(sk, E("!?")).decrypt(ck), a + "!?", ctx)
+            m = rnd.randint(0, 3)
+            check("repeat", E(p).repeat(sk, U(m), 3 * len(p) + 1).decrypt(ck), (p * m)[:3 * len(p) + 1], ctx + (m,))
+            sv = A.split(sk, P)
+            check("slices.len", sv.len(sk).decrypt(ck), len(parts), ctx)
         print(f"trial {t + 1}/{trials} {mode}: {bad} mismatch(es), {time.time() - t_start:.0f} s", flush=True)
 sk.set_logdepth(False)
 sk.close()
