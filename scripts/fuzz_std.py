@@ -71,5 +71,22 @@ for t in range(trials):
     k = rnd.randint(0, la)
     check("insert", [A, {"u": k}, R], a[:k] + r + a[k:], ctx + (k,))
     check("add", [A, R], a + r, ctx)
+    i = a.find(p)
+    check("split_once", [A, P], [a[:i], a[i + len(p):]] if i >= 0 else None, ctx)
+    j = a.rfind(p)
+    check("rsplit_once", [A, P], [a[:j], a[j + len(p):]] if j >= 0 else None, ctx)
+    check("strip_prefix", [A, P], a[len(p):] if a.startswith(p) else None, ctx)
+    parts = a.split(p)
+    check("split_inclusive", [A, P], [x + p for x in parts[:-1]] + ([parts[-1]] if parts[-1] else []), ctx)
+    check("split_terminator", [A, P], parts[:-1] if parts[-1] == "" else parts, ctx)
+    x, y = sorted((rnd.randint(0, la), rnd.randint(0, la)))
+    check("substr_from", [A, {"u": x}], a[x:], ctx + (x,))
+    check("substr_to", [A, {"u": y}], a[:y], ctx + (y,))
+    check("substr_end", [A, {"u": x}, {"u": y}], a[x:y], ctx + (x, y))
+    m = rnd.randint(0, 3)
+    check("repeat", [P, {"u": m}, {"i": 3 * len(p) + 1}], (p * m)[:3 * len(p) + 1], ctx + (m,))
+    check("to_uppercase", [A], a.upper(), ctx)
+    check("trim_start", [S(w)], w.lstrip(" \t"), (w,))
+    check("trim_end", [S(w)], w.rstrip(" \t"), (w,))
     print(f"trial {t + 1}/{trials}: {bad} mismatch(es) so far", flush=True)
 sys.exit(1 if bad else 0)
