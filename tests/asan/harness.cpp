@@ -48,6 +48,9 @@ static void circuits(const fhes_params &p, const char *label) {
       {"substr_eq", {5, 1, 3}}, {"is_uppercase", {}}, {"is_lowercase", {}}, {"is_whitespace", {}},
       {"char_to_lowercase", {}}, {"char_to_uppercase", {}}, {"usize_from_bool", {}},
       {"find_all_range", {9, 3, 2, 6}}, {"any_of", {7}}, {"index_of", {7}}, {"rindex_of", {7}}, {"find_pred", {6}},
+      // wide patterns: the automaton's 3-bit states, the packed pattern length (round 3), the serial fall-back under the multi-bit cap
+      {"replace", {12, 6, 3, 12}}, {"replacen", {12, 7, 4, 14}}, {"split", {12, 8}}, {"splitn", {12, 5}}, {"rsplitn", {12, 6}},
+      {"insert", {12, 5}}, {"substr_end", {12}},
   };
   int n_ok = 0;
   for (const auto &c : cases)
