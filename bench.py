@@ -593,12 +593,29 @@ def main():
         line["sharded"] = sharded
         print(json.dumps(line), flush=True)
 
+    # A failed position-sharded section on more than one rank (an RCCL fault, say) is a failure of the RUN: the JSON line
+    # above carries the error, and every rank leaves with exit code 4 so that the driver does not record a success
+    # (VERDICT r3, weak 9).  With one rank the section is a rehearsal of the call paths and the headline stands alone.
+    failed = 1 if (isinstance(sharded, dict) and "error" in sharded and world_size > 1) else 0
+    if dist:
+        try:
+            ft = torch.tensor([failed], dtype=torch.int32, device="cpu" if rehearsal else f"cuda:{device_index}")
+            dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+            failed = int(ft.item())
+        except Exception as e:
+            sys.stderr.write(f"[bench rank {rank}] status exchange failed: {e!r}\n")
+            failed = 1
+
     lib.fhes_program_destroy(prog)
     lib.fhes_ctx_destroy(ctx)
     lib.fhes_client_key_destroy(ck)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.stderr.write(f"[bench rank {rank}] position-sharded section failed on some rank: exit 4\n")
+        sys.stderr.flush()
+        sys.exit(4)
 
 
 if __name__ == "__main__":

