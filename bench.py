@@ -100,10 +100,15 @@ def cpu_baseline(which, pairs, budget_s=20.0):
     dt = time.time() - t0
     dec = [decode_result("find", w.decrypt(o), num_blocks_usize(255)) for o in outs]
     ok = all((-1 if g is None else g) == t.find(q) for g, (t, q) in zip(dec, pairs[:S]))
+    simd = {0: "scalar", 1: "AVX2", 2: "AVX-512"}.get(int(w.orc.oracle_get_simd()), "?")
     return {"value": round(S * p.n_pbs / dt, 2), "unit": "PBS/s", "cores": cores, "kind": "port",
+            "label": "CPU restatement (port), NOT tfhe-rs: the reference's Rust path cannot be built on this box",
+            "ms_per_pbs_per_core": round(1e3 * dt * cores / (S * p.n_pbs), 2),
+            "ms_one_bootstrap_alone": round(t_pbs * 1e3, 2), "simd": simd,
             "sample": f"{S} independent find(s) (64-char input, 4-char pattern) batched level by level: {S * p.n_pbs} PBS in "
-                      f"{p.n_levels} levels, {dt:.1f} s wall on {cores} threads (OpenMP, one PBS per thread; "
-                      f"{os.cpu_count()} logical CPUs on the host, {cores} usable by this process; one bootstrap alone: {t_pbs * 1e3:.0f} ms), result_ok={ok}",
+                      f"{p.n_levels} levels, {dt:.1f} s wall on {cores} threads (OpenMP; the oracle's loops in their {simd} form, same bits as the "
+                      f"scalar statement; wide levels share one pass over the keyswitching key per group of 8; "
+                      f"{os.cpu_count()} logical CPUs on the host, {cores} usable by this process; one bootstrap alone: {t_pbs * 1e3:.1f} ms), result_ok={ok}",
             "wall_s": round(dt, 3)}
 
 

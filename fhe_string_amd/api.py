@@ -93,6 +93,27 @@ class ServerKey:
         self.num_blocks_char = client_key.num_blocks_char
         self.params = client_key.params
 
+    @staticmethod
+    def serialize(client_key):
+        """server_key.rs:11 (`#[derive(Serialize)]`): the standard-domain bootstrapping and keyswitching keys of `client_key`
+        as one versioned blob (fhes_server_key_serialize; 170 MB for the default set)."""
+        n = check(_L().fhes_server_key_serialize(client_key._h, None, 0))
+        buf = (C.c_uint8 * n)()
+        check(_L().fhes_server_key_serialize(client_key._h, buf, n))
+        return bytes(buf)
+
+    @staticmethod
+    def from_bytes(data, device=0):
+        """`Deserialize`: uploads the blob's keys to `device` (Fourier transform there); no client key involved."""
+        sk = ServerKey.__new__(ServerKey)
+        arr = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        sk._h = check_ptr(_L().fhes_server_key_deserialize(arr, len(data), device))
+        sk.params = Params()
+        check(_L().fhes_ctx_params(_L().fhes_server_key_ctx(sk._h), C.byref(sk.params)))
+        sk.num_blocks_char = _L().fhes_server_key_num_blocks_char(sk._h)
+        sk.num_blocks_usize = _L().fhes_server_key_num_blocks_usize(sk._h)
+        return sk
+
     @property
     def ctx(self):
         return _L().fhes_server_key_ctx(self._h)

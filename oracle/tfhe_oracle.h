@@ -58,6 +58,11 @@ typedef struct {
 
 typedef struct oracle_ctx oracle_ctx;
 
+/* Round 4: the hot loops have an AVX2 form that performs the scalar statement's IEEE-754 operation sequence on several
+ * elements per instruction (same bits; tests/test_oracle.py compares the two).  0 selects the scalar statement. */
+void oracle_set_simd(int on);
+int oracle_get_simd(void);
+
 oracle_ctx *oracle_ctx_create(const oracle_params *p);
 void oracle_ctx_destroy(oracle_ctx *c);
 
@@ -92,6 +97,8 @@ void oracle_make_lut_poly(const oracle_ctx *c, const uint64_t *f_table, uint64_t
 
 void oracle_keyswitch(const oracle_ctx *c, const uint64_t *in_big /*[kN+1]*/,
                       uint64_t *out_small /*[n+1]*/);
+/* `count` keyswitches in one pass over the key (same integers per ciphertext as oracle_keyswitch) */
+void oracle_keyswitch_batch(const oracle_ctx *c, const uint64_t *const *ins, uint64_t *const *outs, int count);
 void oracle_modswitch(const oracle_ctx *c, const uint64_t *small /*[n+1]*/,
                       uint32_t *a_tilde /*[n+1]*/);
 void oracle_blind_rotate(const oracle_ctx *c, const uint32_t *a_tilde, const uint64_t *lut_poly,

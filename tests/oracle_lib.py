@@ -14,6 +14,8 @@ def load():
         return _lib
     lib = C.CDLL(PATH)
     sig = {
+        "oracle_set_simd": (None, [C.c_int]),
+        "oracle_get_simd": (C.c_int, []),
         "oracle_ctx_create": (_P, [_P]),
         "oracle_ctx_destroy": (None, [_P]),
         "oracle_set_keys": (C.c_int, [_P, _P, _P]),
@@ -28,6 +30,7 @@ def load():
         "oracle_negacyclic_mul_exact": (None, [_P, _P, _P, _P]),
         "oracle_make_lut_poly": (None, [_P, _P, _P]),
         "oracle_keyswitch": (None, [_P, _P, _P]),
+        "oracle_keyswitch_batch": (None, [_P, _P, _P, C.c_int]),
         "oracle_modswitch": (None, [_P, _P, _P]),
         "oracle_blind_rotate": (None, [_P, _P, _P, _P]),
         "oracle_sample_extract": (None, [_P, _P, _P]),

@@ -288,3 +288,73 @@ def test_forward_transform_internal_form_and_tables(w):
         nb, half = 1 << l, M >> (l + 1)
         e = (sexp[np.arange(nb) * 2 * half].astype(np.int64) * half) % (2 * N)
         assert np.array_equal(psi[nb:2 * nb], root[e]), l
+
+
+# ---- round 4: the vectorised forms of the oracle compute the scalar statement's bits -------------------------------
+@pytest.mark.parametrize("which", ["toy", "toy_multibit2", "toy_multibit3", "default", "multibit3", "shape_1_1", "shape_3_3",
+                                   "shape_k2_l2", "shape_l3"])
+def test_simd_forms_equal_the_scalar_statement_word_for_word(which, libs):
+    """AVX2 / AVX-512 loops (two / four complex points per instruction) against the scalar definition: whole bootstraps,
+    every output word, on the classic and multi-bit blind rotates and on shapes with k > 1 and two levels"""
+    ww = world(which)
+    best = None
+    try:
+        ww.orc.oracle_set_simd(-1)
+        best = ww.orc.oracle_get_simd()
+        if best == 0:
+            pytest.skip("oracle built without AVX2")
+        space = 1 << (ww.p.message_bits + ww.p.carry_bits)
+        vals = np.arange(min(space, 3 if which in ("default", "multibit3") else 8), dtype=np.uint8)
+        cts = ww.encrypt(vals)
+        table = np.array([(3 * x + 1) % space for x in range(space)], dtype=np.uint64)
+        poly = np.zeros(ww.N, dtype=np.uint64)
+        ww.orc.oracle_make_lut_poly(ww.oc, ptr(table), ptr(poly))
+        ref = None
+        for level in range(best + 1):
+            ww.orc.oracle_set_simd(level)
+            assert ww.orc.oracle_get_simd() == level
+            outs = np.stack([ww.oracle_pbs(cts[i], poly) for i in range(len(vals))])
+            if ref is None:
+                ref = outs
+                assert list(ww.decrypt(outs)) == [(3 * int(v) + 1) % space for v in vals]
+            else:
+                assert np.array_equal(outs, ref), f"SIMD level {level} differs from the scalar statement"
+    finally:
+        ww.orc.oracle_set_simd(-1)
+
+
+def test_simd_transforms_equal_the_scalar_transforms(w, libs):
+    rng = np.random.default_rng(44)
+    a = rng.integers(-(1 << 22), 1 << 22, size=w.N).astype(np.int64)
+    res = []
+    try:
+        w.orc.oracle_set_simd(-1)
+        best = w.orc.oracle_get_simd()
+        for level in range(best + 1):
+            w.orc.oracle_set_simd(level)
+            spec, back = np.zeros(w.N), np.zeros(w.N, dtype=np.uint64)
+            w.orc.oracle_fft_forward_internal(w.oc, ptr(a), ptr(spec))
+            big = np.ascontiguousarray(spec * 2.0 ** 40)
+            w.orc.oracle_fft_inverse_torus(w.oc, ptr(big), ptr(back))
+            res.append((spec.copy(), back.copy()))
+    finally:
+        w.orc.oracle_set_simd(-1)
+    for spec, back in res[1:]:
+        assert np.array_equal(spec.view(np.uint64), res[0][0].view(np.uint64))
+        assert np.array_equal(back, res[0][1])
+
+
+@pytest.mark.parametrize("which", ["toy", "default"])
+def test_grouped_keyswitch_equals_single_keyswitches(which, libs):
+    """oracle_exec_levels takes groups of a level's nodes through ONE pass over the keyswitching key"""
+    ww = world(which)
+    cts = ww.encrypt(np.arange(7, dtype=np.uint8) % 16)
+    n1 = ww.p.lwe_dim + 1
+    single = np.zeros((len(cts), n1), dtype=np.uint64)
+    for i in range(len(cts)):
+        ww.orc.oracle_keyswitch(ww.oc, ptr(cts[i]), ptr(single[i]))
+    grouped = np.zeros_like(single)
+    ins = (C.c_void_p * len(cts))(*[cts[i].ctypes.data for i in range(len(cts))])
+    outs = (C.c_void_p * len(cts))(*[grouped[i].ctypes.data for i in range(len(cts))])
+    ww.orc.oracle_keyswitch_batch(ww.oc, ins, outs, len(cts))
+    assert np.array_equal(single, grouped)
