@@ -89,6 +89,7 @@ SIGNATURES = {
     "fhes_server_key_create": (_P, [_P, C.c_int32]),
     "fhes_server_key_destroy": (None, [_P]),
     "fhes_server_key_ctx": (_P, [_P]),
+    "fhes_server_key_info": (C.c_int, [_P, _P, _P, _P]),
     "fhes_server_key_set_logdepth": (C.c_int, [_P, C.c_int32]),
     "fhes_string_encrypt": (_P, [_P, C.c_char_p, C.c_int64, _i32p]),
     "fhes_string_trivial": (_P, [_P, C.c_char_p, _i32p]),

@@ -109,9 +109,9 @@ class ServerKey:
         arr = (C.c_uint8 * len(data)).from_buffer_copy(data)
         sk._h = check_ptr(_L().fhes_server_key_deserialize(arr, len(data), device))
         sk.params = Params()
-        check(_L().fhes_ctx_params(_L().fhes_server_key_ctx(sk._h), C.byref(sk.params)))
-        sk.num_blocks_char = _L().fhes_server_key_num_blocks_char(sk._h)
-        sk.num_blocks_usize = _L().fhes_server_key_num_blocks_usize(sk._h)
+        nbc, nbu = C.c_int32(), C.c_int32()
+        check(_L().fhes_server_key_info(sk._h, C.byref(sk.params), C.byref(nbc), C.byref(nbu)))
+        sk.num_blocks_char, sk.num_blocks_usize = nbc.value, nbu.value
         return sk
 
     @property

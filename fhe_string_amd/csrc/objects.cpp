@@ -96,6 +96,14 @@ void fhes_server_key_destroy(fhes_server_key *sk) {
 
 fhes_ctx *fhes_server_key_ctx(fhes_server_key *sk) { return sk ? sk->ctx : nullptr; }
 
+int fhes_server_key_info(const fhes_server_key *sk, fhes_params *params, int32_t *num_blocks_char, int32_t *num_blocks_usize) {
+  if (!sk) return fail(FHES_ERR_INVALID, "null server key");
+  if (params) *params = sk->p;
+  if (num_blocks_char) *num_blocks_char = sk->nb_char;
+  if (num_blocks_usize) *num_blocks_usize = sk->nb_usize;
+  return FHES_OK;
+}
+
 int fhes_server_key_set_comm(fhes_server_key *sk, fhes_comm *comm) {
   if (!sk) return fail(FHES_ERR_INVALID, "null server key");
   std::lock_guard<std::mutex> lk(sk->mu);

@@ -256,6 +256,9 @@ typedef struct fhes_ct fhes_ct;                 /* radix ciphertext: FheString /
 fhes_server_key *fhes_server_key_create(const fhes_client_key *ck, int32_t device);
 void fhes_server_key_destroy(fhes_server_key *sk);
 fhes_ctx *fhes_server_key_ctx(fhes_server_key *sk);
+/* The public facts of a key: its parameter set and the block counts of lib.rs:60-62 (`num_blocks_char`, `num_blocks_usize`;
+ * crate-private fields of server_key.rs:12-17 that a binding needs after fhes_server_key_deserialize).  Any pointer may be NULL. */
+int fhes_server_key_info(const fhes_server_key *sk, fhes_params *params, int32_t *num_blocks_char, int32_t *num_blocks_usize);
 /* Opt-in: every later fhes_string_op on this key runs the "<op>_logdepth" form of its circuit -- the
  * serial scans of the reference (mod.rs:341-349, search.rs:91-109, compare.rs:89-96, split.rs:274-319)
  * replaced by parallel-prefix forms with identical results (tests/test_circuits_plain.py).  Default
