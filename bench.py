@@ -112,6 +112,38 @@ def cpu_baseline(which, pairs, budget_s=20.0):
             "wall_s": round(dt, 3)}
 
 
+N_CU, SPEC_CLOCK_HZ, FP64_VECTOR_PEAK_TFLOPS = 256, 2.4e9, 78.6     # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def against_spec(cr, br_rate):
+    """The same achieved rate against yardsticks that do NOT come from this kernel's own measured slot costs (VERDICT r3,
+    item 3): the guide's issue rates (an f64 instruction 4 cycles, any other VALU instruction 2 cycles per wave on a SIMD-32 at
+    the 2.4 GHz peak clock), the FP64 vector peak in flops, and the share of VALU slots that are not f64 arithmetic."""
+    out = {}
+    try:
+        valu, f64 = cr["valu_per_wave_iter"], cr["f64_per_wave_iter"]
+        cmux = cr["cmux_iterations_per_pbs"]
+        spec_cycles = f64 * 4.0 + (valu - f64) * 2.0          # per wave and CMUX; 4 waves of a PBS on the 4 SIMDs of one CU
+        spec_peak = N_CU * SPEC_CLOCK_HZ / (cmux * spec_cycles)
+        out["peak_at_spec_issue_rates"] = round(spec_peak, 1)
+        out["frac_at_spec_issue_rates"] = round(br_rate / spec_peak, 4)
+        raw, pbs = cr.get("raw", {}), cr.get("pbs_profiled")
+        if pbs and all(k in raw for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64")):
+            flop_per_pbs = (2 * raw["SQ_INSTS_VALU_FMA_F64"] + raw["SQ_INSTS_VALU_ADD_F64"] + raw["SQ_INSTS_VALU_MUL_F64"]) * 64 / pbs
+            tf = flop_per_pbs * br_rate / 1e12
+            out["fp64_mflop_per_pbs"] = round(flop_per_pbs / 1e6, 1)
+            out["fp64_tflops"] = round(tf, 2)
+            out["frac_of_fp64_peak"] = round(tf / FP64_VECTOR_PEAK_TFLOPS, 4)
+        out["non_f64_valu_share"] = round((valu - f64) / valu, 4)
+        if "f64_min_per_wave_iter" in cr:
+            out["f64_min_per_wave_cmux_canonical"] = cr["f64_min_per_wave_iter"]
+        out["spec_note"] = ("`peak` / `frac` price a slot at what scripts/micro/f64_rate.hip measures on the chip; `*_at_spec_issue_rates` at the "
+                            "guide's 4 / 2 cycles and 2.4 GHz; `frac_of_fp64_peak` counts FMA as 2 flops against the 78.6 TF vector peak")
+    except Exception as e:
+        out["spec_error"] = repr(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -494,6 +526,7 @@ def main():
                                                            "two co-resident workgroups recover part of it: `frac_of_serial_sum` > 1"} if lp else None),
                             "achieved_whole_job": round(total_pbs / world_size / dt_max, 1),
                             "frac_whole_job": round(total_pbs / world_size / dt_max / bound, 4),
+                            **against_spec(cr, br_rate),
                             "valu_per_wave_cmux": round(cr["valu_per_wave_iter"], 1), "f64_per_wave_cmux": round(cr["f64_per_wave_iter"], 1),
                             "issue_cycles_f64": cr["issue_cycles_f64_2waves"], "issue_cycles_other": round(cr["issue_cycles_other_next_to_f64"], 3),
                             "clock_ghz_under_load": round(cr["clock_ghz_under_load"], 3),

@@ -246,10 +246,45 @@ AVX512_FN static inline __m512d w_xor(__m512d a, __m512i m) { return _mm512_cast
 #define W_NEG_ODD _mm512_set_epi64(W_SIGN, 0, W_SIGN, 0, W_SIGN, 0, W_SIGN, 0)
 #define W_NEG_ODD_POINTS _mm512_set_epi64(W_SIGN, W_SIGN, 0, 0, W_SIGN, W_SIGN, 0, 0) /* complex points 1 and 3 */
 
+/* one butterfly s = u + t v, d = 2 u - s on four points (t as its two broadcast forms) */
+#define W_BFLY_FWD(u, v, tre, tim, sv, dv)          \
+  do {                                              \
+    sv = _mm512_fmadd_pd(tre, v, u);                \
+    sv = _mm512_fmadd_pd(tim, w_swap(v), sv);       \
+    dv = _mm512_fmsub_pd(two, u, sv);               \
+  } while (0)
+
 AVX512_FN static void fft_fwd_avx512(const oracle_ctx *c, cplx *x) {
   const int M = c->M;
   const __m512d two = _mm512_set1_pd(2.0);
   int half = M / 2, nb = 1;
+  /* two stages per pass over the data while both halves hold at least four points: the butterflies of stage (half) and of
+   * stage (half / 2) on the four quarters of a block -- the same operations on the same operands, half the loads and stores */
+  for (; half >= 8; half >>= 2, nb <<= 2) {
+    const int q = half / 2;
+    for (int b = 0; b < nb; b++) {
+      const __m512d t1 = _mm512_broadcast_f64x2(_mm_loadu_pd((const double *)&c->psi[nb + b]));
+      const __m512d ta = _mm512_broadcast_f64x2(_mm_loadu_pd((const double *)&c->psi[2 * nb + 2 * b]));
+      const __m512d tb = _mm512_broadcast_f64x2(_mm_loadu_pd((const double *)&c->psi[2 * nb + 2 * b + 1]));
+      const __m512d t1re = w_re(t1), t1im = w_xor(w_im(t1), W_NEG_EVEN);
+      const __m512d tare = w_re(ta), taim = w_xor(w_im(ta), W_NEG_EVEN);
+      const __m512d tbre = w_re(tb), tbim = w_xor(w_im(tb), W_NEG_EVEN);
+      double *blk = (double *)(x + (size_t)b * 2 * half);
+      for (int j = 0; j < q; j += 4) {
+        const __m512d x0 = _mm512_loadu_pd(blk + 2 * j), x1 = _mm512_loadu_pd(blk + 2 * (j + q));
+        const __m512d x2 = _mm512_loadu_pd(blk + 2 * (j + half)), x3 = _mm512_loadu_pd(blk + 2 * (j + half + q));
+        __m512d s0, d0, s1, d1, y0, y1, y2, y3;
+        W_BFLY_FWD(x0, x2, t1re, t1im, s0, d0); /* stage (half): pairs (j, j + half) */
+        W_BFLY_FWD(x1, x3, t1re, t1im, s1, d1);
+        W_BFLY_FWD(s0, s1, tare, taim, y0, y1); /* stage (half / 2), first half-block */
+        W_BFLY_FWD(d0, d1, tbre, tbim, y2, y3); /* second half-block */
+        _mm512_storeu_pd(blk + 2 * j, y0);
+        _mm512_storeu_pd(blk + 2 * (j + q), y1);
+        _mm512_storeu_pd(blk + 2 * (j + half), y2);
+        _mm512_storeu_pd(blk + 2 * (j + half + q), y3);
+      }
+    }
+  }
   for (; half >= 4; half >>= 1, nb <<= 1) {
     for (int b = 0; b < nb; b++) {
       const __m512d t = _mm512_broadcast_f64x2(_mm_loadu_pd((const double *)&c->psi[nb + b]));
@@ -257,10 +292,10 @@ AVX512_FN static void fft_fwd_avx512(const oracle_ctx *c, cplx *x) {
       double *blk = (double *)(x + (size_t)b * 2 * half);
       for (int j = 0; j < half; j += 4) {
         const __m512d u = _mm512_loadu_pd(blk + 2 * j), v = _mm512_loadu_pd(blk + 2 * (j + half));
-        __m512d sv = _mm512_fmadd_pd(tre, v, u);
-        sv = _mm512_fmadd_pd(tim, w_swap(v), sv);
+        __m512d sv, dv;
+        W_BFLY_FWD(u, v, tre, tim, sv, dv);
         _mm512_storeu_pd(blk + 2 * j, sv);
-        _mm512_storeu_pd(blk + 2 * (j + half), _mm512_fmsub_pd(two, u, sv));
+        _mm512_storeu_pd(blk + 2 * (j + half), dv);
       }
     }
   }
@@ -316,17 +351,45 @@ AVX512_FN static void fft_inv_avx512(const oracle_ctx *c, cplx *x) {
       _mm512_storeu_pd(q + 8, _mm512_shuffle_f64x2(sv, d, 0xEE));
     }
   }
-  for (int half = 4; half <= M / 2; half <<= 1) {
+#define W_BFLY_INV(u, v, ww, sv, dv)                                 \
+  do {                                                               \
+    sv = _mm512_fmadd_pd(v, w_re(ww), u);                            \
+    sv = _mm512_fmadd_pd(w_swap(v), w_xor(w_im(ww), W_NEG_ODD), sv); \
+    dv = _mm512_fmsub_pd(two, u, sv);                                \
+  } while (0)
+  int half = 4;
+  for (; 2 * half <= M / 2; half <<= 2) { /* stages (half) and (2 half) in one pass over blocks of 4 half points */
+    const cplx *wa = c->itw + half, *wb = c->itw + 2 * half;
+    for (int b = 0; b < M; b += 4 * half) {
+      double *blk = (double *)(x + b);
+      for (int j = 0; j < half; j += 4) {
+        const __m512d x0 = _mm512_loadu_pd(blk + 2 * j), x1 = _mm512_loadu_pd(blk + 2 * (j + half));
+        const __m512d x2 = _mm512_loadu_pd(blk + 2 * (j + 2 * half)), x3 = _mm512_loadu_pd(blk + 2 * (j + 3 * half));
+        const __m512d wA = _mm512_loadu_pd((const double *)(wa + j));
+        const __m512d wB0 = _mm512_loadu_pd((const double *)(wb + j)), wB1 = _mm512_loadu_pd((const double *)(wb + j + half));
+        __m512d s0, d0, s1, d1, y0, y1, y2, y3;
+        W_BFLY_INV(x0, x1, wA, s0, d0);  /* stage (half): pairs (j, j + half) of both sub-blocks */
+        W_BFLY_INV(x2, x3, wA, s1, d1);
+        W_BFLY_INV(s0, s1, wB0, y0, y2); /* stage (2 half): pairs (j, j + 2 half) and (j + half, j + 3 half) */
+        W_BFLY_INV(d0, d1, wB1, y1, y3);
+        _mm512_storeu_pd(blk + 2 * j, y0);
+        _mm512_storeu_pd(blk + 2 * (j + half), y1);
+        _mm512_storeu_pd(blk + 2 * (j + 2 * half), y2);
+        _mm512_storeu_pd(blk + 2 * (j + 3 * half), y3);
+      }
+    }
+  }
+  for (; half <= M / 2; half <<= 1) {
     const cplx *w = c->itw + half;
     for (int b = 0; b < M; b += 2 * half) {
       double *blk = (double *)(x + b);
       for (int j = 0; j < half; j += 4) {
         const __m512d u = _mm512_loadu_pd(blk + 2 * j), v = _mm512_loadu_pd(blk + 2 * (j + half));
         const __m512d ww = _mm512_loadu_pd((const double *)(w + j));
-        __m512d sv = _mm512_fmadd_pd(v, w_re(ww), u);
-        sv = _mm512_fmadd_pd(w_swap(v), w_xor(w_im(ww), W_NEG_ODD), sv);
+        __m512d sv, dv;
+        W_BFLY_INV(u, v, ww, sv, dv);
         _mm512_storeu_pd(blk + 2 * j, sv);
-        _mm512_storeu_pd(blk + 2 * (j + half), _mm512_fmsub_pd(two, u, sv));
+        _mm512_storeu_pd(blk + 2 * (j + half), dv);
       }
     }
   }
@@ -846,12 +909,10 @@ void oracle_blind_rotate(const oracle_ctx *c, const uint32_t *at, const uint64_t
   for (int i = 0; i < n; i++) {
     const int a = (int)at[i];
     if (a == 0) continue; /* diff == 0: exact no-op */
-    const size_t ggsw_bytes = sizeof(cplx) * (size_t)L * kp1 * kp1 * M;
-    const char *gi = (const char *)(c->bsk_f + (size_t)i * L * kp1 * kp1 * M);
+    /* (software prefetch of the step's key row -- 64 KB for the default set -- was measured and dropped: 21.8 against 17.1 ms per
+     * blind rotate; the hardware streamer does better on its own) */
     for (int cc = 0; cc < kp1; cc++) {
       uint64_t *ac = acc + (size_t)cc * N;
-      /* the key row of this step streams from memory (64 KB for the default set): request it while the transforms run */
-      for (size_t off = ggsw_bytes / kp1 * cc; off < ggsw_bytes / kp1 * (cc + 1); off += 64) __builtin_prefetch(gi + off, 0, 2);
       poly_rotate(N, ac, a, rot);
       for (int j = 0; j < N; j++) rot[j] -= ac[j];
       digits_fwd(c, rot, D + (size_t)cc * L * M, dig);

@@ -198,6 +198,22 @@ if br and br[0] in sq:
         "raw": {k2: v2 for k2, v2 in c.items()},
         "note": "SQ_* ACTIVE / WAIT / WAVE counters are quad-cycles; SQ_INSTS_* are wave-instructions; one workgroup = one PBS = 4 waves x cmux_iterations",
     }
+    if "multibit" not in extra:
+        # Minimum number of f64 FMA / ADD / MUL instructions that produce the canonical arithmetic's bits, counted per
+        # CMUX of the 2_2 set (N = 2048, M = 1024 points, k = 1, one level) and divided by the 256 lanes of a workgroup:
+        #   2 forward transforms   9 stages x 512 butterflies x 6  +  the lane-pair stage 512 x 8                 = 2 x 31 744
+        #   external product       2 outputs x 1024 points x 8                                                    =     16 384
+        #   2 inverse transforms   first stage 512 x 4 adds + 9 x 512 x 6, minus 2 per butterfly whose twiddle is
+        #                          exactly 1 or -i (1022 of them: s costs 2 instead of 4, d = fma(2, u, -s) stays)  = 2 x 27 652
+        #   2 untwists             1024 points x 4 (1 / M and 2^-64 ride in the table), twist[0] = 1 skipped      = 2 x  4 092
+        #   2 x 2048 roundings     6 per coefficient (y - rndne(y) form of 4.4)                                   = 2 x 12 288
+        M_pts = 1024
+        fwd = 9 * (M_pts // 2) * 6 + (M_pts // 2) * 8
+        inv = (M_pts // 2) * 4 + 9 * (M_pts // 2) * 6 - 2 * (M_pts - 2)
+        comp["f64_min_per_wave_iter"] = (2 * fwd + 2 * M_pts * 8 + 2 * inv + 2 * (M_pts * 4 - 4) + 2 * 2 * M_pts * 6) / 256
+        comp["f64_min_note"] = ("minimum f64 FMA / ADD / MUL instructions per lane and CMUX that reproduce DESIGN.md section 4 bit for bit "
+                                "(derivation in scripts/summarize_profile.py); measured f64_per_wave_iter equals it: the arithmetic is at its floor, "
+                                "what is left to remove are the non-f64 VALU slots")
     if comp["valu_per_wave_iter"] and c_f64 and c_other and clock and n_iter:
         other = comp["valu_per_wave_iter"] - comp["f64_per_wave_iter"]
         cyc = comp["f64_per_wave_iter"] * c_f64 + other * c_other
