@@ -115,6 +115,9 @@ SIGNATURES = {
     "fhes_comm_create_rccl": (_P, [_P, C.c_int32, C.c_int32, _P]),
     "fhes_comm_create_host": (_P, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
     "fhes_comm_destroy": (None, [_P]),
+    "fhes_comm_self_test": (C.c_int, [_P]),
+    "fhes_rccl_library_path": (C.c_char_p, []),
+    "fhes_rccl_hip_runtime_path": (C.c_char_p, []),
     "fhes_comm_rank": (C.c_int32, [_P]),
     "fhes_comm_world": (C.c_int32, [_P]),
     "fhes_comm_is_rccl": (C.c_int32, [_P]),

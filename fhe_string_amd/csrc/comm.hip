@@ -4,6 +4,7 @@
 // all-gather of the per-position BooleanBlocks, replicated reduction.  Transports: RCCL on device
 // pointers (resolved with dlopen: no link-time dependency) or caller-supplied host callbacks.
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <rccl/rccl.h>  // types and prototypes only; the functions are looked up at run time
 
 #include <cstring>
@@ -28,17 +29,68 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
+  std::string rccl_path, hip_path;  // the files the bound RCCL and ITS HIP runtime were loaded from
 };
 
+// The file a code address lives in (dladdr), as (device, inode) + path: "which HIP runtime is this?"
+struct LibId {
+  std::string path;
+  dev_t dev = 0;
+  ino_t ino = 0;
+  bool ok = false;
+  bool same(const LibId &o) const { return ok && o.ok && dev == o.dev && ino == o.ino; }
+};
+LibId lib_of(const void *addr) {
+  LibId id;
+  Dl_info info;
+  if (!addr || !dladdr(addr, &info) || !info.dli_fname) return id;
+  id.path = info.dli_fname;
+  struct stat st;
+  if (stat(info.dli_fname, &st) == 0) { id.dev = st.st_dev; id.ino = st.st_ino; id.ok = true; }
+  return id;
+}
+
+// RCCL has to drive the SAME HIP runtime instance this library allocates its arena with.  A process can hold two of them --
+// PyTorch wheels bundle libamdhip64 / librccl, and when this library is loaded BEFORE torch the loader keeps the system
+// runtime for us and adds torch's next to it; `dlopen("librccl.so.1")` then hands back torch's RCCL (same soname), bound to a
+// runtime that has never seen our context: ncclCommInitRank answers "unhandled cuda error / no ROCm-capable device"
+// (gpurun_out/r03_flaky.txt).  So: take a candidate, ask IT for hipGetDeviceCount (dlsym on the handle walks its own
+// dependencies), compare that runtime's file with the one our own calls resolve to, and fall back to the librccl that sits
+// next to OUR runtime (loaded by absolute path: a second copy with its own bindings).
+RcclApi api;   // bound once, by the first caller of rccl()
+
 RcclApi *rccl() {
-  static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (api.lib) break;
+    const LibId ours = lib_of(reinterpret_cast<const void *>(&hipGetDeviceCount));
+    std::vector<std::string> names = {"librccl.so.1", "librccl.so"};
+    if (ours.ok) {
+      const std::string dir = ours.path.substr(0, ours.path.find_last_of('/') + 1);
+      names.push_back(dir + "librccl.so.1");
+      names.push_back(dir + "librccl.so");
     }
-    if (!api.lib) { api.error = std::string("cannot load librccl: ") + dlerror(); return; }
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    std::string seen;
+    for (const std::string &name : names) {
+      void *h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (!h) continue;
+      const LibId theirs = lib_of(dlsym(h, "hipGetDeviceCount"));
+      if (!ours.ok || !theirs.ok || ours.same(theirs)) {   // (a runtime we cannot identify is taken on trust, as before)
+        api.lib = h;
+        api.rccl_path = lib_of(dlsym(h, "ncclCommInitRank")).path;
+        api.hip_path = theirs.path;
+        break;
+      }
+      seen += (seen.empty() ? "" : "; ") + lib_of(dlsym(h, "ncclCommInitRank")).path + " -> " + theirs.path;
+      dlclose(h);
+    }
+    if (!api.lib) {
+      api.error = seen.empty() ? std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found")
+                               : "every librccl in reach is bound to another HIP runtime than this library (" + ours.path +
+                                     "): " + seen + " -- two ROCm runtimes in one process (e.g. PyTorch's bundled one next to /opt/rocm); "
+                                     "load this library after the framework that brings its own runtime, or make one runtime visible";
+      return;
+    }
 #define FHES_SYM(field, sym)                                                        \
   api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, sym));          \
   if (!api.field) { api.error = std::string("librccl lacks ") + sym; return; }
@@ -54,9 +106,15 @@ RcclApi *rccl() {
   return api.error.empty() ? &api : nullptr;
 }
 
+std::string rccl_error() {
+  rccl();
+  return api.error;
+}
+
 int rccl_fail(ncclResult_t r, const char *what) {
   RcclApi *a = rccl();
-  return fail(FHES_ERR_NO_DEVICE, "RCCL error %d (%s) in %s", (int)r, a ? a->GetErrorString(r) : "?", what);
+  return fail(FHES_ERR_NO_DEVICE, "RCCL error %d (%s) in %s [librccl %s on HIP runtime %s]", (int)r, a ? a->GetErrorString(r) : "?", what,
+              a ? a->rccl_path.c_str() : "?", a ? a->hip_path.c_str() : "?");
 }
 
 }  // namespace
@@ -219,7 +277,7 @@ int fhes_comm_unique_id(uint8_t id[FHES_COMM_ID_BYTES]) {
 fhes_comm *fhes_comm_create_rccl(fhes_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[FHES_COMM_ID_BYTES]) {
   if (!ctx || !id || world < 1 || rank < 0 || rank >= world) { fail(FHES_ERR_INVALID, "comm_create_rccl: bad argument"); return nullptr; }
   RcclApi *a = rccl();
-  if (!a) { fail(FHES_ERR_NO_DEVICE, "RCCL unavailable"); return nullptr; }
+  if (!a) { fail(FHES_ERR_STATE, "RCCL unavailable: %s", rccl_error().c_str()); return nullptr; }
   if (hipSetDevice(ctx->device) != hipSuccess) { fail(FHES_ERR_NO_DEVICE, "hipSetDevice failed"); return nullptr; }
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
@@ -228,6 +286,49 @@ fhes_comm *fhes_comm_create_rccl(fhes_ctx *ctx, int32_t rank, int32_t world, con
   ncclResult_t r = a->CommInitRank(&c->nccl, world, u, rank);
   if (r != ncclSuccess) { rccl_fail(r, "ncclCommInitRank"); delete c; return nullptr; }
   return c;
+}
+
+// Which librccl / HIP runtime the RCCL transport is bound to ("" before the first use or when unavailable).
+const char *fhes_rccl_library_path(void) { return rccl() ? api.rccl_path.c_str() : ""; }
+const char *fhes_rccl_hip_runtime_path(void) { return rccl() ? api.hip_path.c_str() : ""; }
+
+// One all-gather, one all-reduce and one broadcast of a few words on memory of THIS library's runtime, through whatever
+// transport the communicator has -- with RCCL also at world == 1, where the data-path functions return early: it is the
+// check that the bound librccl accepts our device pointers (the two-runtimes failure shows here, not at the first wide run).
+int fhes_comm_self_test(fhes_comm *c) {
+  if (!c || !c->ctx) return fail(FHES_ERR_INVALID, "comm_self_test: needs a device communicator");
+  fhes_ctx *ctx = c->ctx;
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(FHES_ERR_NO_DEVICE, "hipSetDevice failed");
+  const int W = c->world, per = 64;
+  std::vector<uint64_t> h((size_t)W * per, 0);
+  for (int q = 0; q < per; q++) h[(size_t)c->rank * per + q] = 0x1000ull * (uint64_t)(c->rank + 1) + (uint64_t)q;
+  uint64_t *d = nullptr;
+  FHES_HIP(hipMalloc(reinterpret_cast<void **>(&d), h.size() * 8));
+  int rc = FHES_OK;
+  auto finish = [&](int code) { (void)hipFree(d); return code; };
+  if (hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return finish(fail(FHES_ERR_NO_DEVICE, "self test: upload failed"));
+  if (c->nccl) {
+    RcclApi *a = rccl();
+    ncclResult_t r = a->AllGather(d + (size_t)c->rank * per, d, per, ncclUint64, c->nccl, ctx->stream);
+    if (r == ncclSuccess) r = a->AllReduce(d, d, per, ncclUint64, ncclSum, c->nccl, ctx->stream);   // first block: sum over ranks of rank 0's words
+    if (r == ncclSuccess) r = a->Broadcast(d + per * (size_t)(W - 1), d + per * (size_t)(W - 1), per, ncclUint64, W - 1, c->nccl, ctx->stream);
+    if (r != ncclSuccess) return finish(rccl_fail(r, "self test collectives"));
+  } else {
+    rc = dev_all_gather(c, d, (size_t)per * 8);
+    if (rc == FHES_OK) rc = dev_all_reduce_sum(c, d, (size_t)per * 8);
+    if (rc == FHES_OK) rc = dev_broadcast(c, d + per * (size_t)(W - 1), (size_t)per * 8, W - 1);
+    if (rc != FHES_OK) return finish(rc);
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return finish(fail(FHES_ERR_NO_DEVICE, "self test: the collectives faulted on the stream"));
+  if (hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return finish(fail(FHES_ERR_NO_DEVICE, "self test: download failed"));
+  for (int r = 0; r < W; r++)
+    for (int q = 0; q < per; q++) {
+      const uint64_t want = r == 0 ? (uint64_t)W * (0x1000ull + (uint64_t)q) : 0x1000ull * (uint64_t)(r + 1) + (uint64_t)q;
+      if (h[(size_t)r * per + q] != want)
+        return finish(fail(FHES_ERR_STATE, "self test: word %d of rank %d's block is %llx, expected %llx", q, r, (unsigned long long)h[(size_t)r * per + q],
+                           (unsigned long long)want));
+    }
+  return finish(FHES_OK);
 }
 
 fhes_comm *fhes_comm_create_host(fhes_ctx *ctx, int32_t rank, int32_t world, fhes_allgather_fn ag, fhes_bcast_fn bc, void *user) {

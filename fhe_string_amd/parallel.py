@@ -48,6 +48,16 @@ class Comm:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         return Comm(check_ptr(_lib.load().fhes_comm_create_rccl(ctx, rank, world, buf)))
 
+    def self_test(self):
+        """one all-gather / all-reduce / broadcast of a few words through this communicator's transport (collective)"""
+        check(_lib.load().fhes_comm_self_test(self._h))
+
+    @staticmethod
+    def rccl_binding():
+        """(librccl file, HIP runtime file it is bound to) of the RCCL transport"""
+        lib = _lib.load()
+        return lib.fhes_rccl_library_path().decode(), lib.fhes_rccl_hip_runtime_path().decode()
+
     @staticmethod
     def rccl_from_torch(ctx, dist):
         """the id travels through torch.distributed (any backend); the data path is this library's own RCCL"""

@@ -348,6 +348,14 @@ typedef int (*fhes_bcast_fn)(void *user, void *buf, int64_t bytes, int32_t root)
 fhes_comm *fhes_comm_create_host(fhes_ctx *ctx, int32_t rank, int32_t world, fhes_allgather_fn all_gather,
                                  fhes_bcast_fn broadcast, void *user);
 void fhes_comm_destroy(fhes_comm *comm);
+/* Diagnostics of the transport.  fhes_comm_self_test runs one all-gather, one all-reduce and one broadcast of a few words
+ * on device memory of THIS library's HIP runtime (collective: every rank calls it) -- with RCCL also at world == 1, where the
+ * data path needs no collective -- and checks the words.  The RCCL binding is resolved against the HIP runtime this library
+ * is bound to (a process may hold a second one, e.g. the runtime a PyTorch wheel bundles): fhes_comm_create_rccl fails with
+ * FHES_ERR_STATE and a message naming both files instead of RCCL's "unhandled cuda error" when no matching librccl exists. */
+int fhes_comm_self_test(fhes_comm *comm);
+const char *fhes_rccl_library_path(void);
+const char *fhes_rccl_hip_runtime_path(void);
 int32_t fhes_comm_rank(const fhes_comm *comm);
 int32_t fhes_comm_world(const fhes_comm *comm);
 /* 1 = RCCL, 0 = host callbacks */
