@@ -94,6 +94,9 @@ SIGNATURES = {
     "fhes_string_encrypt": (_P, [_P, C.c_char_p, C.c_int64, _i32p]),
     "fhes_string_trivial": (_P, [_P, C.c_char_p, _i32p]),
     "fhes_usize_encrypt": (_P, [_P, C.c_uint64]),
+    "fhes_usize_trivial": (_P, [_P, C.c_uint64]),
+    "fhes_radix_encrypt": (_P, [_P, C.c_uint64]),
+    "fhes_radix_decrypt": (C.c_int, [_P, _P, _P]),
     "fhes_ct_destroy": (None, [_P]),
     "fhes_ct_num_blocks": (C.c_int32, [_P]),
     "fhes_string_decrypt": (C.c_int, [_P, _P, _P, C.c_int64]),

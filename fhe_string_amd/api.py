@@ -51,6 +51,16 @@ class ClientKey:
     def num_blocks_usize(self):
         return _L().fhes_client_key_num_blocks_usize(self._h)
 
+    def encrypt(self, message):
+        """client_key.rs:23-28: a RadixCiphertext of num_blocks_char blocks"""
+        return RadixCiphertext(check_ptr(_L().fhes_radix_encrypt(self._h, int(message))))
+
+    def decrypt(self, ct):
+        """client_key.rs:31-33"""
+        out = C.c_uint64()
+        check(_L().fhes_radix_decrypt(self._h, ct._h, C.byref(out)))
+        return out.value
+
     def decrypt_bool(self, b):
         out = C.c_int32()
         check(_L().fhes_bool_decrypt(self._h, b._h, C.byref(out)))
@@ -213,6 +223,10 @@ class BooleanBlock(_Ct):
     pass
 
 
+class RadixCiphertext(_Ct):
+    """tfhe::integer::RadixCiphertext as far as the reference's API shows it (client_key.rs:23-33)"""
+
+
 class FheUsize(_Ct):
     """mod.rs:401-442"""
 
@@ -222,6 +236,11 @@ class FheUsize(_Ct):
 
     def decrypt(self, ck):
         return ck.decrypt_usize(self)
+
+    @staticmethod
+    def new_trivial(k, v):
+        """mod.rs:426-429"""
+        return FheUsize(check_ptr(_L().fhes_usize_trivial(k._h, int(v))))
 
     @staticmethod
     def new_from_bool(k, b):
@@ -236,6 +255,11 @@ class FheUsize(_Ct):
 
 class FheAsciiChar(_Ct):
     """mod.rs:30-38; predicates convert.rs:14-49, trim.rs:15-25"""
+
+    @staticmethod
+    def new(ck, c):
+        """mod.rs:35-37"""
+        return FheAsciiChar(check_ptr(_L().fhes_radix_encrypt(ck._h, int(c) & 0xFF)))
 
     def is_uppercase(self, k):
         return BooleanBlock(_op(k, "is_uppercase", self)[0])

@@ -1243,6 +1243,9 @@ static const OpSig kOps[] = {
     // compare.rs:119 (clear index), FheAsciiChar predicates (convert.rs:14,22; trim.rs:15), FheUsize::new_from_bool
     {"substr_eq", "SIS"}, {"is_uppercase", "C"}, {"is_lowercase", "C"}, {"is_whitespace", "C"},
     {"char_to_lowercase", "C"}, {"char_to_uppercase", "C"}, {"usize_from_bool", "B"},
+    // the crate-public helpers of logic.rs:13-65 and mod.rs:271-287 (L = one BooleanBlock per element, one object)
+    {"any", "L"}, {"all", "L"}, {"element_at_bool", "LU"}, {"if_then_else_zero", "BU"}, {"scalar_if_then_else_zero", "BI"},
+    {"if_then_else_bool", "BBB"},
 };
 
 // "<op>_logdepth" selects the parallel-prefix forms of the serial scans (S::fast)
@@ -1415,7 +1418,7 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
   const std::string sg = sig;
   if (rest && std::count(sg.begin(), sg.end(), 'S') < 2) throw std::invalid_argument("'" + op + ".rest': only operations on (self, pattern) have a find_all to hand in");
   size_t need = 0;
-  for (char c : sg) need += (c == 'S' || c == 'I' || c == 'V');
+  for (char c : sg) need += (c == 'S' || c == 'I' || c == 'V' || c == 'L');
   if (shape.size() != need)
     throw std::invalid_argument("operation '" + op + "' (signature " + sg + ") needs " + std::to_string(need) + " shape entries");
   int32_t n_inputs = 0;
@@ -1426,6 +1429,7 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
       else if (c == 'U') n_inputs += Bu;
       else if (c == 'C') n_inputs += Bc;
       else if (c == 'B') n_inputs += 1;
+      else if (c == 'L') { if (shape[k] < 0) throw std::invalid_argument("negative element count"); n_inputs += shape[k++]; }
       else if (c == 'V') { if (shape[k] < 0) throw std::invalid_argument("negative element count"); n_inputs += shape[k++] * (1 + 2 * Bu); }
       else { if (shape[k] < 0) throw std::invalid_argument("negative integer argument"); k++; }
     }
@@ -1439,6 +1443,7 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
   std::vector<int64_t> ints;
   std::vector<Radix> chars;
   std::vector<Blk> bools;
+  std::vector<Blk> flags;   // 'L': one BooleanBlock per element
   std::vector<S::Slice> vec;
   std::vector<Blk> injected;
   {
@@ -1464,6 +1469,9 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
         chars.push_back(r);
       } else if (c == 'B') {
         bools.push_back(b.input(next++, 1));
+      } else if (c == 'L') {
+        const int n = shape[k++];
+        for (int e = 0; e < n; e++) flags.push_back(b.input(next++, 1));
       } else if (c == 'V') {
         const int n = shape[k++];
         vec.resize(n);
@@ -1555,6 +1563,18 @@ Program compile_op(const fhes_params &p, const std::string &op_full, const std::
     put_radix(s.to_uppercase_char(chars[0]));
   } else if (op == "usize_from_bool") {  // mod.rs:431-433
     put_radix(s.usize_from_bool(bools[0]));
+  } else if (op == "any") {  // logic.rs:41-51
+    put_bool(s.any(flags));
+  } else if (op == "all") {  // logic.rs:54-65
+    put_bool(s.all(flags));
+  } else if (op == "element_at_bool") {  // mod.rs:271-287
+    put_bool(s.element_at_bool(flags, us[0]));
+  } else if (op == "if_then_else_zero") {  // logic.rs:13-16
+    put_radix(s.if_then_else_zero(bools[0], us[0]));
+  } else if (op == "scalar_if_then_else_zero") {  // logic.rs:19-25
+    put_radix(s.scalar_if_then_else_zero(bools[0], (uint64_t)ints[0]));
+  } else if (op == "if_then_else_bool") {  // logic.rs:28-38
+    put_bool(s.if_then_else_bool(bools[0], bools[1], bools[2]));
   } else if (op == "repeat") {  // insert.rs:20
     put_str(s.repeat(strs[0], us[0], (size_t)ints[0], max_len_key));
   } else if (op == "slices_len") put_radix(s.slices_len(vec));

@@ -203,6 +203,42 @@ fhes_ct *fhes_usize_encrypt(fhes_client_key *ck, uint64_t v) {
   return ct;
 }
 
+// ClientKey::encrypt (client_key.rs:23-28: RadixClientKey::encrypt -> num_blocks_char blocks, lib.rs:64) and FheAsciiChar::new
+// (mod.rs:35-37).  The value is reduced modulo M^num_blocks_char like the radix decomposition of tfhe-rs.
+fhes_ct *fhes_radix_encrypt(fhes_client_key *ck, uint64_t v) {
+  if (!ck) { fail(FHES_ERR_INVALID, "null argument"); return nullptr; }
+  fhes_params p;
+  fhes_client_key_params(ck, &p);
+  const int Bc = fhes_client_key_num_blocks_char(ck);
+  const uint64_t M = 1ull << p.message_bits;
+  std::vector<uint8_t> blocks(Bc);
+  for (int k = 0; k < Bc; k++, v /= M) blocks[k] = (uint8_t)(v % M);
+  auto *ct = new fhes_ct;
+  ct->n_blocks = Bc;
+  ct->ct_words = fhes_ct_words(&p);
+  ct->host.assign((size_t)Bc * ct->ct_words, 0);
+  int rc = fhes_client_encrypt_blocks(ck, blocks.data(), Bc, ct->host.data());
+  if (rc) { delete ct; return nullptr; }
+  ct->degree.assign((size_t)Bc, (uint8_t)(M - 1));
+  ct->noise.assign((size_t)Bc, 0);
+  return ct;
+}
+
+// FheUsize::new_trivial (mod.rs:426-429): create_trivial_radix(v, num_blocks_usize); no randomness, no device work
+fhes_ct *fhes_usize_trivial(const fhes_server_key *sk, uint64_t v) {
+  if (!sk) { fail(FHES_ERR_INVALID, "null argument"); return nullptr; }
+  const uint64_t M = (uint64_t)sk->msg_mod;
+  const Dims d(sk->p);
+  auto *ct = new fhes_ct;
+  ct->n_blocks = sk->nb_usize;
+  ct->ct_words = d.ct_words();
+  ct->host.assign((size_t)ct->n_blocks * ct->ct_words, 0);
+  for (int k = 0; k < sk->nb_usize; k++, v /= M) ct->host[(size_t)k * ct->ct_words + d.big] = (v % M) * d.delta;
+  ct->degree.assign((size_t)ct->n_blocks, (uint8_t)(M - 1));
+  ct->noise.assign((size_t)ct->n_blocks, 0);
+  return ct;
+}
+
 void fhes_ct_destroy(fhes_ct *ct) {
   if (!ct) return;
   if (ct->handle >= 0 && ct->ctx) fhes_arena_free(ct->ctx, ct->handle, ct->n_blocks);
@@ -317,6 +353,9 @@ int fhes_usize_decrypt(const fhes_client_key *ck, fhes_ct *v, uint64_t *out) {
   *out = r;
   return FHES_OK;
 }
+
+// ClientKey::decrypt::<T> (client_key.rs:31-33): the radix value of ANY ciphertext object, least significant block first
+int fhes_radix_decrypt(const fhes_client_key *ck, fhes_ct *v, uint64_t *out) { return fhes_usize_decrypt(ck, v, out); }
 
 int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out) {
   if (!ck || !b || !out || b->n_blocks != 1) return fail(FHES_ERR_INVALID, "bad argument");

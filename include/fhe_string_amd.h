@@ -272,12 +272,18 @@ fhes_ct *fhes_string_encrypt(fhes_client_key *ck, const char *s, int64_t pad, in
 fhes_ct *fhes_string_trivial(const fhes_server_key *sk, const char *s, int32_t *status);
 /* FheUsize::new (mod.rs:406) */
 fhes_ct *fhes_usize_encrypt(fhes_client_key *ck, uint64_t v);
+/* FheUsize::new_trivial (mod.rs:426-429) */
+fhes_ct *fhes_usize_trivial(const fhes_server_key *sk, uint64_t v);
+/* ClientKey::encrypt (client_key.rs:23-28) / FheAsciiChar::new (mod.rs:35-37): num_blocks_char blocks */
+fhes_ct *fhes_radix_encrypt(fhes_client_key *ck, uint64_t v);
 void fhes_ct_destroy(fhes_ct *ct);
 int32_t fhes_ct_num_blocks(const fhes_ct *ct);
 /* decrypt: FheString::decrypt (mod.rs:121-129) -> NUL-terminated into buf */
 int fhes_string_decrypt(const fhes_client_key *ck, fhes_ct *s, char *buf, int64_t buf_len);
 int fhes_usize_decrypt(const fhes_client_key *ck, fhes_ct *v, uint64_t *out);
 int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out);
+/* ClientKey::decrypt::<T> (client_key.rs:31-33): radix value of any ciphertext object */
+int fhes_radix_decrypt(const fhes_client_key *ck, fhes_ct *v, uint64_t *out);
 /* raw decoded value (message + carry + padding bit) of every block; values[num_blocks] */
 int fhes_ct_decrypt_blocks(const fhes_client_key *ck, fhes_ct *c, uint8_t *values);
 

