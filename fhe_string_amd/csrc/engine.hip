@@ -477,15 +477,15 @@ static int launch_br_v1(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
-template <int LOGN, int G, bool PIPE, bool LAT = false, int BL = 23>
+template <int LOGN, int G, bool PIPE, bool LAT = false, int BL = 23, bool ILV = false>
 static int launch_br_mb(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
-  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_mb<LOGN, G, PIPE, LAT, 18>(ctx, lane, d);
+  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_mb<LOGN, G, PIPE, LAT, 18, ILV>(ctx, lane, d);
   constexpr int N = 1 << LOGN, M = N / 2;
   const int n_deg = (ctx->dims.n / G) * ((1 << G) - 1);
   constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
   const size_t lds = (size_t)2 * SLOTS * 16 + (size_t)M * 16 + (size_t)(M / 2) * 16 + (size_t)M * 16 + (size_t)((n_deg + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_mb_kernel<LOGN, BL, G, PIPE, LAT>;
-  const unsigned bit = 8 + 4 * (G - 2) + (PIPE ? 1 : 0) + (LAT ? 2 : 0);  // per context: one base per parameter set
+  auto kern = dev::blind_rotate_mb_kernel<LOGN, BL, G, PIPE, LAT, ILV>;
+  const unsigned bit = 8 + 4 * (G - 2) + (PIPE ? 1 : 0) + (LAT ? 2 : 0);  // per context: one base per parameter set (and one key layout)
   if (!(ctx->attr_done & (1u << bit))) {
     FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -566,7 +566,44 @@ static int launch_br_gen_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
+// N = 8192 (glwe_dim 1): one thread group per ciphertext, products accumulated in registers (blind_rotate_big_kernel);
+// FHES_GEN_BIG=0 keeps the generic kernel (the tests compare the two)
+template <int LOGN, int LV>
+static int launch_br_big_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  constexpr int N = 1 << LOGN, M = N / 2;
+  const Dims &dm = ctx->dims;
+  const size_t per = (size_t)2 * N * 8, need = per * (size_t)d.v_count;
+  if (lane.gen_scratch_bytes < need) {
+    lane.drop(lane.gen_scratch);
+    lane.gen_scratch = nullptr;
+    lane.gen_scratch_bytes = 0;
+    FHES_HIP(hipMalloc(&lane.gen_scratch, need));
+    lane.gen_scratch_bytes = need;
+  }
+  const size_t lds = (size_t)2 * M * 16 + (size_t)((dm.n + 1 + 3) & ~3) * 4;
+  auto kern = dev::blind_rotate_big_kernel<LOGN, LV>;
+  const unsigned bit = 1u << (LOGN == 12 ? 30 : 31);   // one parameter set per context: one level count
+  if (!(ctx->attr_done & bit)) {
+    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ctx->attr_done |= bit;
+  }
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 8), lds, lane.stream, d, ctx->arena, ctx->ct_stride, lane.ks_out, ctx->ks_stride,
+                     dm.n, dm.pbs_base_log, ctx->bsk_f, ctx->lut_polys, ctx->twist, ctx->tw, ctx->psi, lane.gen_scratch, per);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+static bool use_big_kernel(const Dims &dm) {
+  static const bool off = getenv("FHES_GEN_BIG") && atoi(getenv("FHES_GEN_BIG")) == 0;
+  return !off && dm.k == 1 && dm.N == 8192;
+}
 static int launch_br_gen(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  if (use_big_kernel(ctx->dims)) {
+    switch (ctx->dims.L) {
+      case 1: return launch_br_big_n<13, 1>(ctx, lane, d);
+      case 2: return launch_br_big_n<13, 2>(ctx, lane, d);
+      default: return launch_br_big_n<13, 3>(ctx, lane, d);
+    }
+  }
   switch (ctx->dims.N) {
     case 256: return launch_br_gen_n<8>(ctx, lane, d);
     case 512: return launch_br_gen_n<9>(ctx, lane, d);
@@ -588,8 +625,10 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
     // workgroup per CU: everything in registers, bundle pipeline), throughput with the pipeline
     // (g = 3) and without (g = 2).  br_variant 2 forces the latency build, 3 the throughput build.
     const bool lat = ctx->br_variant == 2 || (ctx->br_variant == 0 && d.v_count <= ctx->n_cus);
-    if (ctx->dims.g == 3)  // measured: the latency build gains nothing for g = 3 (3.21 vs 3.16 ms)
+    if (ctx->dims.g == 3) {  // measured: the latency build gains nothing for g = 3 (3.21 vs 3.16 ms)
+      if (ctx->mb_ilv) return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true, false, 23, true>(ctx, lane, d) : launch_br_mb<8, 3, true, false, 23, true>(ctx, lane, d);
       return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true>(ctx, lane, d) : launch_br_mb<8, 3, true>(ctx, lane, d);
+    }
     if (ctx->dims.N == 2048) return lat ? launch_br_mb<11, 2, true, true>(ctx, lane, d) : launch_br_mb<11, 2, false>(ctx, lane, d);
     return lat ? launch_br_mb<8, 2, true, true>(ctx, lane, d) : launch_br_mb<8, 2, false>(ctx, lane, d);
   }
@@ -917,10 +956,12 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
     FHES_HIP(hipGetLastError());
     if (fast_shape(ctx->p)) {  // the register-order layout of the throughput kernels
       if (!ctx->bsk_e) FHES_HIP(hipMalloc(&ctx->bsk_e, npoly * d.M * 16));
+      ctx->mb_ilv = (d.g == 3 && getenv("FHES_MB_INTERLEAVE") && atoi(getenv("FHES_MB_INTERLEAVE")) != 0) ? 1 : 0;
+      const int nc_ilv = ctx->mb_ilv ? (1 << d.g) : 0;
       if (d.N == 2048)
-        hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<11>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e);
+        hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<11>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e, nc_ilv);
       else
-        hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<8>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e);
+        hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<8>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e, nc_ilv);
       FHES_HIP(hipGetLastError());
     }
     FHES_HIP(hipStreamSynchronize(ctx->stream));

@@ -174,12 +174,25 @@ struct FftPlan {
 
 // forward: x holds the points of pass (LO = HI-NB); ends with the spectrum in `buf`
 // (canonical bit-reversed order, position == in-place index) and a barrier.
+// The twiddles of a pass depend on the thread only: left alone, the compiler hoists the loads of EVERY pass of both
+// transforms out of the blind-rotate loop and keeps them live across it (28 registers per pass: the source of the generic
+// kernel's spills at N >= 2048).  `tw_here` makes the table pointer opaque per pass, so a pass's twiddles are fetched where
+// the pass runs.  (Shapes below N = 2048 have the registers to keep them and run 5-10 % faster hoisted: fft_forward / fft_inverse
+// apply it from LOGM = 10 on.)
+// (An opaque OFFSET, not an opaque pointer: a pointer that went through the asm statement loses its address space and every
+// load from it becomes a flat_load, which also counts against the LDS wait counter.)
+__device__ __forceinline__ const double2 *tw_here(const double2 *tw) {
+  int z = 0;
+  asm volatile("" : "+s"(z));
+  return tw + z;
+}
+
 template <int LOGM, int HI>
 __device__ __forceinline__ void fft_forward(double2 (&x)[8], int q, double2 *buf,
                                             const double2 *__restrict__ tw) {
   constexpr int NB = HI >= 3 ? 3 : HI;
   constexpr int LO = HI - NB;
-  fft_butterflies<LOGM, true, LO, NB>(x, q, tw);
+  fft_butterflies<LOGM, true, LO, NB>(x, q, LOGM >= 10 ? tw_here(tw) : tw);
 #pragma unroll
   for (int e = 0; e < 8; ++e) buf[fft_point<LOGM, LO, NB>(q, e)] = x[e];
   __syncthreads();
@@ -197,7 +210,7 @@ __device__ __forceinline__ void fft_forward(double2 (&x)[8], int q, double2 *buf
 template <int LOGM, int LO, int NB>
 __device__ __forceinline__ void fft_inverse(double2 (&x)[8], int q, double2 *buf,
                                             const double2 *__restrict__ tw) {
-  fft_butterflies<LOGM, false, LO, NB>(x, q, tw);
+  fft_butterflies<LOGM, false, LO, NB>(x, q, LOGM >= 10 ? tw_here(tw) : tw);
   if constexpr (LO + NB < LOGM) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) buf[fft_point<LOGM, LO, NB>(q, e)] = x[e];
@@ -920,6 +933,215 @@ __device__ __forceinline__ void load_pass_twiddles_tab(double2 (&w)[7], int q, c
 }
 
 // ------------------------------------------------------------------------------------------
+// K2+K3 (N = 8192, round 4): blind rotate + sample extract for the classic shapes with N = 8192
+// (glwe_dim 1, L <= 3; e.g. the 3_3-shaped set: two levels of base 2^15).  The generic kernel above gives
+// every polynomial its own thread group -- 1024 threads at N = 8192, 128 registers each, 250 of them spilled -- and keeps
+// the (k + 1) * L digit spectra in a global scratch (384 KB per ciphertext).  Here ONE group of N / 16 threads (512 at
+// N = 8192: 256 registers, nothing spilled) walks the polynomials one after the other, and the spectra never leave the
+// chip: the products are accumulated in registers as each digit transform completes,
+//     for (row, level) in the oracle's order:  D = FFT(digit_level(X^a acc_row - acc_row));  O_col += D * G[level][row][col]
+// (the FMA chain of DESIGN.md 4.7 term by term: same operands, same order, same bits), then one inverse transform per
+// column.  Digits of level l are recomputed from the rotated difference for every level (a carry chain of at most L - 1
+// steps) instead of being carried across the transforms.
+//   LDS: buf double2[M] | obuf double2[M] (2 x 64 KB at N = 8192) | at u32[n + 1];   scratch per workgroup: acc u64[2][N]
+// ------------------------------------------------------------------------------------------
+// one 3-bit register pass with its 7 twiddles in registers (index bits [LO, LO + 3); the stage of index bit 0 has its own
+// forms: fwd_butterfly_last / the exact u +- v of the inverse transform) -- fft_butterflies with the loads taken out
+template <bool FWD, int LO>
+__device__ __forceinline__ void fft_pass_w(double2 (&x)[8], const double2 (&w)[7]) {
+#pragma unroll
+  for (int st = 0; st < 3; ++st) {
+    const int fb = FWD ? (2 - st) : st;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e & (1 << fb)) continue;
+      const int e1 = e | (1 << fb);
+      if (FWD) {
+        const double2 t = fb == 2 ? w[0] : (fb == 1 ? w[1 + (e >> 2)] : w[3 + (e >> 1)]);
+        if (LO + fb == 0) fwd_butterfly_last(x[e], x[e1], t);
+        else fwd_butterfly(x[e], x[e1], t);
+      } else if (LO + fb == 0) {  // twiddle exactly 1
+        const double2 u = x[e], v = x[e1];
+        x[e] = make_double2(u.x + v.x, u.y + v.y);
+        x[e1] = make_double2(u.x - v.x, u.y - v.y);
+      } else {
+        inv_butterfly(x[e], x[e1], fb == 2 ? w[e & 3] : (fb == 1 ? w[4 + (e & 1)] : w[6]));
+      }
+    }
+  }
+}
+
+template <int LOGN, int L>
+__global__ __launch_bounds__((1 << LOGN) / 16) void blind_rotate_big_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride,
+    int n_small, int BL, const double2 *__restrict__ bsk_f, const uint64_t *__restrict__ lut_polys,
+    const double2 *__restrict__ twist, const double2 *__restrict__ tw, const double2 *__restrict__ psi,
+    unsigned char *__restrict__ scratch, size_t scratch_per_wg) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
+  static_assert(LOGM == 12, "written for four passes of three index bits: N = 8192 (N = 4096 has LOGM = 11 and stays on the generic kernel)");
+  constexpr int KP1 = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double2 *buf = reinterpret_cast<double2 *>(smem_raw);                          // [M]   exchange buffer of the transforms
+  double2 *obuf = buf + M;                                                       // [M]   column 1 of the products while column 0 is transformed
+  uint32_t *at = reinterpret_cast<uint32_t *>(smem_raw + (size_t)2 * M * 16);    // [n + 1]
+  uint64_t *acc = reinterpret_cast<uint64_t *>(scratch + (size_t)blockIdx.x * scratch_per_wg);  // [2][N]
+
+  const int q = threadIdx.x;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  for (int j = q; j <= n_small; j += TP)
+    at[j] = (uint32_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  __syncthreads();
+  {  // acc = (0, X^{-b~} * LUT)
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
+    for (int j = q; j < KP1 * N; j += TP) {
+      const int pr = j / N, jj = j % N;
+      acc[j] = pr < KP1 - 1 ? 0 : ((t == 0) ? lut[jj] : rot_read<N>(lut, t, jj));
+    }
+  }
+  __syncthreads();
+
+  const double scale = 1.0 / (double)M;
+  const int total = BL * L;
+  const uint64_t Bm1 = ((uint64_t)1 << BL) - 1, half = (uint64_t)1 << (BL - 1), tmask = ((uint64_t)1 << total) - 1;
+  // balanced digit of level `lt` (level L - 1 = least significant) of the rounded prefix v
+  auto digit = [&](uint64_t v, int lt) __attribute__((always_inline)) {
+    int64_t g = 0;
+#pragma unroll
+    for (int l = L - 1; l >= 0; --l) {
+      if (l < lt) break;
+      g = (int64_t)(v & Bm1);
+      v >>= BL;
+      if ((uint64_t)g >= half) { g -= (int64_t)1 << BL; v += 1; }
+    }
+    return (double)g;
+  };
+  // exchange between two passes through buf: layout (LO_FROM, 3) -> layout (LO_TO, 3)
+#define FHES_XCHG(LO_FROM, LO_TO)                                                              \
+  do {                                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) buf[fft_point<LOGM, LO_FROM, 3>(q, e)] = x[e]; \
+    __syncthreads();                                                                           \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) x[e] = buf[fft_point<LOGM, LO_TO, 3>(q, e)];   \
+  } while (0)
+
+  for (int i = 0; i < n_small; ++i) {
+    const int a = (int)at[i];
+    if (a == 0) continue;  // X^0 * acc - acc == 0: exact no-op (uniform branch)
+    const double2 *G = tw_here(bsk_f + (size_t)i * L * KP1 * KP1 * M);  // [L][row][col][M]
+    // the products of column 0 accumulate in registers, those of column 1 in LDS (thread-private slots q + e * TP: no conflicts,
+    // no barrier) -- both columns in registers next to the prefetched key rows spilled 128 registers
+    double2 O0[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      O0[e] = make_double2(-0.0, -0.0);
+      obuf[q + e * TP] = make_double2(-0.0, -0.0);
+    }
+#pragma unroll 1
+    for (int row = 0; row < KP1; ++row) {
+      const uint64_t *acc_r = acc + (size_t)row * N;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        double2 x[8], w[7];
+        load_fwd_twiddles<LOGM, LOGM - 3, false>(w, q, tw_here(psi));  // in flight while the digits are formed
+        // the rotated difference is re-read for every level (L2-resident scratch) instead of being carried in registers
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);
+          const uint64_t d0 = rot_read<N>(acc_r, a, p) - acc_r[p];
+          const uint64_t d1 = rot_read<N>(acc_r, a, p + M) - acc_r[p + M];
+          x[e] = make_double2(digit((((d0 >> (64 - total - 1)) + 1) >> 1) & tmask, l), digit((((d1 >> (64 - total - 1)) + 1) >> 1) & tmask, l));
+        }
+        // forward transform: every pass's twiddles are requested one pass ahead (behind the butterflies, in front of the
+        // exchange and its barrier), the key rows of this term before the last pass
+        fft_pass_w<true, LOGM - 3>(x, w);
+        load_fwd_twiddles<LOGM, LOGM - 6, false>(w, q, tw_here(psi));
+        FHES_XCHG(LOGM - 3, LOGM - 6);
+        fft_pass_w<true, LOGM - 6>(x, w);
+        load_fwd_twiddles<LOGM, LOGM - 9, false>(w, q, tw_here(psi));
+        FHES_XCHG(LOGM - 6, LOGM - 9);
+        fft_pass_w<true, LOGM - 9>(x, w);
+        const double2 *G0 = G + (((size_t)l * KP1 + row) * KP1 + 0) * M, *G1 = G0 + M;
+        double2 g0[8], g1[8];
+        load_fwd_twiddles<LOGM, 0, false>(w, q, tw_here(psi));
+        FHES_XCHG(LOGM - 9, 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g0[e] = G0[fft_point<LOGM, 0, 3>(q, e)]; g1[e] = G1[fft_point<LOGM, 0, 3>(q, e)]; }
+        fft_pass_w<true, 0>(x, w);
+        // the spectrum is in the registers in the layout the products want (pass (0, 3)): no trip through buf.
+        // The chain's first term is a plain product in the oracle; fma(a, b, -0.0) IS that product, bit for bit (a * b + (-0) keeps
+        // the product's value and the sign of a zero), so the accumulators start at -0.0 and the loop body has one form
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const double2 dd = x[e];
+          double2 o1 = obuf[q + e * TP];
+          O0[e] = make_double2(__builtin_fma(dd.x, g0[e].x, O0[e].x), __builtin_fma(dd.x, g0[e].y, O0[e].y));
+          o1 = make_double2(__builtin_fma(dd.x, g1[e].x, o1.x), __builtin_fma(dd.x, g1[e].y, o1.y));
+          O0[e] = make_double2(__builtin_fma(-dd.y, g0[e].y, O0[e].x), __builtin_fma(dd.y, g0[e].x, O0[e].y));
+          o1 = make_double2(__builtin_fma(-dd.y, g1[e].y, o1.x), __builtin_fma(dd.y, g1[e].x, o1.y));
+          obuf[q + e * TP] = o1;
+        }
+        __syncthreads();  // every thread has taken its points out of buf before the next transform writes there
+      }
+    }
+    // every rotated difference of this iteration has been taken: the accumulator may change now
+#pragma unroll 1
+    for (int col = 0; col < KP1; ++col) {
+      double2 x[8], w[7];
+      load_pass_twiddles<LOGM, 3>(w, q, tw_here(tw));  // second inverse pass (the first one owns bit 0: its twiddles are 1 and the stage-1 / stage-2 ones)
+      double2 w0[7];
+      load_pass_twiddles<LOGM, 0>(w0, q, tw_here(tw));
+      if (col == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = O0[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = obuf[q + e * TP];
+      }
+      fft_pass_w<false, 0>(x, w0);
+      FHES_XCHG(0, 3);
+      fft_pass_w<false, 3>(x, w);
+      load_pass_twiddles<LOGM, 6>(w, q, tw_here(tw));
+      FHES_XCHG(3, 6);
+      fft_pass_w<false, 6>(x, w);
+      int zc = 0;
+      asm volatile("" : "+s"(zc));  // the accumulator words are fetched behind this point (see tw_here)
+      uint64_t *acc_c = acc + (size_t)col * N + zc;
+      const double2 *twist_l = tw_here(twist);
+      double2 tws[8];
+      uint64_t alo[8], ahi[8];
+      load_pass_twiddles<LOGM, 9>(w, q, tw_here(tw));
+      // untwist factors and the accumulator words of the update: requested in front of the last exchange
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);
+        tws[e] = twist_l[p];
+        alo[e] = acc_c[p];
+        ahi[e] = acc_c[p + M];
+      }
+      FHES_XCHG(6, 9);
+      fft_pass_w<false, 9>(x, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);
+        const double2 v = cmul_conj(x[e], tws[e]);
+        acc_c[p] = alo[e] + torus_from_f64(v.x * scale);
+        acc_c[p + M] = ahi[e] + torus_from_f64(v.y * scale);
+      }
+      __syncthreads();  // buf is re-used by the next column; the accumulator is settled before the next rotation reads it
+    }
+  }
+#undef FHES_XCHG
+
+  // ---- sample extract: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+  for (int j = q; j < N; j += TP) out[j] = (j == 0) ? acc[0] : (uint64_t)0 - acc[N - j];
+  if (q == 0) out[N] = acc[N];
+}
+
+// ------------------------------------------------------------------------------------------
 // K2+K3 (variant 5): the throughput blind rotate (every launch size).  256 threads = two halves (output
 // polynomial r) x 128 threads x 8 points, two workgroups per CU (<= 256 registers, exactly 80 KB LDS each).
 // Structure of an iteration (4 workgroup barriers):
@@ -1357,13 +1579,15 @@ __device__ __forceinline__ void load_inv_twiddles_tab_all(double2 (&w)[7], int q
 
 // LAT = true: the latency build -- one workgroup per CU (512 registers per lane), pass twiddles and
 // twist factors in registers (as variant 2), always with the bundle pipeline.
-template <int LOGN, int BL, int G, bool PIPE, bool LAT>
+// ILV (round-4 layout A/B, g = 3 throughput build only): the 2^G GGSWs of a group interleaved row by row in the key
+template <int LOGN, int BL, int G, bool PIPE, bool LAT, bool ILV = false>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LAT ? 1 : 2) void blind_rotate_mb_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
     int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
     const double2 *__restrict__ twist_inv /* twist / M */, const double2 *__restrict__ tw,
     const double2 *__restrict__ root /* [2N] */, const double2 *__restrict__ psi /* forward twiddles [M] */,
     const double2 *__restrict__ cdpp /* [8][M/8] */) {
+  constexpr bool ilv = ILV;
   constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
   constexpr int NP = (LOGM - 1) / 3, NC = 1 << G;
   static_assert(LOGM % 3 == 1 && (NP == 2 || NP == 3), "supported: N = 256, N = 2048");
@@ -1422,7 +1646,11 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
   }
   const __amdgpu_buffer_rsrc_t rs_g =
       __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_groups * NC * 4 * M * 16), 0x00020000);
-  const unsigned voff_g = (unsigned)(r * 8 * TP + q) * 16u;  // G[((row*2 + r)*8 + e)*TP + q]
+  // G[((row*2 + r)*8 + e)*TP + q] inside GGSW c of a group; interleaved: rows of 2 KB ordered (row, r, e, c)
+  const unsigned voff_g = ilv ? (unsigned)(r * 8 * NC * TP + q) * 16u : (unsigned)(r * 8 * TP + q) * 16u;
+  auto goff = [&](unsigned so, int c, int row, int e) __attribute__((always_inline)) {
+    return ilv ? so + (unsigned)(((row * 16 + e) * NC + c) * TP * 16) : so + (unsigned)c * (unsigned)(4 * M * 16) + (unsigned)((row * 16 + e) * TP * 16);
+  };
   // E(p) of the slots this thread holds when the external product runs: p = point_C(q, e) has e in
   // bits [LO_C, LO_C+3), so bitrev(p) = bitrev(point_C(q, 0)) + (bitrev3(e) << (LOGM - 3 - LO_C)) and
   // E(p) * d = E(point_C(q, 0)) * d - bitrev3(e) * (d << (LOGM - 1 - LO_C))   (mod 2N)
@@ -1479,18 +1707,17 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
     for (int ee = 0; ee < EB; ++ee) {
       const int e = eb + ee;
       if (cb == 1) {
-        b0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
-        b1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
+        b0[e] = buf_load_d2(rs_g, voff_g, goff(so, 0, 0, e));
+        b1[e] = buf_load_d2(rs_g, voff_g, goff(so, 0, 1, e));
       }
 #pragma unroll
       for (int cc = 0; cc < CB; ++cc) {
         const int c = cb + cc;
         if (c >= NC) continue;
-        const unsigned soc = so + (unsigned)c * (unsigned)(4 * M * 16);
         const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);  // constant after unrolling
         tww[ee][cc] = root[(sexp0 * deg[c] - br3 * (deg[c] << (LOGM - 1 - LO_C))) & (2 * N - 1)];
-        tg0[ee][cc] = buf_load_d2(rs_g, voff_g, soc + (unsigned)((0 * 16 + e) * TP * 16));
-        tg1[ee][cc] = buf_load_d2(rs_g, voff_g, soc + (unsigned)((1 * 16 + e) * TP * 16));
+        tg0[ee][cc] = buf_load_d2(rs_g, voff_g, goff(so, c, 0, e));
+        tg1[ee][cc] = buf_load_d2(rs_g, voff_g, goff(so, c, 1, e));
       }
     }
   };
@@ -1532,15 +1759,14 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
       for (int eb = 0; eb < 8; eb += 2) {
 #pragma unroll
         for (int e = eb; e < eb + 2; ++e) {
-          b0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16));
-          b1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16));
+          b0[e] = buf_load_d2(rs_g, voff_g, goff(so, 0, 0, e));
+          b1[e] = buf_load_d2(rs_g, voff_g, goff(so, 0, 1, e));
 #pragma unroll
           for (int c = 1; c < NC; ++c) {
-            const unsigned soc = so + (unsigned)c * (unsigned)(4 * M * 16);
-            const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);  // constant after unrolling
+                const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);  // constant after unrolling
             const double2 w = root[(sexp0 * deg[c] - br3 * (deg[c] << (LOGM - 1 - LO_C))) & (2 * N - 1)];
-            const double2 g0 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((0 * 16 + e) * TP * 16));
-            const double2 g1 = buf_load_d2(rs_g, voff_g, soc + (unsigned)((1 * 16 + e) * TP * 16));
+            const double2 g0 = buf_load_d2(rs_g, voff_g, goff(so, c, 0, e));
+            const double2 g1 = buf_load_d2(rs_g, voff_g, goff(so, c, 1, e));
             b0[e] = cfma(g0, w, b0[e]);
             b1[e] = cfma(g1, w, b1[e]);
           }
@@ -1686,12 +1912,19 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
 // p = fft_point<LOGM, LO_last3, 3>(q, e) of the last 3-bit pass (the layout the spectrum
 // is in when the external product runs).  grid = polynomials, block = M/8.
 template <int LOGN>
-__global__ void bsk_to_engine_layout_kernel(const double2 *__restrict__ canon, double2 *__restrict__ out) {
+__global__ void bsk_to_engine_layout_kernel(const double2 *__restrict__ canon, double2 *__restrict__ out, int nc_ilv = 0) {
   constexpr int M = (1 << LOGN) / 2, LOGM = LOGN - 1, TP = M / 8;
   constexpr int NP = (LOGM - 1) / 3;
   constexpr int LO_C = LOGM - 3 * NP;
   const int q = threadIdx.x;
   const double2 *src = canon + (size_t)blockIdx.x * M;
+  if (nc_ilv > 1) {  // multi-bit, interleaved: polynomial ((group * NC + c) * 4 + rc) -> rows (rc, e, c) of the group's block
+    const int rc = blockIdx.x & 3, c = (blockIdx.x >> 2) % nc_ilv, grp = (blockIdx.x >> 2) / nc_ilv;
+    double2 *base = out + (size_t)grp * nc_ilv * 4 * M;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) base[((size_t)(rc * 8 + e) * nc_ilv + c) * TP + q] = src[fft_point<LOGM, LO_C, 3>(q, e)];
+    return;
+  }
   double2 *dst = out + (size_t)blockIdx.x * M;
 #pragma unroll
   for (int e = 0; e < 8; ++e) dst[(size_t)e * TP + q] = src[fft_point<LOGM, LO_C, 3>(q, e)];
