@@ -564,3 +564,39 @@ class StringEncryption:
     @staticmethod
     def encrypt(s, k, l=None):
         return FheString.new(k, s, l)
+
+
+# ---- the crate-public helpers of logic.rs / mod.rs (one small circuit each; bindings/rust/src/ciphertext/logic.rs) ----
+def _concat(k, blocks):
+    arr = (C.c_void_p * max(len(blocks), 1))(*[b._h for b in blocks])
+    return _Ct(check_ptr(_L().fhes_ct_concat(k._h, arr, len(blocks))))
+
+
+def any_of(k, v):
+    """logic.rs:41-51 `any`"""
+    return BooleanBlock(_op(k, "any", _concat(k, v))[0])
+
+
+def all_of(k, v):
+    """logic.rs:54-65 `all`"""
+    return BooleanBlock(_op(k, "all", _concat(k, v))[0])
+
+
+def element_at_bool(k, v, i):
+    """mod.rs:271-287"""
+    return BooleanBlock(_op(k, "element_at_bool", _concat(k, v), i)[0])
+
+
+def if_then_else_zero(k, a, b):
+    """logic.rs:13-16 (FheUsize-sized operand)"""
+    return FheUsize(_op(k, "if_then_else_zero", a, b)[0])
+
+
+def scalar_if_then_else_zero(k, a, c):
+    """logic.rs:19-25"""
+    return FheUsize(_op(k, "scalar_if_then_else_zero", a, ints=(int(c),))[0])
+
+
+def if_then_else_bool(k, a, b, c):
+    """logic.rs:28-38"""
+    return BooleanBlock(_op(k, "if_then_else_bool", a, b, c)[0])

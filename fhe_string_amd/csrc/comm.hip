@@ -445,6 +445,20 @@ int fhes_comm_broadcast_keys(fhes_comm *c, int32_t root) {
   if (rc == FHES_OK) rc = dev_broadcast(c, ctx->ksk_bias, bias_b, root);
   if (rc == FHES_OK) rc = dev_broadcast(c, ctx->bsk_f, bsk_b, root);
   if (rc == FHES_OK && has_e) rc = dev_broadcast(c, ctx->bsk_e, bsk_b, root);
+  if (rc == FHES_OK && d.g > 1) {  // the layout of a multi-bit key (engine.h: mb_ilv) belongs to the key: it travels with it
+    uint64_t *flag = nullptr;
+    FHES_HIP(hipMalloc(reinterpret_cast<void **>(&flag), 8));
+    uint64_t v = (uint64_t)ctx->mb_ilv;
+    hipError_t he = hipMemcpy(flag, &v, 8, hipMemcpyHostToDevice);
+    if (he == hipSuccess) {
+      rc = dev_broadcast(c, flag, 8, root);
+      if (rc == FHES_OK) he = hipStreamSynchronize(ctx->stream);
+      if (rc == FHES_OK && he == hipSuccess) he = hipMemcpy(&v, flag, 8, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(flag);
+    if (he != hipSuccess) return fail(FHES_ERR_NO_DEVICE, "broadcast_keys: %s", hipGetErrorString(he));
+    if (rc == FHES_OK) ctx->mb_ilv = (int)v;
+  }
   if (rc == FHES_OK) { FHES_HIP(hipStreamSynchronize(ctx->stream)); ctx->keys_loaded = true; }
   return rc;
 }

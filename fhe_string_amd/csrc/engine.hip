@@ -580,7 +580,7 @@ static int launch_br_big_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
     FHES_HIP(hipMalloc(&lane.gen_scratch, need));
     lane.gen_scratch_bytes = need;
   }
-  const size_t lds = (size_t)2 * M * 16 + (size_t)((dm.n + 1 + 3) & ~3) * 4;
+  const size_t lds = (size_t)2 * M * 16 + (size_t)2 * 512 * 16 + (size_t)((dm.n + 1 + 3) & ~3) * 4;
   auto kern = dev::blind_rotate_big_kernel<LOGN, LV>;
   const unsigned bit = 1u << (LOGN == 12 ? 30 : 31);   // one parameter set per context: one level count
   if (!(ctx->attr_done & bit)) {
@@ -628,6 +628,10 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
     if (ctx->dims.g == 3) {  // measured: the latency build gains nothing for g = 3 (3.21 vs 3.16 ms)
       if (ctx->mb_ilv) return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true, false, 23, true>(ctx, lane, d) : launch_br_mb<8, 3, true, false, 23, true>(ctx, lane, d);
       return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true>(ctx, lane, d) : launch_br_mb<8, 3, true>(ctx, lane, d);
+    }
+    if (ctx->mb_ilv) {
+      if (ctx->dims.N == 2048) return lat ? launch_br_mb<11, 2, true, true, 23, true>(ctx, lane, d) : launch_br_mb<11, 2, false, false, 23, true>(ctx, lane, d);
+      return lat ? launch_br_mb<8, 2, true, true, 23, true>(ctx, lane, d) : launch_br_mb<8, 2, false, false, 23, true>(ctx, lane, d);
     }
     if (ctx->dims.N == 2048) return lat ? launch_br_mb<11, 2, true, true>(ctx, lane, d) : launch_br_mb<11, 2, false>(ctx, lane, d);
     return lat ? launch_br_mb<8, 2, true, true>(ctx, lane, d) : launch_br_mb<8, 2, false>(ctx, lane, d);
@@ -956,7 +960,12 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
     FHES_HIP(hipGetLastError());
     if (fast_shape(ctx->p)) {  // the register-order layout of the throughput kernels
       if (!ctx->bsk_e) FHES_HIP(hipMalloc(&ctx->bsk_e, npoly * d.M * 16));
-      ctx->mb_ilv = (d.g == 3 && getenv("FHES_MB_INTERLEAVE") && atoi(getenv("FHES_MB_INTERLEAVE")) != 0) ? 1 : 0;
+      // multi-bit keys: the 2^g GGSWs of a group interleaved row by row (round 4: g = 3 runs 7-10 % faster from it in alternating
+      // same-run launches, profiles/r04_ab_multibit_layout.txt).  Default: on for g = 3; FHES_MB_INTERLEAVE=0 / 1 forces it.
+      {
+        const char *e = getenv("FHES_MB_INTERLEAVE");
+        ctx->mb_ilv = d.g > 1 ? (e ? (atoi(e) != 0) : (d.g == 3)) : 0;
+      }
       const int nc_ilv = ctx->mb_ilv ? (1 << d.g) : 0;
       if (d.N == 2048)
         hipLaunchKernelGGL((dev::bsk_to_engine_layout_kernel<11>), dim3(npoly), dim3(d.M / 8), 0, ctx->stream, ctx->bsk_f, ctx->bsk_e, nc_ilv);

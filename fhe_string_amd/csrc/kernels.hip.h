@@ -943,7 +943,7 @@ __device__ __forceinline__ void load_pass_twiddles_tab(double2 (&w)[7], int q, c
 // (the FMA chain of DESIGN.md 4.7 term by term: same operands, same order, same bits), then one inverse transform per
 // column.  Digits of level l are recomputed from the rotated difference for every level (a carry chain of at most L - 1
 // steps) instead of being carried across the transforms.
-//   LDS: buf double2[M] | obuf double2[M] (2 x 64 KB at N = 8192) | at u32[n + 1];   scratch per workgroup: acc u64[2][N]
+//   LDS: buf double2[M] | obuf double2[M] (2 x 64 KB) | TF, TI double2[512] each | at u32[n + 1];   scratch per workgroup: acc u64[2][N]
 // ------------------------------------------------------------------------------------------
 // one 3-bit register pass with its 7 twiddles in registers (index bits [LO, LO + 3); the stage of index bit 0 has its own
 // forms: fwd_butterfly_last / the exact u +- v of the inverse transform) -- fft_butterflies with the loads taken out
@@ -982,8 +982,10 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void blind_rotate_big_kernel(
   constexpr int KP1 = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double2 *buf = reinterpret_cast<double2 *>(smem_raw);                          // [M]   exchange buffer of the transforms
-  double2 *obuf = buf + M;                                                       // [M]   column 1 of the products while column 0 is transformed
-  uint32_t *at = reinterpret_cast<uint32_t *>(smem_raw + (size_t)2 * M * 16);    // [n + 1]
+  double2 *obuf = buf + M;                                                       // [M]   products of column 1
+  double2 *TF = obuf + M;                                                        // [512] forward twiddles psi[0, 512): passes A, B, C
+  double2 *TI = TF + 512;                                                        // [512] inverse stage tables: TI[2^beta + j] = tw[j << (LOGM - 1 - beta)], beta < 9
+  uint32_t *at = reinterpret_cast<uint32_t *>(TI + 512);                         // [n + 1]
   uint64_t *acc = reinterpret_cast<uint64_t *>(scratch + (size_t)blockIdx.x * scratch_per_wg);  // [2][N]
 
   const int q = threadIdx.x;
@@ -993,7 +995,25 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void blind_rotate_big_kernel(
   const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
   for (int j = q; j <= n_small; j += TP)
     at[j] = (uint32_t)((((ks[j] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  // twiddles of the first three forward passes and of the first three inverse passes live in LDS (16 KB): a pass's twiddles
+  // cost an LDS round trip instead of one through L2; the last pass of each direction has a different set per thread and keeps
+  // the global tables, requested at the START of the transform
+  for (int idx = q; idx < 512; idx += TP) {
+    TF[idx] = psi[idx];
+    const int beta = idx < 2 ? 0 : 31 - __builtin_clz(idx);  // idx = 2^beta + j
+    TI[idx] = idx < 2 ? make_double2(1.0, 0.0) : tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
+  }
   __syncthreads();
+  auto load_inv_tab = [&](double2 (&w)[7], auto lo_tag) __attribute__((always_inline)) {
+    constexpr int LO = decltype(lo_tag)::value;
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) {
+      const int fb = kk < 4 ? 2 : (kk < 6 ? 1 : 0);
+      const int e = kk < 4 ? kk : (kk < 6 ? (kk - 4) : 0);
+      const int beta = LO + fb;
+      w[kk] = beta == 0 ? make_double2(1.0, 0.0) : TI[(1 << beta) + (fft_point<LOGM, LO, 3>(q, e) & ((1 << beta) - 1))];
+    }
+  };
   {  // acc = (0, X^{-b~} * LUT)
     const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
     const int t = (2 * N - (int)at[n_small]) & (2 * N - 1);
@@ -1044,8 +1064,8 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void blind_rotate_big_kernel(
       const uint64_t *acc_r = acc + (size_t)row * N;
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        double2 x[8], w[7];
-        load_fwd_twiddles<LOGM, LOGM - 3, false>(w, q, tw_here(psi));  // in flight while the digits are formed
+        double2 x[8], w[7], wd[7];
+        load_fwd_twiddles<LOGM, 0, false>(wd, q, tw_here(psi));  // the last pass's twiddles (global): in flight across the first three passes
         // the rotated difference is re-read for every level (L2-resident scratch) instead of being carried in registers
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1056,20 +1076,20 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void blind_rotate_big_kernel(
         }
         // forward transform: every pass's twiddles are requested one pass ahead (behind the butterflies, in front of the
         // exchange and its barrier), the key rows of this term before the last pass
+        load_fwd_twiddles<LOGM, LOGM - 3, false>(w, q, TF);
         fft_pass_w<true, LOGM - 3>(x, w);
-        load_fwd_twiddles<LOGM, LOGM - 6, false>(w, q, tw_here(psi));
+        load_fwd_twiddles<LOGM, LOGM - 6, false>(w, q, TF);
         FHES_XCHG(LOGM - 3, LOGM - 6);
         fft_pass_w<true, LOGM - 6>(x, w);
-        load_fwd_twiddles<LOGM, LOGM - 9, false>(w, q, tw_here(psi));
+        load_fwd_twiddles<LOGM, LOGM - 9, false>(w, q, TF);
         FHES_XCHG(LOGM - 6, LOGM - 9);
         fft_pass_w<true, LOGM - 9>(x, w);
         const double2 *G0 = G + (((size_t)l * KP1 + row) * KP1 + 0) * M, *G1 = G0 + M;
         double2 g0[8], g1[8];
-        load_fwd_twiddles<LOGM, 0, false>(w, q, tw_here(psi));
         FHES_XCHG(LOGM - 9, 0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { g0[e] = G0[fft_point<LOGM, 0, 3>(q, e)]; g1[e] = G1[fft_point<LOGM, 0, 3>(q, e)]; }
-        fft_pass_w<true, 0>(x, w);
+        fft_pass_w<true, 0>(x, wd);
         // the spectrum is in the registers in the layout the products want (pass (0, 3)): no trip through buf.
         // The chain's first term is a plain product in the oracle; fma(a, b, -0.0) IS that product, bit for bit (a * b + (-0) keeps
         // the product's value and the sign of a zero), so the accumulators start at -0.0 and the loop body has one form
@@ -1089,10 +1109,9 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void blind_rotate_big_kernel(
     // every rotated difference of this iteration has been taken: the accumulator may change now
 #pragma unroll 1
     for (int col = 0; col < KP1; ++col) {
-      double2 x[8], w[7];
-      load_pass_twiddles<LOGM, 3>(w, q, tw_here(tw));  // second inverse pass (the first one owns bit 0: its twiddles are 1 and the stage-1 / stage-2 ones)
-      double2 w0[7];
-      load_pass_twiddles<LOGM, 0>(w0, q, tw_here(tw));
+      double2 x[8], w[7], wl[7];
+      load_pass_twiddles<LOGM, 9>(wl, q, tw_here(tw));  // the last pass's twiddles (global): in flight across the first three passes
+      load_inv_tab(w, std::integral_constant<int, 0>{});
       if (col == 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = O0[e];
@@ -1100,10 +1119,11 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void blind_rotate_big_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = obuf[q + e * TP];
       }
-      fft_pass_w<false, 0>(x, w0);
+      fft_pass_w<false, 0>(x, w);
+      load_inv_tab(w, std::integral_constant<int, 3>{});
       FHES_XCHG(0, 3);
       fft_pass_w<false, 3>(x, w);
-      load_pass_twiddles<LOGM, 6>(w, q, tw_here(tw));
+      load_inv_tab(w, std::integral_constant<int, 6>{});
       FHES_XCHG(3, 6);
       fft_pass_w<false, 6>(x, w);
       int zc = 0;
@@ -1112,7 +1132,6 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void blind_rotate_big_kernel(
       const double2 *twist_l = tw_here(twist);
       double2 tws[8];
       uint64_t alo[8], ahi[8];
-      load_pass_twiddles<LOGM, 9>(w, q, tw_here(tw));
       // untwist factors and the accumulator words of the update: requested in front of the last exchange
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -1122,7 +1141,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void blind_rotate_big_kernel(
         ahi[e] = acc_c[p + M];
       }
       FHES_XCHG(6, 9);
-      fft_pass_w<false, 9>(x, w);
+      fft_pass_w<false, 9>(x, wl);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int p = fft_point<LOGM, LOGM - 3, 3>(q, e);

@@ -15,6 +15,14 @@ files and sharing NO code with the product's circuit compiler (`fhe_string_amd/c
     element_at_bool                 /root/reference/src/ciphertext/mod.rs:271-287
     FheString::split_opt / split    /root/reference/src/ciphertext/split.rs:238-341
     if_then_else_zero & co          /root/reference/src/ciphertext/logic.rs:13-38
+  and, for the rest of the reference's tables (config 5's suite and its neighbours):
+    rsplit / split_inclusive / split_terminator / rsplit_terminator / splitn / rsplitn / split_ascii_whitespace /
+    split_once / rsplit_once (+ truncate, expand_first / expand_last)        split.rs:86-205, 343-513
+    trim / trim_start / trim_end / strip_prefix / strip_suffix / truncate   trim.rs:15-133
+    replace / replacen                                                      replace.rs:17-104
+    add / insert / repeat                                                   insert.rs:14-124
+    char_at / substr_to / substr_from / substr_end                          mod.rs:165-237
+    to_lowercase / to_uppercase / eq_ignore_ascii_case, lt / le / gt / ge   convert.rs:14-62, compare.rs:56-116
 
 Three layers, as in the reference's stack:
 
@@ -289,6 +297,47 @@ class Integer:
             sums.append(t)
         return self._propagate(sums, self.s.trivial(1))
 
+    def scalar_sub_parallelized(self, a, c):
+        """a - c modulo M^n"""
+        return self.scalar_add_parallelized(a, (self.M ** len(a) - c) % self.M ** len(a))
+
+    def scalar_ge_parallelized(self, a, c):
+        return self._uni(self._scalar_cmp(a, c), lambda s: int(s >= 1), 1) if c < self.M ** len(a) else self.create_trivial_boolean_block(False)
+
+    def scalar_le_parallelized(self, a, c):
+        return self._uni(self._scalar_cmp(a, c), lambda s: int(s <= 1), 1) if c < self.M ** len(a) else self.create_trivial_boolean_block(True)
+
+    def mul_parallelized(self, a, b):
+        """a * b modulo M^n: every block product split into its low and high digit, the shifted terms summed"""
+        nb = len(a)
+        terms = []
+        for i in range(nb):
+            for j in range(nb - i):
+                lo = self._bi(a[i], b[j], lambda x, y: (x * y) % self.M, self.M - 1)
+                row = [self.s.trivial(0) for _ in range(nb)]
+                row[i + j] = lo
+                terms.append(row)
+                if i + j + 1 < nb:
+                    hi = self._bi(a[i], b[j], lambda x, y: (x * y) // self.M, (self.M - 1) ** 2 // self.M)
+                    row = [self.s.trivial(0) for _ in range(nb)]
+                    row[i + j + 1] = hi
+                    terms.append(row)
+        return self.unchecked_sum_ciphertexts_vec_parallelized(terms)
+
+    def rem_of_clear_by(self, i, b):
+        """`rem_parallelized(trivial i, b)` (insert.rs:32): i mod b, and i itself for b = 0 (tfhe-rs's remainder of a division by
+        zero is the numerator).  The numerator is public, so the result is a selection over the possible values of b."""
+        nb = len(b)
+        rows = []
+        for v in range(self.M ** nb):
+            r = i % v if v else i % self.M ** nb
+            if r == 0:
+                continue
+            hit = self.scalar_eq_parallelized(b, v)
+            rows.append(self.scalar_mul_of_boolean_radix(self.into_radix(hit, nb), r))
+        total = self.unchecked_sum_ciphertexts_vec_parallelized(rows)
+        return total if total is not None else self.create_trivial_radix(0, nb)
+
     def unchecked_sum_ciphertexts_vec_parallelized(self, vs):
         """sum of radix integers modulo M^n (None for an empty list, like tfhe-rs): per column, groups of blocks whose values
         together fit the carry space are added and split into a message (stays in the column) and a carry (moves up)"""
@@ -543,6 +592,150 @@ class StringOracle:
             b = self.k.boolean_bitor(b, pi)
         return b, index
 
+    def char_at(self, a, i):                 # mod.rs:217-237
+        v = [self.if_then_else_zero(self.k.scalar_eq_parallelized(i, j), aj) for j, aj in enumerate(a.c)]
+        total = self.k.unchecked_sum_ciphertexts_vec_parallelized(v)
+        return total if total is not None else self.term_char()
+
+    def substr_to(self, a, index):           # mod.rs:165-180
+        return Chars([self.if_then_else_zero(self.k.scalar_gt_parallelized(index, i), ai) for i, ai in enumerate(a.c)])
+
+    def substr_from(self, a, index):         # mod.rs:183-195
+        return Chars([self.char_at(a, self.k.scalar_add_parallelized(index, i)) for i in range(len(a.c))])
+
+    def substr_end(self, a, start, end):     # mod.rs:198-213
+        out = []
+        for i in range(len(a.c)):
+            i_add_index = self.k.scalar_add_parallelized(start, i)
+            lt_end = self.k.lt_parallelized(i_add_index, end)
+            out.append(self.if_then_else_zero(lt_end, self.char_at(a, i_add_index)))
+        return Chars(out)
+
+    def find_pred_unchecked(self, a, pred, reverse=False):   # search.rs:197-213 over mod.rs:292-355
+        return self.index_of_unchecked_with_options([pred(c) for c in a.c], reverse)
+
+    # ---- convert.rs ----
+    def is_uppercase(self, c):               # convert.rs:14-19
+        return self.k.boolean_bitand(self.k.scalar_ge_parallelized(c, 65), self.k.scalar_le_parallelized(c, 90))
+
+    def is_lowercase(self, c):               # convert.rs:22-27
+        return self.k.boolean_bitand(self.k.scalar_ge_parallelized(c, 97), self.k.scalar_le_parallelized(c, 122))
+
+    def char_to_lowercase(self, c):          # convert.rs:30-36
+        return self.k.if_then_else_parallelized(self.is_uppercase(c), self.k.scalar_add_parallelized(c, 32), c)
+
+    def char_to_uppercase(self, c):          # convert.rs:39-45
+        return self.k.if_then_else_parallelized(self.is_lowercase(c), self.k.scalar_sub_parallelized(c, 32), c)
+
+    def to_lowercase(self, a):               # convert.rs:51-55
+        return Chars([self.char_to_lowercase(c) for c in a.c])
+
+    def to_uppercase(self, a):               # convert.rs:58-62
+        return Chars([self.char_to_uppercase(c) for c in a.c])
+
+    def eq_ignore_ascii_case(self, a, s):    # compare.rs:113-116
+        return self.eq(self.to_lowercase(a), self.to_lowercase(s))
+
+    # ---- trim.rs ----
+    def is_whitespace(self, c):              # trim.rs:15-25
+        in_range = self.k.boolean_bitand(self.k.scalar_ge_parallelized(c, 9), self.k.scalar_le_parallelized(c, 13))
+        return self.k.boolean_bitor(in_range, self.k.scalar_eq_parallelized(c, 32))
+
+    def truncate(self, a, index):            # trim.rs:119-133
+        return self.substr_to(a, index)
+
+    def _not_term_not_ws(self, c):           # the closure of trim_end / trim (trim.rs:45-51, 64-70)
+        not_term = self.k.boolean_bitnot(self.k.scalar_eq_parallelized(c, self.TERMINATOR))
+        return self.k.boolean_bitand(not_term, self.k.boolean_bitnot(self.is_whitespace(c)))
+
+    def trim_start(self, a):                 # trim.rs:31-40
+        is_some, val = self.find_pred_unchecked(a, lambda c: self.k.boolean_bitnot(self.is_whitespace(c)))
+        return self.substr_from(a, self.if_then_else_zero(is_some, val))
+
+    def trim_end(self, a):                   # trim.rs:43-59
+        is_some, val = self.find_pred_unchecked(a, self._not_term_not_ws, reverse=True)
+        i = self.if_then_else_zero(is_some, self.k.scalar_add_parallelized(val, 1))
+        return self.truncate(a, i)
+
+    def trim(self, a):                       # trim.rs:62-85
+        found = [self._not_term_not_ws(c) for c in a.c]
+        start = self.index_of_unchecked_with_options(found, False)
+        end = self.index_of_unchecked_with_options(found, True)
+        i = self.if_then_else_zero(end[0], self.k.scalar_add_parallelized(end[1], 1))
+        t = self.truncate(a, i)
+        return self.substr_from(t, self.if_then_else_zero(start[0], start[1]))
+
+    def strip_prefix(self, a, s):            # trim.rs:89-97
+        return self.substr_eq(a, 0, s), self.substr_from(a, self.len(s))
+
+    def strip_suffix(self, a, s):            # trim.rs:101-116
+        found = self.rfind(a, s)
+        stripped = self.truncate(a, found[1])
+        i_add_slen = self.k.add_parallelized(found[1], self.len(s))
+        is_some = self.k.boolean_bitand(found[0], self.k.eq_parallelized(i_add_slen, self.len(a)))
+        return is_some, stripped
+
+    # ---- replace.rs ----
+    def replace_opt(self, a, p, s, n_max, l):    # replace.rs:37-104
+        l = min(l, self.k.M ** self.nb_usize - 1)
+        found = self.find_all(a, p)
+        p_len, s_len = self.len(p), self.len(s)
+        len_diff = self.k.sub_parallelized(p_len, s_len)
+        in_match = self.k.create_trivial_boolean_block(False)
+        j = self.usize_trivial(0)
+        n = self.usize_trivial(0)
+        v = []
+        for i in range(l):
+            c = self.k.scalar_add_parallelized(self.k.mul_parallelized(n, len_diff), i)
+            j_lt_slen = self.k.lt_parallelized(j, s_len)
+            match_and_jltslen = self.k.boolean_bitand(in_match, j_lt_slen)
+            found_c = self.element_at_bool(found, c)
+            if n_max is not None:
+                found_c_ok = self.k.boolean_bitand(found_c, self.k.lt_parallelized(n, n_max))
+            else:
+                found_c_ok = found_c
+            n_add_found_c = self.k.add_parallelized(n, self.k.into_radix(found_c_ok, len(n)))
+            in_match = self.if_then_else_bool(match_and_jltslen, in_match, found_c_ok)
+            j = self.if_then_else_zero(match_and_jltslen, j)
+            n = self.k.if_then_else_parallelized(match_and_jltslen, n, n_add_found_c)
+            sj = self.char_at(s, j)
+            self_c = self.char_at(a, c)
+            v.append(self.k.if_then_else_parallelized(in_match, sj, self_c))
+            j = self.k.scalar_add_parallelized(j, 1)
+        v.append(self.term_char())
+        return Chars(v)
+
+    # ---- insert.rs ----
+    def insert(self, a, index, b):           # insert.rs:48-124
+        l = min(a.max_len() + b.max_len(), self.k.M ** self.nb_usize - 1)
+        b_len = self.len(b)
+        index_add_blen = self.k.add_parallelized(index, b_len)
+        out = []
+        for i in range(l):
+            i_lt = self.k.scalar_gt_parallelized(index_add_blen, i)
+            b_at = self.char_at(b, self.k.sub_parallelized(self.usize_trivial(i), index))
+            a_at = self.char_at(a, self.k.sub_parallelized(self.usize_trivial(i), b_len))
+            c2 = self.k.if_then_else_parallelized(i_lt, b_at, a_at)
+            c0 = self.k.scalar_gt_parallelized(index, i)
+            out.append(self.k.if_then_else_parallelized(c0, a.c[i % len(a.c)], c2))
+        out.append(self.term_char())
+        return Chars(out)
+
+    def add(self, a, s):                     # insert.rs:14-17
+        return self.insert(a, self.len(a), s)
+
+    def repeat(self, a, n, l):               # insert.rs:20-45
+        l = min(l, self.k.M ** self.nb_usize - 1)
+        self_len = self.len(a)
+        n_mul = self.k.mul_parallelized(n, self_len)
+        out = []
+        for i in range(l):
+            i_lt = self.k.lt_parallelized(self.usize_trivial(i), n_mul)
+            ch = self.char_at(a, self.k.rem_of_clear_by(i, self_len))
+            out.append(self.if_then_else_zero(i_lt, ch))
+        out.append(self.term_char())
+        return Chars(out)
+
     # ---- split.rs ----
     def split_opt(self, a, p, inclusive, reverse):    # split.rs:238-333
         pattern_empty = self.is_empty(p)
@@ -588,6 +781,70 @@ class StringOracle:
         out.reverse()
         return out
 
+    def truncate_slices(self, v, i):         # split.rs:86-113
+        n = self.usize_trivial(0)
+        out = []
+        for is_some_i, start, end in v:
+            n_lt_i = self.k.lt_parallelized(n, i)
+            out.append((self.k.boolean_bitand(n_lt_i, is_some_i), start, end))
+            n = self.k.add_parallelized(n, self.k.into_radix(is_some_i, len(n)))
+        return out
+
+    def expand_first(self, v):               # split.rs:147-173
+        not_found = self.k.create_trivial_boolean_block(True)
+        zero = self.usize_trivial(0)
+        out = []
+        for is_some_i, start, end in v:
+            nf_and_some = self.k.boolean_bitand(not_found, is_some_i)
+            out.append((is_some_i, self.k.if_then_else_parallelized(nf_and_some, zero, start), end))
+            not_found = self.k.boolean_bitand(not_found, self.k.boolean_bitnot(is_some_i))
+        return out
+
+    def expand_last(self, v, a):             # split.rs:176-205
+        not_found = self.k.create_trivial_boolean_block(True)
+        self_len = self.len(a)
+        out = []
+        for is_some_i, start, end in reversed(v):
+            nf_and_some = self.k.boolean_bitand(not_found, is_some_i)
+            out.append((is_some_i, start, self.k.if_then_else_parallelized(nf_and_some, self_len, end)))
+            not_found = self.k.boolean_bitand(not_found, self.k.boolean_bitnot(is_some_i))
+        out.reverse()
+        return out
+
+    def splitn(self, a, n, p):               # split.rs:368-373
+        return self.expand_last(self.truncate_slices(self.split(a, p), n), a)
+
+    def rsplitn(self, a, n, p):              # split.rs:380-387
+        v = self.truncate_slices(self.rsplit(a, p), n)
+        v = self.expand_first(list(reversed(v)))
+        return list(reversed(v))
+
+    def split_ascii_whitespace(self, a):     # split.rs:415-473
+        def is_ws(c):
+            return self.k.boolean_bitor(self.is_whitespace(c), self.k.scalar_eq_parallelized(c, self.TERMINATOR))
+        whitespace = [is_ws(c) for c in a.c]
+        # find_all_next_pred_unchecked (search.rs:54-65, 179-194): per i, the first j >= i with the predicate, offset added
+        nxt = []
+        for i in range(len(a.c)):
+            is_some, val = self.index_of_unchecked_with_options(whitespace[i:], False)
+            nxt.append((is_some, self.k.scalar_add_parallelized(val, i)))
+        default = (self.k.create_trivial_boolean_block(False), self.usize_trivial(0))
+        self_len = self.len(a)
+        out = []
+        for i in range(len(a.c)):
+            not_ws = self.k.boolean_bitnot(whitespace[i])
+            prev = self.k.create_trivial_boolean_block(True) if i == 0 else whitespace[i - 1]
+            is_some = self.k.boolean_bitand(not_ws, prev)
+            nx = nxt[i + 1] if i + 1 < len(nxt) else default
+            end = self.k.if_then_else_parallelized(nx[0], nx[1], self_len)
+            out.append((is_some, self.usize_trivial(i), end))
+        return out
+
+    def split_once_opt(self, a, p, reverse):     # split.rs:478-501
+        found = self.rfind(a, p) if reverse else self.find(a, p)
+        nxt = self.k.add_parallelized(found[1], self.len(p))
+        return found[0], self.substr_to(a, found[1]), self.substr_from(a, nxt)
+
     def split(self, a, p):                   # split.rs:339-341
         return self.split_opt(a, p, False, False)
 
@@ -620,6 +877,67 @@ class StringOracle:
         starts = [b for e in elems for b in e[1]]
         ends = [b for e in elems for b in e[2]]
         return self.values(some + starts + ends)
+
+
+def string_blocks_of(chars):
+    return [b for ch in chars.c for b in ch]
+
+
+def run_args(so, op, args):
+    """`args` in the reference's argument order: FheString operands (Chars), FheUsize operands (block lists), clear integers"""
+    S = [x for x in args if isinstance(x, Chars)]
+    U = [x for x in args if isinstance(x, list)]
+    I = [x for x in args if isinstance(x, int)]
+    if op in ("trim", "trim_start", "trim_end", "to_lowercase", "to_uppercase"):
+        return so.values(string_blocks_of(getattr(so, op)(S[0])))
+    if op in ("strip_prefix", "strip_suffix"):
+        is_some, val = getattr(so, op)(S[0], S[1])
+        return so.values([is_some] + string_blocks_of(val))
+    if op == "replace":
+        return so.values(string_blocks_of(so.replace_opt(S[0], S[1], S[2], None, I[0])))
+    if op == "replacen":
+        return so.values(string_blocks_of(so.replace_opt(S[0], S[1], S[2], U[0], I[0])))
+    if op == "add":
+        return so.values(string_blocks_of(so.add(S[0], S[1])))
+    if op == "insert":
+        return so.values(string_blocks_of(so.insert(S[0], U[0], S[1])))
+    if op == "repeat":
+        return so.values(string_blocks_of(so.repeat(S[0], U[0], I[0])))
+    if op == "eq_ignore_ascii_case":
+        return so.out_bool(so.eq_ignore_ascii_case(S[0], S[1]))
+    if op in ("splitn", "rsplitn"):
+        return so.out_slices(getattr(so, op)(S[0], U[0], S[1]))
+    if op == "split_ascii_whitespace":
+        return so.out_slices(so.split_ascii_whitespace(S[0]))
+    if op in ("split_once", "rsplit_once"):
+        is_some, a, b = so.split_once_opt(S[0], S[1], op == "rsplit_once")
+        return so.values([is_some] + string_blocks_of(a) + string_blocks_of(b))
+    if op in ("char_at",):
+        return so.values(so.char_at(S[0], U[0]))
+    if op in ("substr_to", "substr_from", "truncate"):
+        return so.values(string_blocks_of(getattr(so, op)(S[0], U[0])))
+    if op == "substr_end":
+        return so.values(string_blocks_of(so.substr_end(S[0], U[0], U[1])))
+    return run_op(so, op, S)
+
+
+def run_plain_args(op, args, nb_usize, message_bits=2, carry_bits=2):
+    """`args`: the reference-table form -- {"s": text, "pad": n} / {"u": value} / {"i": value} in argument order"""
+    M = 1 << message_bits
+    nb_char = 0
+    while M ** nb_char < 128:
+        nb_char += 1
+    sh = PlainBlocks(message_bits, carry_bits)
+    so = StringOracle(sh, nb_char, nb_usize)
+    ops = []
+    for a in args:
+        if "s" in a:
+            ops.append(so.string_from_blocks([Blk(v, M - 1) for v in so.string_block_values(a["s"], a.get("pad"))]))
+        elif "u" in a:
+            ops.append([Blk(d, M - 1) for d in so.k.digits(a["u"], nb_usize)])
+        else:
+            ops.append(int(a["i"]))
+    return run_args(so, op, ops), sh.n_lut
 
 
 def run_plain(op, texts, pads, nb_usize, message_bits=2, carry_bits=2):

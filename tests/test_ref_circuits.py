@@ -113,3 +113,72 @@ def test_config1_at_the_real_parameter_set_under_oracle_encryption(libs):
         want, _ = sc.run_plain(op, [" A bcbc ", "bc"], [None, None], bu)
         assert got == want, op
         assert decode({"op": op, "a": " A bcbc "}, got, bu) == expect
+
+
+# ---- the rest of the reference's tables (trim / replace / insert / convert / remaining split variants) ---------------------
+CASES_EXT = json.load(open(os.path.join(HERE, "golden", "reference_tables.json")))["cases_ext"]
+
+
+@pytest.mark.parametrize("idx", range(len(CASES_EXT)))
+def test_extended_tables_on_plain_blocks_and_against_the_compiled_programs(idx, libs):
+    """every table case of tests/{trim,replace,insert,convert,split,compare}.rs beyond the hot path: the restatement's decoded
+    result is the table's, and the compiled programs (faithful AND log-depth) produce the restatement's OUTPUT BLOCKS one by one"""
+    from fhe_string_amd import _lib
+    from fhe_string_amd._lib import FheError
+    from tests.progs import build_inputs, decode_generic
+    from tests.test_circuits_plain import prog
+    case = CASES_EXT[idx]
+    bu = num_blocks_usize(255)
+    want, _ = sc.run_plain_args(case["op"], case["args"], bu)
+    shape, digits = build_inputs(_lib.load(), case["op"], case["args"], bu)
+    p = prog(case["op"], shape, bu)
+    self_str = case["args"][0]["s"] if "s" in case["args"][0] else None
+    assert decode_generic(case["op"], np.array(want), p.out_parts, bu, self_str) == case["expect"], (case, want)
+    for form in ("", "_logdepth"):
+        try:
+            pf = prog(case["op"] + form, shape, bu)
+        except (FheError, AssertionError):
+            assert form == "_logdepth"
+            continue
+        got = [int(v) for v in pf.run_plain(digits.astype("int64"))]
+        assert got == want, (case, form)
+
+
+def test_random_inputs_block_by_block_against_both_forms_of_the_compiled_programs(libs):
+    """random strings, occurring patterns of 1-7 characters (the class of the round-3 fault: `replace_logdepth` lost patterns of 4-5
+    characters), padded and unpadded: restatement == faithful program == log-depth program, every output block"""
+    import random
+    from fhe_string_amd import _lib
+    from fhe_string_amd._lib import FheError
+    from tests.progs import build_inputs
+    from tests.test_circuits_plain import prog
+    rng = random.Random(0x5EED4)
+    bu = num_blocks_usize(255)
+    alphabet = "ab c,x"
+    checked = 0
+    for trial in range(36):
+        n = rng.randint(4, 14)
+        text = "".join(rng.choice(alphabet) for _ in range(n))
+        m = rng.randint(1, min(7, n))
+        at = rng.randint(0, n - m)
+        pat = text[at:at + m] if rng.random() < 0.8 else "".join(rng.choice(alphabet) for _ in range(m))
+        sub = "".join(rng.choice("yz") for _ in range(rng.randint(0, 3)))
+        pad_a = None if rng.random() < 0.5 else n + rng.randint(0, 3)
+        pad_p = None if rng.random() < 0.6 else m + rng.randint(0, 2)
+        A, P, S = {"s": text, "pad": pad_a}, {"s": pat, "pad": pad_p}, {"s": sub, "pad": None}
+        ops = [("find", [A, P]), ("rfind", [A, P]), ("contains", [A, P]), ("split", [A, P]), ("rsplit", [A, P]),
+               ("replace", [A, P, S, {"i": n + 6}]), ("replacen", [A, P, S, {"u": rng.randint(0, 3)}, {"i": n + 6}]),
+               ("strip_suffix", [A, P]), ("split_once", [A, P]), ("trim", [A]), ("splitn", [A, {"u": rng.randint(0, 4)}, P])]
+        for op, args in rng.sample(ops, 4):
+            want, _ = sc.run_plain_args(op, args, bu)
+            shape, digits = build_inputs(_lib.load(), op, args, bu)
+            for form in ("", "_logdepth"):
+                try:
+                    pf = prog(op + form, shape, bu)
+                except (FheError, AssertionError):
+                    assert form == "_logdepth"
+                    continue
+                got = [int(v) for v in pf.run_plain(digits.astype("int64"))]
+                assert got == want, (op + form, args)
+                checked += 1
+    assert checked >= 200
