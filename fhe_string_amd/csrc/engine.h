@@ -86,6 +86,7 @@ struct fhes_ctx {
 
   // keys
   bool keys_loaded = false;
+  void *bsk_e_base = nullptr;  // allocation behind bsk_e when it was made by fhes_upload_keys (a broadcast allocates bsk_e itself)
   int mb_ilv = 0;  // multi-bit key in the interleaved layout (FHES_MB_INTERLEAVE=1 at key upload; round-4 A/B)
   uint64_t *ksk = nullptr;   // [big][ks_level][ks_stride]
   uint64_t *ksk_bias = nullptr;  // [ks_stride]: (B/2) * sum_{i,l} ksk[i][l][j]  (biased-digit keyswitch)

@@ -873,7 +873,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e);
+  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e_base ? ctx->bsk_e_base : (void *)ctx->bsk_e);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->twist_inv64); (void)hipFree(ctx->root); (void)hipFree(ctx->psi); (void)hipFree(ctx->odd_fix); (void)hipFree(ctx->cdpp); (void)hipFree(ctx->lut_polys);
   (void)hipDeviceSynchronize();
   auto drop_lane = [](Lane &l) {
@@ -959,7 +959,15 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
 #undef FHES_B2F
     FHES_HIP(hipGetLastError());
     if (fast_shape(ctx->p)) {  // the register-order layout of the throughput kernels
-      if (!ctx->bsk_e) FHES_HIP(hipMalloc(&ctx->bsk_e, npoly * d.M * 16));
+      if (!ctx->bsk_e) {
+        // developer knob (round-4 experiment: does the multi-bit kernel's rate depend on where the key lies?): FHES_BSK_E_PAD bytes in
+        // front of the engine-layout key.  The padded allocation is released through bsk_e_base.
+        const char *pad_s = getenv("FHES_BSK_E_PAD");
+        const size_t pad = pad_s ? (size_t)strtoull(pad_s, nullptr, 0) & ~(size_t)255 : 0;
+        FHES_HIP(hipMalloc(&ctx->bsk_e_base, npoly * d.M * 16 + pad));
+        ctx->bsk_e = reinterpret_cast<double2 *>(reinterpret_cast<unsigned char *>(ctx->bsk_e_base) + pad);
+        if (getenv("FHES_DEBUG_ADDR")) fprintf(stderr, "[fhes] bsk_e at %p (%zu bytes, pad %zu)\n", (void *)ctx->bsk_e, npoly * d.M * 16, pad);
+      }
       // multi-bit keys: the 2^g GGSWs of a group interleaved row by row (round 4: g = 3 runs 7-10 % faster from it in alternating
       // same-run launches, profiles/r04_ab_multibit_layout.txt).  Default: on for g = 3; FHES_MB_INTERLEAVE=0 / 1 forces it.
       {
