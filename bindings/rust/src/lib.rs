@@ -82,6 +82,24 @@ impl StringEncryption for str {
     }
 }
 
+/// The paths under which code written against the reference names tfhe-rs's types (its example does:
+/// `use tfhe::{integer::BooleanBlock, shortint::prelude::PARAM_MESSAGE_2_CARRY_2_KS_PBS};`, examples/cmd/main.rs:5): with this crate
+/// the same line reads `use fhe_string::tfhe::{...}`.
+pub mod tfhe {
+    pub mod integer {
+        pub use crate::{BooleanBlock, RadixCiphertext};
+    }
+    pub mod shortint {
+        pub use crate::ClassicPBSParameters;
+        pub mod parameters {
+            pub use crate::PARAM_MESSAGE_2_CARRY_2_KS_PBS;
+        }
+        pub mod prelude {
+            pub use crate::PARAM_MESSAGE_2_CARRY_2_KS_PBS;
+        }
+    }
+}
+
 /// Message of the last failing ABI call on this thread (`fhes_last_error`).
 pub(crate) fn last_error() -> String {
     unsafe {

@@ -158,6 +158,18 @@ int main() {
   fhes_ct *u = fhes_usize_encrypt(ck, 201);
   uint64_t uv = 0;
   EXPECT(u && fhes_usize_decrypt(ck, u, &uv) == FHES_OK && uv == 201, "usize round trip");
+  // round 4: ClientKey::encrypt / decrypt (client_key.rs:23-33), FheUsize::new_trivial, server-key facts
+  {
+    fhes_ct *rc8 = fhes_radix_encrypt(ck, 0x1F7);  // reduced modulo M^num_blocks_char = 256
+    uint64_t rv = 0;
+    EXPECT(rc8 && fhes_ct_num_blocks(rc8) == fhes_client_key_num_blocks_char(ck), "radix encrypt: block count");
+    EXPECT(rc8 && fhes_radix_decrypt(ck, rc8, &rv) == FHES_OK && rv == 0xF7, "radix round trip (got %llu)", (unsigned long long)rv);
+    EXPECT(fhes_radix_encrypt(nullptr, 1) == nullptr && fhes_radix_decrypt(ck, nullptr, &rv) < 0 && fhes_radix_decrypt(ck, rc8, nullptr) < 0, "null arguments accepted");
+    EXPECT(fhes_usize_trivial(nullptr, 5) == nullptr, "trivial usize without a key accepted");
+    int32_t nbc = -1, nbu = -1;
+    EXPECT(fhes_server_key_info(nullptr, nullptr, &nbc, &nbu) < 0, "server key info of a null key accepted");
+    fhes_ct_destroy(rc8);
+  }
 
   // ---- serialisers: round trips ----
   std::vector<uint8_t> ck_blob((size_t)fhes_client_key_serialize(ck, nullptr, 0));

@@ -33,8 +33,10 @@ gen_ffi = load(os.path.join(CRATE, "gen_ffi.py"), "gen_ffi")
 
 def rust_files():
     out = []
-    for d, _, files in os.walk(SRC):
-        out += [os.path.join(d, f) for f in files if f.endswith(".rs")]
+    for root in (SRC, os.path.join(CRATE, "examples")):
+        for d, _, files in os.walk(root):
+            out += [os.path.join(d, f) for f in files if f.endswith(".rs")]
+    out.append(os.path.join(CRATE, "build.rs"))
     return sorted(out)
 
 
