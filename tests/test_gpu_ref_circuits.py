@@ -102,3 +102,46 @@ def test_faithful_split_blocks_on_a_shorter_input(libs):
         want, _ = sc.run_plain("split", [s, pat], pads, bu)
         got, _ = device_blocks(w, "split", [s, pat], pads, bu)
         assert got == want, pat
+
+
+def device_blocks_args(w, op, args, bu):
+    """like device_blocks, for operations with FheUsize / clear-integer operands (reference-table argument form)"""
+    from fhe_string_amd import _lib
+    from tests.progs import build_inputs
+    shape, digits = build_inputs(_lib.load(), op, args, bu)
+    p = Prog(w.p, op, shape, bu)
+    cts = w.encrypt(np.asarray(digits, dtype=np.uint8))
+    ctx = w.ctx()
+    h = check(w.lib.fhes_arena_alloc(ctx, len(cts)))
+    check(w.lib.fhes_arena_upload(ctx, h, len(cts), ptr(cts)))
+    in_h = np.arange(h, h + len(cts), dtype=np.int32)
+    out_h = np.zeros(p.n_outputs, dtype=np.int32)
+    check(w.lib.fhes_program_run(ctx, p.h, ptr(in_h), ptr(out_h)))
+    dev = np.zeros((p.n_outputs, w.W), dtype=np.uint64)
+    check(w.lib.fhes_arena_download(ctx, int(out_h[0]), p.n_outputs, ptr(dev)))
+    check(w.lib.fhes_arena_free(ctx, h, len(cts)))
+    check(w.lib.fhes_arena_free(ctx, int(out_h[0]), p.n_outputs))
+    return [int(v) for v in w.decrypt(dev)]
+
+
+@pytest.mark.parametrize("form", ["", "_logdepth"])
+def test_config5_suite_operations_blocks_on_a_shorter_input(form, libs):
+    """the operations of BASELINE config 5's suite (find / rfind / split / replace / trim, `examples/cmd/main.rs:127-142`, `:219-238`,
+    `:269-283`, `:442-449`) and their neighbours on a 24-character padded input: the device's decrypted output blocks, in both forms of
+    every circuit, against the restatement (the check at device level that round 3's `replace_logdepth` fault would have failed)"""
+    w = world("default", l=255)
+    bu = num_blocks_usize(255)
+    text = "  the fish and the fishes "
+    A = {"s": text, "pad": 28}
+    P, S = {"s": "fish", "pad": None}, {"s": "_", "pad": None}
+    cases = [("rfind", [A, P]), ("trim", [A]), ("trim_start", [A]), ("trim_end", [A]), ("replace", [A, P, S, {"i": 30}]),
+             ("replacen", [A, P, S, {"u": 1}, {"i": 30}]), ("splitn", [A, {"u": 2}, P]), ("rsplit", [A, P]),
+             ("split_once", [A, P]), ("strip_suffix", [A, {"s": "es ", "pad": None}]), ("split_ascii_whitespace", [A])]
+    for op, args in cases:
+        want, _ = sc.run_plain_args(op, args, bu)
+        try:
+            got = device_blocks_args(w, op + form, args, bu)
+        except Exception as e:      # an operation without a log-depth form
+            assert form == "_logdepth" and "unknown" in str(e).lower(), (op, e)
+            continue
+        assert got == want, (op + form, [i for i, (x, y) in enumerate(zip(got, want)) if x != y][:10])
