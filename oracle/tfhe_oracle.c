@@ -562,6 +562,7 @@ oracle_ctx *oracle_ctx_create(const oracle_params *p) {
   if (!p || p->poly_size < 8 || (p->poly_size & (p->poly_size - 1))) return NULL;
   if (p->glwe_dim < 1 || p->pbs_level < 1 || p->lwe_dim < 1) return NULL;
   oracle_ctx *c = (oracle_ctx *)calloc(1, sizeof(*c));
+  (void)simd_level(); /* the path is chosen here, before any worker thread asks */
   c->p = *p;
   c->N = p->poly_size;
   c->M = c->N / 2;
