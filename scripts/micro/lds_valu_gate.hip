@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -89,6 +90,107 @@ __global__ __launch_bounds__(THREADS) void k(unsigned long long *stamps, double 
   sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = x[0] + x[1] + x[2] + x[3] + x[4] + x[5] + x[6] + x[7] + (double)(r[0].x + r[1].y + r[2].z + r[3].w);
 }
 
+// K: the shipped kernel's own phase structure per CMUX iteration, with its instruction counts (profiles/EXPERIMENTS.md, census of round 4):
+//   B6->B1  20 loads | 88 f64 + 157 other VALU | 8 stores | barrier
+//   B1->B3   8 loads | 72 f64 | 8 stores, 8 loads (wave-local exchange) | 72 f64 | 32 f64 + 32 dpp-class | 8 loads (twiddles) | 8 stores | barrier
+//   B3->B5   8 loads | 64 f64 | 32 f64 + 32 dpp-class | 72 f64 | 8 stores, 8 loads | 72 f64 | 8 stores, 6 loads | barrier
+//   B5->B6   8 loads | 184 f64 + 48 other | 8 stores | barrier
+// VARIANT 0: as shipped; 1: the same work with every exchange fused into the phase's ends (one load burst at the start, one store burst at the
+// end of each barrier phase: what the phases would cost WITHOUT the extra LDS round trips inside them); 2: as 0 without any LDS operation; 3: as
+// 0 without any arithmetic.
+#define INT8 asm volatile("v_xor_b32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_xor_b32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_add_u32 %7, %7, %8" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]) : "v"(yk))
+template <int N> __device__ __forceinline__ void fma_blocks(double (&x)[8], double a, double b) {
+  if constexpr (N > 0) { FMA8X; fma_blocks<N - 1>(x, a, b); }
+}
+template <int N> __device__ __forceinline__ void int_blocks(unsigned (&y)[8], unsigned yk) {
+  if constexpr (N > 0) { INT8; int_blocks<N - 1>(y, yk); }
+}
+template <int VARIANT>
+__global__ __launch_bounds__(256) void kk(unsigned long long *stamps, double *sink, int iters, double a, double b) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  double x[8];
+  unsigned y[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { x[i] = threadIdx.x + 1.0 + i; y[i] = threadIdx.x + i; }
+  const unsigned yk = threadIdx.x | 1u;
+  const unsigned addr = (threadIdx.x & 255) * 16u;
+  u32x4 wv = {threadIdx.x, 1u, 2u, 3u};
+  u32x4 r[4] = {};
+  constexpr bool LDS = VARIANT != 2, ALU = VARIANT != 3, FUSED = VARIANT == 1;
+  // VARIANT 4: the same totals in four IDENTICAL phases (one load burst, one store burst each); 5: as shipped with a workgroup barrier at the
+  // two wave-local exchanges as well (six phases); 6: four identical phases with the loads and stores split into two round trips each
+#define K_RD(n) do { if constexpr (LDS) { emit_rd<0, n>(r, addr); } } while (0)
+#define K_WR(n) do { if constexpr (LDS) { emit_wr<0, n>(addr, wv); } } while (0)
+#define K_WAIT do { if constexpr (LDS) { WAIT0; } } while (0)
+#define K_F(n) do { if constexpr (ALU) { fma_blocks<n>(x, a, b); } } while (0)
+#define K_I(n) do { if constexpr (ALU) { int_blocks<n>(y, yk); } } while (0)
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  for (int it = 0; it < iters; it++) {
+    if constexpr (VARIANT == 4) {
+#pragma unroll
+      for (int ph = 0; ph < 4; ph++) {
+        K_RD(10); K_RD(9); K_WAIT; K_F(21); K_I(8); K_WR(8); K_WR(4); K_WAIT; __builtin_amdgcn_s_barrier();
+      }
+    } else if constexpr (VARIANT == 6) {
+#pragma unroll
+      for (int ph = 0; ph < 4; ph++) {
+        K_RD(10); K_WAIT; K_F(10); K_I(4); K_WR(6); K_RD(9); K_WAIT; K_F(11); K_I(4); K_WR(6); K_WAIT; __builtin_amdgcn_s_barrier();
+      }
+    } else if constexpr (VARIANT == 5) {
+      K_RD(10); K_RD(10); K_WAIT; K_F(11); K_I(20); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(8); K_WAIT; K_F(9); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier(); K_RD(8); K_WAIT; K_F(9); K_F(4); K_I(4); K_RD(8); K_WAIT; K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(8); K_WAIT; K_F(8); K_F(4); K_I(4); K_F(9); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier(); K_RD(8); K_WAIT; K_F(9); K_WR(8); K_RD(6); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(8); K_WAIT; K_F(23); K_I(6); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+    } else if constexpr (!FUSED) {
+      K_RD(10); K_RD(10); K_WAIT; K_F(11); K_I(20); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(8); K_WAIT; K_F(9); K_WR(8); K_RD(8); K_WAIT; K_F(9); K_F(4); K_I(4); K_RD(8); K_WAIT; K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(8); K_WAIT; K_F(8); K_F(4); K_I(4); K_F(9); K_WR(8); K_RD(8); K_WAIT; K_F(9); K_WR(8); K_RD(6); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(8); K_WAIT; K_F(23); K_I(6); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+    } else {
+      K_RD(10); K_RD(10); K_WAIT; K_F(11); K_I(20); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(12); K_RD(12); K_WAIT; K_F(22); K_I(4); K_WR(8); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(11); K_RD(11); K_WAIT; K_F(30); K_I(4); K_WR(8); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(8); K_WAIT; K_F(23); K_I(6); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  if ((threadIdx.x & 63) == 0) stamps[(size_t)blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+  sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = x[0] + x[1] + x[2] + x[3] + x[4] + x[5] + x[6] + x[7] + (double)(r[0].x + r[1].y + r[2].z + r[3].w) + (double)(y[0] ^ y[1] ^ y[2] ^ y[3] ^ y[4] ^ y[5] ^ y[6] ^ y[7]);
+}
+
+template <int VARIANT>
+static void run_k(unsigned long long *d_st, double *d_sink, int n_cu, int wg_per_cu) {
+  const int iters = 5000;
+  auto kern = kk<VARIANT>;
+  hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float ms = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(n_cu * wg_per_cu), dim3(256), 65536, 0, d_st, d_sink, iters, 1.0000001, 1e-9);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  std::vector<unsigned long long> st((size_t)n_cu * wg_per_cu * 4);
+  hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> cyc;
+  for (size_t i = 0; i < st.size(); i++) cyc.push_back((double)st[i] / iters);
+  std::sort(cyc.begin(), cyc.end());
+  static const char *names[] = {"as shipped", "exchanges fused into the phase ends", "no LDS operations", "no arithmetic",
+                                "four identical phases, one round trip each", "as shipped + barriers at the wave-local exchanges (six phases)",
+                                "four identical phases, two round trips each"};
+  printf("{\"structure\": \"K\", \"variant\": \"%s\", \"workgroups_per_cu\": %d, \"cycles_per_iteration_median_wave\": %.1f, "
+         "\"wall_us_per_iteration\": %.4f, \"cycles_per_cmux_per_cu_at_wall\": %.0f}\n",
+         names[VARIANT], wg_per_cu, cyc[cyc.size() / 2], ms * 1e3 / iters, cyc[cyc.size() / 2] / wg_per_cu);
+  fflush(stdout);
+}
+
 template <int STRUCT, int NW, int NR, int NF, int TAIL, int THREADS>
 static void run(unsigned long long *d_st, double *d_sink, int n_cu) {
   const int iters = 20000;
@@ -152,5 +254,18 @@ int main() {
   run<S_B, 8, 8, 8, 0, 256>(d_st, d_sink, n_cu);
   run<S_T, 8, 8, 8, 4, 256>(d_st, d_sink, n_cu);
   run<S_T, 8, 8, 8, 8, 256>(d_st, d_sink, n_cu);
+  // the kernel's own phase structure (per CMUX iteration: 941 VALU of which 656 f64, 48 stores, 74 loads, 4 barriers)
+  if (getenv("GATE_KERNEL_LIKE") == nullptr || atoi(getenv("GATE_KERNEL_LIKE")) != 0) {
+    run_k<0>(d_st, d_sink, n_cu, 1);
+    run_k<0>(d_st, d_sink, n_cu, 2);
+    run_k<1>(d_st, d_sink, n_cu, 1);
+    run_k<1>(d_st, d_sink, n_cu, 2);
+    run_k<2>(d_st, d_sink, n_cu, 2);
+    run_k<3>(d_st, d_sink, n_cu, 2);
+    run_k<4>(d_st, d_sink, n_cu, 1);
+    run_k<4>(d_st, d_sink, n_cu, 2);
+    run_k<6>(d_st, d_sink, n_cu, 2);
+    run_k<5>(d_st, d_sink, n_cu, 2);
+  }
   return 0;
 }
