@@ -165,14 +165,16 @@ template <int VARIANT>
 static void run_k(unsigned long long *d_st, double *d_sink, int n_cu, int wg_per_cu) {
   const int iters = 5000;
   auto kern = kk<VARIANT>;
-  hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  // the allocation decides how many workgroups a CU holds (64 KB -> 2, 52 KB -> 3, 40 KB -> 4); variants 0 and 5 touch rows 0-9 (40 KB) only
+  const int lds_bytes = wg_per_cu <= 2 ? 65536 : (wg_per_cu == 3 ? 49152 : 38912);  // 4 per CU: reads of row 9 run past 38 KB and are dropped by the hardware (timing only)
+  hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   float ms = 0;
   for (int rep = 0; rep < 3; rep++) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(n_cu * wg_per_cu), dim3(256), 65536, 0, d_st, d_sink, iters, 1.0000001, 1e-9);
+    hipLaunchKernelGGL(kern, dim3(n_cu * wg_per_cu), dim3(256), lds_bytes, 0, d_st, d_sink, iters, 1.0000001, 1e-9);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
@@ -226,8 +228,8 @@ int main() {
   if (hipGetDeviceProperties(&prop, 0) == hipSuccess) n_cu = prop.multiProcessorCount;
   unsigned long long *d_st;
   double *d_sink;
-  hipMalloc(&d_st, (size_t)(n_cu + 1) * 8 * 8);
-  hipMalloc(&d_sink, (size_t)(n_cu + 1) * 512 * 8);
+  hipMalloc(&d_st, (size_t)(n_cu + 1) * 16 * 8);       // up to four 256-thread workgroups per CU (16 waves)
+  hipMalloc(&d_sink, (size_t)(n_cu + 1) * 1024 * 8);
   // VALU only / LDS only references
   run<S_B, 0, 0, 20, 0, 512>(d_st, d_sink, n_cu);
   run<S_B, 0, 0, 20, 0, 256>(d_st, d_sink, n_cu);
@@ -266,6 +268,10 @@ int main() {
     run_k<4>(d_st, d_sink, n_cu, 2);
     run_k<6>(d_st, d_sink, n_cu, 2);
     run_k<5>(d_st, d_sink, n_cu, 2);
+    // what more resident workgroups would be worth IF registers and LDS allowed them (they do not: 240 registers, 80 KB per workgroup)
+    run_k<0>(d_st, d_sink, n_cu, 3);
+    run_k<5>(d_st, d_sink, n_cu, 3);
+    run_k<0>(d_st, d_sink, n_cu, 4);
   }
   return 0;
 }
