@@ -184,12 +184,16 @@ static void run_k(unsigned long long *d_st, double *d_sink, int n_cu, int wg_per
   std::vector<double> cyc;
   for (size_t i = 0; i < st.size(); i++) cyc.push_back((double)st[i] / iters);
   std::sort(cyc.begin(), cyc.end());
+  int resident = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void *>(kern), 256, lds_bytes);
   static const char *names[] = {"as shipped", "exchanges fused into the phase ends", "no LDS operations", "no arithmetic",
                                 "four identical phases, one round trip each", "as shipped + barriers at the wave-local exchanges (six phases)",
                                 "four identical phases, two round trips each"};
   printf("{\"structure\": \"K\", \"variant\": \"%s\", \"workgroups_per_cu\": %d, \"cycles_per_iteration_median_wave\": %.1f, "
-         "\"wall_us_per_iteration\": %.4f, \"cycles_per_cmux_per_cu_at_wall\": %.0f}\n",
-         names[VARIANT], wg_per_cu, cyc[cyc.size() / 2], ms * 1e3 / iters, cyc[cyc.size() / 2] / wg_per_cu);
+         "\"cycles_per_iteration_slowest_wave\": %.1f, \"wall_us_per_iteration\": %.4f, \"cycles_per_cmux_per_cu\": %.0f, "
+         "\"implied_clock_ghz\": %.3f, \"resident_workgroups_per_cu_by_occupancy_api\": %d}\n",
+         names[VARIANT], wg_per_cu, cyc[cyc.size() / 2], cyc.back(), ms * 1e3 / iters, cyc[cyc.size() / 2] / wg_per_cu,
+         cyc[cyc.size() / 2] / (ms * 1e3 / iters) / 1e3, resident);
   fflush(stdout);
 }
 
