@@ -517,6 +517,33 @@ static int launch_br_v5(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+// variant 8: three workgroups per CU (48 KB of LDS, <= 168 registers); N = 2048 only
+template <int BL = 23, int ABL = 0>
+static int launch_br_v8(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  if (BL == 23 && ABL == 0 && ctx->dims.pbs_base_log == 18) return launch_br_v8<18>(ctx, lane, d);
+  constexpr int N = 2048, M = N / 2;
+  const size_t lds = (size_t)2 * M * 16 + (size_t)2 * (M / 2) * 16;  // 48 KB
+  auto kern = dev::blind_rotate_v8_kernel<11, BL, ABL>;
+  // the threads' own accumulator words wait in global memory between two updates: 32 KB per workgroup
+  const size_t need = (size_t)d.v_count * 8 * 256 * 16;
+  if (lane.gen_scratch_bytes < need) {
+    lane.drop(lane.gen_scratch);
+    lane.gen_scratch = nullptr;
+    lane.gen_scratch_bytes = 0;
+    FHES_HIP(hipMalloc(&lane.gen_scratch, need));
+    lane.gen_scratch_bytes = need;
+  }
+  if (ABL != 0 || !(ctx->attr_done & (1u << 26))) {
+    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ABL == 0) ctx->attr_done |= 1u << 26;
+  }
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena, ctx->ct_stride, lane.ks_out, ctx->ks_stride,
+                     ctx->dims.n, ctx->bsk_e, ctx->lut_polys, ctx->twist_inv64, ctx->tw, ctx->psi, ctx->cdpp,
+                     reinterpret_cast<ulonglong2 *>(lane.gen_scratch));
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
 // generic shapes (k <= 3, L <= 3, N = 256 .. 8192): blind_rotate_gen_kernel with its per-workgroup global scratch
 static size_t gen_scratch_per_wg(const Dims &d) {
   return (size_t)(d.k + 1) * d.N * 8 + (size_t)(d.k + 1) * d.L * d.M * 16;
@@ -639,8 +666,16 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   if (!fast_shape(ctx->p) || ctx->br_variant == 12) return launch_br_gen(ctx, lane, d);  // 12: the generic kernel on a 2_2 set (tests)
   int variant = ctx->br_variant;
   if (variant == 0) variant = 7;  // every launch size
-  if (variant != 1 && (variant < 5 || variant > 10 || variant == 8))
-    return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d does not exist (1, 5, 6, 7; 9 and 10 are timing-only ablations)", variant);
+  if (variant != 1 && (variant < 5 || variant > 10) && variant != 13 && variant != 14)
+    return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d does not exist (1, 5, 6, 7, 8; 9, 10, 13 and 14 are timing-only ablations)", variant);
+  if (variant == 8) {
+    if (ctx->dims.N != 2048) return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant 8 is written for N = 2048");
+    return launch_br_v8<>(ctx, lane, d);
+  }
+  if (variant == 13 || variant == 14) {  // timing-only ablations of variant 8 (WRONG results)
+    if (ctx->dims.N != 2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the ablation builds exist for the default set only");
+    return variant == 13 ? launch_br_v8<23, 1>(ctx, lane, d) : launch_br_v8<23, 2>(ctx, lane, d);
+  }
   if (ctx->dims.pbs_base_log != 23 && variant == 1)
     return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant 1 is instantiated for pbs_base_log 23 only");
   if (ctx->dims.N == 2048) {
@@ -1104,11 +1139,11 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  if (v < 0 || (v > 10 && v != 12)) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
-  if (v == 9 || v == 10) {  // timing-only ablations compute WRONG results: a developer has to ask for them by name
+  if (v < 0 || v == 11 || v > 14) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
+  if (v == 9 || v == 10 || v == 13 || v == 14) {  // timing-only ablations compute WRONG results: a developer has to ask for them by name
     const char *e = getenv("FHES_DEV_ABLATIONS");
     if (!e || std::string(e) != "1")
-      return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variants 9 / 10 are timing-only ablations with wrong results (set FHES_DEV_ABLATIONS=1)");
+      return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variants 9 / 10 / 13 / 14 are timing-only ablations with wrong results (set FHES_DEV_ABLATIONS=1)");
   }
   ctx->br_variant = v;
   return FHES_OK;

@@ -1544,6 +1544,331 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
 }
 
 // ------------------------------------------------------------------------------------------
+// K2+K3 (variant 8, round 4): variant 5 on a diet -- THREE workgroups per CU.  The synthetic kernel with variant 5's
+// instruction counts (scripts/micro/lds_valu_gate.hip, structure "K") says what a third resident workgroup is worth: 4.3-4.6 k
+// cycles per CMUX and CU in steady state against 6.4 k with two.  A third workgroup needs <= 168 registers and <= 52 KB of LDS:
+//   * LDS: Y (image of -acc AND the only exchange buffer, 32 KB) | inverse stage tables (8 KB) | forward twiddles (8 KB) = 48 KB.
+//     Without variant 5's second buffer X two more workgroup barriers are needed: Ba "every rotated read of the image is done"
+//     before pass A's output goes into Y, and B4 "the other half has read my spectrum" before the inverse exchanges overwrite
+//     it -- six barriers per iteration (the synthetic: 6 457 against 6 398 cycles at two residents, 4 298 against 4 237 at three);
+//   * registers: own accumulator words (32) + points (32) + GGSW rows (64) are the floor; a pass's twiddles cost four table loads
+//     with the quarter-turn partners derived (16); the lane-pair constants and the untwist factors are requested where the
+//     registers of the previous pass's twiddles have died.
+// Arithmetic, layouts, swizzle, integer tricks: variant 5's, statement by statement (same bits).
+// ------------------------------------------------------------------------------------------
+// The lane-pair stage of the forward transform with HALF the constants (variant 8): the last-stage twiddles of consecutive blocks
+// are quarter turns of each other, t' = (t.im, -t.re) bit for bit, so the constant of point e + 1 follows from the
+// one of point e (e even): with c = (s t.re, t.im), s = +-1 by lane parity, c' = (s c.y, -s c.x), and the sign s moves onto the
+// partner's value (a sign flip of the high dword on odd lanes): fma(s c.y, px, own) == fma(c.y, s px, own) -- the same product,
+// the same rounding, the same bits as fft_fwd_stage0_dpp with all eight constants.
+__device__ __forceinline__ void fft_fwd_stage0_dpp_half(double2 (&x)[8], const double2 (&c)[4], int sign_mask /* q odd: 0x80000000 */) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const double2 ce = c[e >> 1];
+    {
+      const double px = dpp_swap1(x[e].x), py = dpp_swap1(x[e].y);
+      double re = __builtin_fma(ce.x, px, x[e].x);
+      re = __builtin_fma(-ce.y, py, re);
+      double im = __builtin_fma(ce.x, py, x[e].y);
+      im = __builtin_fma(ce.y, px, im);
+      x[e] = make_double2(re, im);
+    }
+    {
+      int lo = __double2loint(x[e + 1].x), hi = __double2hiint(x[e + 1].x);
+      lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+      hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true) ^ sign_mask;
+      const double spx = __hiloint2double(hi, lo);
+      lo = __double2loint(x[e + 1].y), hi = __double2hiint(x[e + 1].y);
+      lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+      hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true) ^ sign_mask;
+      const double spy = __hiloint2double(hi, lo);
+      // c' = (s c.y, -s c.x):  re = fma(c'.x, px, own.x) = fma(c.y, s px, .);  re = fma(-c'.y, py, re) = fma(c.x, s py, re)
+      //                        im = fma(c'.x, py, own.y) = fma(c.y, s py, .);  im = fma(c'.y, px, im) = fma(-c.x, s px, im)
+      double re = __builtin_fma(ce.y, spx, x[e + 1].x);
+      re = __builtin_fma(ce.x, spy, re);
+      double im = __builtin_fma(ce.y, spy, x[e + 1].y);
+      im = __builtin_fma(-ce.x, spx, im);
+      x[e + 1] = make_double2(re, im);
+    }
+  }
+}
+
+typedef double __attribute__((ext_vector_type(2))) fhes_f64x2;
+typedef fhes_f64x2 __attribute__((address_space(3))) *lds_f64x2_ptr;
+// one complex slot at an LDS byte address (ds_read_b128 / ds_write_b128)
+__device__ __forceinline__ double2 lds_get_d2(unsigned a) {
+  const fhes_f64x2 v = *(lds_f64x2_ptr)(uintptr_t)a;
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_put_d2(unsigned a, double2 v) {
+  fhes_f64x2 t;
+  t.x = v.x;
+  t.y = v.y;
+  *(lds_f64x2_ptr)(uintptr_t)a = t;
+}
+
+// ABL: timing-only ablations (WRONG results): 1 = the own words neither stored nor reloaded, 2 = also no key loads
+template <int LOGN, int BL, int ABL = 0>
+__global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 3) void blind_rotate_v8_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
+    int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
+    const double2 *__restrict__ twist_inv /* twist / (M * 2^64): torus_from_f64_pair */, const double2 *__restrict__ tw,
+    const double2 *__restrict__ psi /* forward twiddles [M] */, const double2 *__restrict__ cdpp /* [8][M/8] */,
+    ulonglong2 *__restrict__ own_scratch /* [workgroups][8][256]: the threads' own accumulator words between two updates */) {
+  constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
+  constexpr int NP = (LOGM - 1) / 3;
+  static_assert(LOGM % 3 == 1 && NP == 3, "written for N = 2048 (three 3-bit passes + the lane-pair stage)");
+  static_assert(BL >= 1 && BL <= 31, "single-level digit must fit the high dword");
+  static_assert(TP >= 128, "a wave lies inside one half and the swizzle term is common to a thread's points");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double2 *ybuf = reinterpret_cast<double2 *>(smem_raw);  // [2][M]  image of -acc and exchange buffer
+  double2 *T = ybuf + (size_t)2 * M;                      // [M/2]   inverse stage tables
+  double2 *TF = T + M / 2;                                // [M/2]   forward twiddles psi[0, M/2)
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
+  if (lds0 & (unsigned)(2 * N * 8 - 1)) __builtin_trap();  // the rotated reads OR the block's address into their offsets
+  const int tid = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(tid / TP);  // the half (output polynomial): wave-uniform
+  const int q = tid % TP;
+  const double sgn = (q & 1) ? -1.0 : 1.0;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  auto modswitch_of = [&](uint64_t w) __attribute__((always_inline)) {
+    return (int)((((w >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  };
+  for (int idx = 2 + tid; idx < M / 2; idx += blockDim.x) {
+    const int beta = 31 - __builtin_clz(idx);  // idx = 2^beta + j
+    T[idx] = tw[(idx - (1 << beta)) << (LOGM - 1 - beta)];
+  }
+  for (int idx = tid; idx < M / 2; idx += blockDim.x) TF[idx] = psi[idx];
+  __syncthreads();
+
+  constexpr int LO_A = LOGM - 3, LO_B = LOGM - 6, LO_C = LOGM - 9;
+  double2 wfa[7];  // forward pass A: the same 7 twiddles for every thread (SGPRs)
+#pragma unroll
+  for (int kk = 0; kk < 7; ++kk) wfa[kk] = psi[1 + kk];
+  const double2 wnone[4] = {};
+  const __amdgpu_buffer_rsrc_t rs_twg = __builtin_amdgcn_make_buffer_rsrc((void *)tw, 0, (M / 2) * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g =
+      __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_small * 4 * M * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_cd = __builtin_amdgcn_make_buffer_rsrc((void *)cdpp, 0, M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ti = __builtin_amdgcn_make_buffer_rsrc((void *)twist_inv, 0, M * 16, 0x00020000);
+  const unsigned voff_q = (unsigned)q * 16u;
+  const unsigned voff_g = (unsigned)(r * 8 * TP + q) * 16u;
+  // The own accumulator words (32 registers) are needed twice per iteration only -- when the digits are formed and when the
+  // update is added -- and the LDS image is overwritten in between.  They wait in a per-workgroup global scratch (L2-resident:
+  // 32 KB per workgroup, written once and read once per iteration, coalesced) instead of in registers the third workgroup
+  // does not have: stored at the update, kept in registers across B6 for the next iteration's digits, dropped, and requested
+  // again before B5.
+  const __amdgpu_buffer_rsrc_t rs_own = __builtin_amdgcn_make_buffer_rsrc((void *)(own_scratch + (size_t)blockIdx.x * 8 * 256), 0, 8 * 256 * 16, 0x00020000);
+  const unsigned voff_t = (unsigned)tid * 16u;
+
+  // nacc: NEGATED coefficients p = q + e*TP (lo) and p + M (hi) of polynomial r
+  uint64_t nlo[8], nhi[8];
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - modswitch_of(ks[n_small])) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = fft_point<LOGM, LO_A, 3>(q, e);
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      nlo[e] = (uint64_t)0 - v0;
+      nhi[e] = (uint64_t)0 - v1;
+      reinterpret_cast<uint64_t *>(ybuf + (size_t)r * M)[image_word<LOGM>(p)] = nlo[e];
+      reinterpret_cast<uint64_t *>(ybuf + (size_t)r * M)[image_word<LOGM>(p + M)] = nhi[e];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, make_ulonglong2(nlo[e], nhi[e])),
+                                             rs_own, voff_t, (unsigned)(e * 256 * 16), 0);
+    }
+  }
+  __syncthreads();
+
+  // Byte addresses of this thread's slots in the three pass layouts, fswz spelled out.  Pass A: one base, the points 2 KB apart
+  // (immediate offsets).  Passes B and C: the swizzle XORs the register index e into bank bits that hold thread bits, so the eight
+  // addresses are base ^ constant(e) -- the compiler keeps all of them in registers across the loop (25 with the other half's),
+  // which the third workgroup cannot afford.  The bases are made opaque before every use: one v_xor per access instead.
+  // (Y starts at LDS offset 0 and a half is 16 KB: the XORs below stay inside the half, and bit 14 selects it.)
+  const unsigned yr0 = lds0 + (unsigned)r * (unsigned)(M * 16);
+  const unsigned aA = yr0 + 16u * (unsigned)fswz(q);
+  unsigned aB = yr0 + 16u * (unsigned)(((q >> 4) << 7) | (q & 15));
+  unsigned aC = yr0 + 16u * (unsigned)(((q >> 1) << 4) | (((q >> 1) & 7) << 1) | (q & 1));
+  auto fresh = [](int v) { asm volatile("" : "+v"(v)); return v; };  // a copy the compiler cannot hoist address arithmetic from
+  constexpr uint64_t ROUND = (uint64_t)1 << (63 - BL);
+
+  int a_next = modswitch_of(ks[0]);
+  for (int i = 0; i < n_small; ++i) {
+    const int a = a_next;
+    double2 x[8];
+    {
+      const unsigned sb = ((unsigned)(q - a) << 4) ^ (1u << (LOGM + 5));
+      const unsigned img_base = (unsigned)r * (unsigned)(M * 16) + lds0;
+      const unsigned swz_all = ((sb >> 3) & 0xE0u) | img_base;
+      uint64_t va[8], vb[8];
+      int hmv[8], m0v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned se = sb + (unsigned)(e * TP * 16);
+        hmv[e] = __builtin_amdgcn_sbfe(se, LOGM + 4, 1);
+        m0v[e] = __builtin_amdgcn_sbfe(se, LOGM + 5, 1);
+        const unsigned off0 = ((se & (unsigned)((M - 1) << 4)) ^ swz_all) | ((unsigned)hmv[e] & 8u);
+        va[e] = *(lds_u64_ptr)(uintptr_t)(off0);
+        vb[e] = *(lds_u64_ptr)(uintptr_t)(off0 ^ 8u);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m0 = m0v[e];
+        const int m1 = m0 ^ hmv[e];
+        uint64_t dd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m32 = h == 0 ? m0 : m1;
+          const uint64_t v = h == 0 ? va[e] : vb[e];
+          const uint64_t mm = ((uint64_t)(uint32_t)m32 << 32) | (uint64_t)(uint32_t)m32;
+          const uint64_t kk = ROUND | (uint64_t)(uint32_t)(m32 & 1);
+          dd[h] = add64(add64(v ^ mm, h == 0 ? nlo[e] : nhi[e]), kk);
+        }
+        const double d0 = (double)((int)(uint32_t)(dd[0] >> 32) >> (32 - BL));
+        const double d1 = (double)((int)(uint32_t)(dd[1] >> 32) >> (32 - BL));
+        x[e] = make_double2(d0, d1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t ks_next = ks[i + 1];
+    // the key's two rows in two requests: the second goes out after the first pass, whose butterflies need the registers
+    double2 g0[8], g1[8];
+    const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g0[e] = ABL < 2 ? buf_load_d2(rs_g, voff_g, so + (unsigned)((0 * 16 + e) * TP * 16)) : make_double2(x[e].y, wfa[e & 3].x);
+    double2 w[7];
+    fft_butterflies_reg<true>(x, wfa);
+    a_next = modswitch_of(ks_next);
+    asm volatile("" : "+s"(a_next));
+    __syncthreads();  // Ba: every rotated read of the image is done -- Y may be overwritten
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g1[e] = ABL < 2 ? buf_load_d2(rs_g, voff_g, so + (unsigned)((1 * 16 + e) * TP * 16)) : make_double2(x[e].x, wfa[e & 3].y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds_put_d2(aA + (unsigned)(e * TP * 16), x[e]);
+    load_fwd_twiddles<LOGM, LO_B>(w, fresh(q), TF);
+    __syncthreads();  // B1
+    asm volatile("" : "+v"(aB));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = lds_get_d2(aB ^ (unsigned)(e * 0x120));
+    __builtin_amdgcn_sched_barrier(0);
+    fft_butterflies_reg<true>(x, w);
+    asm volatile("" : "+v"(aB));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds_put_d2(aB ^ (unsigned)(e * 0x120), x[e]);  // B -> C stays inside a wave
+    load_fwd_twiddles<LOGM, LO_C>(w, fresh(q), TF);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" : "+v"(aC));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = lds_get_d2(aC ^ (unsigned)(e << 5));
+    __builtin_amdgcn_sched_barrier(0);
+    fft_butterflies_reg<true>(x, w);
+    {
+      // the lane-pair constants take the registers the pass twiddles have just left: four loads, the odd points' constants derived
+      double2 cd[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cd[e] = buf_load_d2(rs_cd, voff_q, (unsigned)(2 * e * TP * 16));
+      fft_fwd_stage0_dpp_half(x, cd, (q & 1) << 31);
+    }
+    // the spectrum goes into the slots of the pass-C layout: this wave's own region of Y
+    asm volatile("" : "+v"(aC));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds_put_d2(aC ^ (unsigned)(e << 5), x[e]);
+    __syncthreads();  // B3
+    asm volatile("" : "+v"(aC));
+    // the other half's spectrum in two bursts of four reads (variant 5: one of eight; sixteen registers fewer at the kernel's peak)
+    if (r == 0) {
+#pragma unroll
+      for (int hb = 0; hb < 8; hb += 4) {
+        double2 oth[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) oth[e] = lds_get_d2(aC ^ (unsigned)((M * 16) | ((hb + e) << 5)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[hb + e] = ext_mac(x[hb + e], oth[e], g0[hb + e], g1[hb + e]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("; v8: end of form r = 0");
+    } else {
+#pragma unroll
+      for (int hb = 0; hb < 8; hb += 4) {
+        double2 oth[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) oth[e] = lds_get_d2(aC ^ (unsigned)((M * 16) | ((hb + e) << 5)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[hb + e] = ext_mac(oth[e], x[hb + e], g0[hb + e], g1[hb + e]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("; v8: end of form r = 1");
+    }
+    // the first inverse pass's twiddles only now (variant 5: before B3): sixteen registers fewer under the products, the kernel's peak
+    load_pass_twiddles_tab<LOGM, LO_C>(w, fresh(q), T, wnone);
+    fft_stage_bit0_dpp(x, sgn);
+    fft_butterflies_reg<false>(x, w);  // inverse pass C
+    __syncthreads();  // B4: the other half has read my spectrum -- my region of Y may be overwritten
+    asm volatile("" : "+v"(aC));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds_put_d2(aC ^ (unsigned)(e << 5), x[e]);  // C -> B stays inside a wave
+    load_pass_twiddles_tab<LOGM, LO_B>(w, fresh(q), T, wnone);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" : "+v"(aB));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = lds_get_d2(aB ^ (unsigned)(e * 0x120));
+    __builtin_amdgcn_sched_barrier(0);
+    fft_butterflies_reg<false>(x, w);
+    asm volatile("" : "+v"(aB));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds_put_d2(aB ^ (unsigned)(e * 0x120), x[e]);
+    double2 wtop[4] = {};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) wtop[e] = buf_load_d2(rs_twg, voff_q, (unsigned)(e * TP * 16));
+    load_pass_twiddles_tab<LOGM, LO_A>(w, fresh(q), T, wtop);
+    double2 twi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) twi[e] = buf_load_d2(rs_ti, voff_q, (unsigned)(e * TP * 16));
+    double2 own[8];  // the own accumulator words as stored at the previous update (bit patterns)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) own[e] = ABL == 0 ? buf_load_d2(rs_own, voff_t, (unsigned)(e * 256 * 16)) : twi[e];
+    __syncthreads();  // B5
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = lds_get_d2(aA + (unsigned)(e * TP * 16));
+    __builtin_amdgcn_sched_barrier(0);
+    fft_butterflies_reg<false>(x, w);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double2 v = cmul_conj(x[e], make_double2(-twi[e].x, -twi[e].y));
+      nlo[e] = add64(torus_from_f64_pair(v.x), (uint64_t)__double_as_longlong(own[e].x));
+      nhi[e] = add64(torus_from_f64_pair(v.y), (uint64_t)__double_as_longlong(own[e].y));
+      lds_put_d2(aA + (unsigned)(e * TP * 16), make_double2(__longlong_as_double((long long)nlo[e]), __longlong_as_double((long long)nhi[e])));
+      if (ABL == 0)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, make_ulonglong2(nlo[e], nhi[e])),
+                                               rs_own, voff_t, (unsigned)(e * 256 * 16), 0);
+    }
+    __syncthreads();  // B6 (it also waits for the stores above: the words are in memory before they are requested again)
+  }
+
+  // ---- sample extract from the image of -acc: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+  const uint64_t *img = reinterpret_cast<const uint64_t *>(smem_raw);
+  for (int j = tid; j < N; j += blockDim.x) {
+    const int jj = (j == 0) ? 0 : N - j;
+    const uint64_t v = img[image_word<LOGM>(jj)];
+    out[j] = (j == 0) ? (uint64_t)0 - v : v;
+  }
+  if (tid == 0) out[N] = (uint64_t)0 - img[(size_t)2 * M + image_word<LOGM>(0)];
+}
+
+// ------------------------------------------------------------------------------------------
 // K4: multi-bit blind rotate (grouping factor G = 2 or 3) + sample extract.  Same transforms,
 // rounding and FMA chains as the classic kernels, different step:
 //     bundle = G_0 + sum_{c=1}^{2^G-1} G_c * X^{deg_c}      (Fourier domain, c ascending)
