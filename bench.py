@@ -571,7 +571,7 @@ def main():
             "find_wall_ms_single": round(single_ms, 3),
             "pbs_per_s_single_find": round(pbs_per_find / (single_ms * 1e-3), 1),
             "find_wall_ms_single_logdepth": round(log_ms, 3),
-            "logdepth_variant": {"pbs": log_pbs, "levels": log_levels, "note": "opt-in FheString.find(..., logdepth=True): parallel-prefix first-match scan, identical decrypted result"},
+            "logdepth_variant": {"pbs": log_pbs, "levels": log_levels, "note": "opt-in FheString.find(..., logdepth=True): first-match one-hot from prefix counts inside a block (two levels for 64 positions), identical decrypted result"},
             "callers": callers,
             "roofline": None,
             "sharded": None,

@@ -395,7 +395,7 @@ class FheString(_Ct):
         return BooleanBlock(_op(k, "contains", self, s)[0])
 
     def find(self, k, s, logdepth=False):
-        """search.rs:23-28.  logdepth=True selects the opt-in parallel-prefix first-match scan
+        """search.rs:23-28.  logdepth=True selects the opt-in first-match scan by prefix counts
         (same decrypted result, ~14 instead of n+5 dependent levels)."""
         o = _op(k, "find_logdepth" if logdepth else "find", self, s)
         return FheOption(BooleanBlock(o[0]), FheUsize(o[1]))

@@ -113,16 +113,113 @@ struct S {
     }
     return is_lt;
   }
-  // inclusive prefix AND / OR (Sklansky: ceil(log2 n) levels, (n/2) log2 n lookups)
-  std::vector<Blk> prefix_scan(std::vector<Blk> v, bool is_and) {
+  // ---- boolean scans with the prefix COUNTS formed inside one block (round 4) -----------------------------------
+  // A sum of booleans is linear -- free -- and a block holds values up to space - 1, so "is any of the first i set" is ONE
+  // lookup of a prefix count instead of a tree of pairwise ORs.  Split n booleans into m chunks of s:
+  //   level 1:  any_c = [sum of chunk c > 0]
+  //   level 2:  [local count up to i + number of earlier chunks with a hit > 0]            (s + m - 1 <= space - 1)
+  // -- two levels and n + m lookups for n <= 64 at a 16-value space where Sklansky takes six levels and (n/2) log2 n; above
+  // that the chunk flags are scanned recursively (one more level per factor of space - 2).  Sums must also stay under the
+  // noise cap: the plan shrinks its chunks for noisy operands and falls back to Sklansky when nothing fits.
+  struct WidePlan { size_t s = 0, m = 0; bool two_level = false, ok = false; };
+  // (first_set's second-level sum has as many addends as the prefix OR's: the local count stops one short and !v[i] takes its place)
+  WidePlan wide_plan(const std::vector<Blk> &v) const {
+    WidePlan pl;
+    const size_t n = v.size(), top = (size_t)o.b.space() - 1;
+    double nz = 1.0;  // the chunk flags are fresh lookups: one unit each
+    for (const Blk &x : v) {
+      if (x.deg > 1) return pl;
+      nz = std::max(nz, x.noise);
+    }
+    const size_t room = std::min<size_t>(top, (size_t)(o.b.noise_cap() / nz));  // addends of a sum that stay a valid lookup input
+    if (room < 3) return pl;
+    pl.ok = true;
+    for (size_t m = 1; m < room; m++) {  // fewest chunks first
+      const size_t s = (n + m - 1) / m;
+      if (s + (m - 1) <= room) {
+        pl.s = s, pl.m = m, pl.two_level = true;
+        return pl;
+      }
+    }
+    pl.s = room - 1;  // one unit for "an earlier chunk has a hit"
+    pl.m = (n + pl.s - 1) / pl.s;
+    return pl;
+  }
+  Blk sum_of(const std::vector<Blk> &v, size_t lo, size_t hi) {
+    Blk t = o.b.trivial(0);
+    for (size_t i = lo; i < hi; i++) t = o.b.add(t, v[i]);
+    return t;
+  }
+  // per chunk: number of earlier chunks with a hit (two-level plan) or the flag "an earlier chunk has a hit" (recursive plan)
+  std::vector<Blk> hits_before(const std::vector<Blk> &v, const WidePlan &pl) {
+    std::vector<Blk> anys;
+    for (size_t c = 0; c < pl.m; c++) {
+      const size_t lo = c * pl.s, hi = std::min(v.size(), lo + pl.s);
+      anys.push_back(hi - lo == 1 ? v[lo] : o.b.pbs(sum_of(v, lo, hi), [](uint64_t x) { return x > 0 ? 1 : 0; }));
+    }
+    std::vector<Blk> before(pl.m, o.b.trivial(0));
+    if (pl.two_level) {
+      for (size_t c = 1; c < pl.m; c++) before[c] = o.b.add(before[c - 1], anys[c - 1]);
+    } else {
+      std::vector<Blk> incl = prefix_or_wide(anys);
+      for (size_t c = 1; c < pl.m; c++) before[c] = incl[c - 1];
+    }
+    return before;
+  }
+  std::vector<Blk> prefix_or_sklansky(std::vector<Blk> v) {
     const size_t n = v.size();
     for (size_t span = 1; span < n; span <<= 1)
       for (size_t i = 0; i < n; i++)
-        if ((i / span) & 1) {
-          const Blk &left = v[(i / span) * span - 1];
-          v[i] = is_and ? o.bitand_(v[i], left) : o.bitor_(v[i], left);
-        }
+        if ((i / span) & 1) v[i] = o.bitor_(v[i], v[(i / span) * span - 1]);
     return v;
+  }
+  // inclusive prefix OR
+  std::vector<Blk> prefix_or_wide(const std::vector<Blk> &v) {
+    const size_t n = v.size();
+    if (n <= 1) return v;
+    const WidePlan pl = wide_plan(v);
+    if (!pl.ok) return prefix_or_sklansky(v);
+    const std::vector<Blk> before = hits_before(v, pl);
+    std::vector<Blk> out(n);
+    for (size_t c = 0; c < pl.m; c++) {
+      const size_t lo = c * pl.s, hi = std::min(n, lo + pl.s);
+      Blk t = before[c];
+      for (size_t i = lo; i < hi; i++) {
+        t = o.b.add(t, v[i]);
+        out[i] = (i == 0) ? v[0] : o.b.pbs(t, [](uint64_t x) { return x > 0 ? 1 : 0; });
+      }
+    }
+    return out;
+  }
+  // one-hot of the first set boolean: first[i] = v[i] & no earlier one set = [hits before + local count before i + !v[i] == 0]
+  std::vector<Blk> first_set_wide(const std::vector<Blk> &v) {
+    const size_t n = v.size();
+    if (n <= 1) return v;
+    const WidePlan pl = wide_plan(v);
+    if (!pl.ok) {
+      std::vector<Blk> pre = prefix_or_sklansky(v), out(n);
+      for (size_t i = 0; i < n; i++) out[i] = i == 0 ? v[0] : o.bitand_(v[i], o.bitnot_(pre[i - 1]));
+      return out;
+    }
+    const std::vector<Blk> before = hits_before(v, pl);
+    std::vector<Blk> out(n);
+    for (size_t c = 0; c < pl.m; c++) {
+      const size_t lo = c * pl.s, hi = std::min(n, lo + pl.s);
+      Blk t = before[c];
+      for (size_t i = lo; i < hi; i++) {
+        out[i] = (i == 0) ? v[0] : o.b.pbs(o.b.add(t, o.bitnot_(v[i])), [](uint64_t x) { return x == 0 ? 1 : 0; });
+        t = o.b.add(t, v[i]);
+      }
+    }
+    return out;
+  }
+  // inclusive prefix AND / OR; AND by De Morgan (negation is linear)
+  std::vector<Blk> prefix_scan(std::vector<Blk> v, bool is_and) {
+    if (!is_and) return prefix_or_wide(v);
+    for (Blk &x : v) x = o.bitnot_(x);
+    std::vector<Blk> r = prefix_or_wide(v);
+    for (Blk &x : r) x = o.bitnot_(x);
+    return r;
   }
   // compare.rs:89-96 without the carried state: is_eq before char i is the AND of eq_0..eq_{i-1};
   // the terms lt_i & is_eq_i are mutually exclusive (only the first differing char can set one)
@@ -183,23 +280,18 @@ struct S {
   }
 
   // Opt-in alternative to the serial scan of mod.rs:341-349 with identical decrypted results:
-  //   b_i      = found[0] | ... | found[i-1]          (Sklansky parallel prefix, ceil(log2 n) levels)
-  //   first[i] = found[i] & !b_i                       (one-hot)
+  //   first[i] = found[i] & !(found[0] | ... | found[i-1])     (one-hot; first_set_wide: prefix counts inside a block, two levels for n <= 64)
   //   index    = sum_i first[i] * i                    (mutually exclusive terms -> no carries)
-  // Depth ~log2(n) + 3 instead of n.  The faithful circuit stays the default.
+  // Depth 2 + 2 (n <= 64 at a 16-value space) instead of n.  The faithful circuit stays the default.
   Option index_of_logdepth(const std::vector<Blk> &v0, bool reverse) {
     std::vector<Blk> v = v0;
     const size_t n = v.size();
     if (reverse) std::reverse(v.begin(), v.end());
     if (n == 0) return {o.trivial_bool(false), usize(0)};
-    std::vector<Blk> pre = prefix_scan(v, false);  // inclusive prefix OR
+    std::vector<Blk> first = first_set_wide(v);  // one-hot
     std::vector<Radix> terms;
-    for (size_t i = 0; i < n; i++) {
-      Blk first = i == 0 ? v[0] : o.bitand_(v[i], o.bitnot_(pre[i - 1]));
-      const size_t idx = reverse ? n - 1 - i : i;
-      terms.push_back(scalar_if_then_else_zero(first, idx));
-    }
-    return {pre[n - 1], sum_exclusive(terms, Bu)};
+    for (size_t i = 0; i < n; i++) terms.push_back(scalar_if_then_else_zero(first[i], reverse ? n - 1 - i : i));
+    return {any(v), sum_exclusive(terms, Bu)};
   }
 
   // mod.rs:132-156
