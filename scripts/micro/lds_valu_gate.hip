@@ -105,6 +105,11 @@ template <int N> __device__ __forceinline__ void fma_blocks(double (&x)[8], doub
 template <int N> __device__ __forceinline__ void int_blocks(unsigned (&y)[8], unsigned yk) {
   if constexpr (N > 0) { INT8; int_blocks<N - 1>(y, yk); }
 }
+// eight half-wave / row exchanges of register pairs (gfx950: v_permlane32_swap, v_permlane16_swap; two wait states after a VALU write of an operand)
+#define SWAP8 asm volatile("s_nop 1\n v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n s_nop 1\n v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]))
+template <int N> __device__ __forceinline__ void swap_blocks(unsigned (&y)[8]) {
+  if constexpr (N > 0) { SWAP8; swap_blocks<N - 1>(y); }
+}
 template <int VARIANT>
 __global__ __launch_bounds__(256) void kk(unsigned long long *stamps, double *sink, int iters, double a, double b) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -124,11 +129,20 @@ __global__ __launch_bounds__(256) void kk(unsigned long long *stamps, double *si
 #define K_WAIT do { if constexpr (LDS) { WAIT0; } } while (0)
 #define K_F(n) do { if constexpr (ALU) { fma_blocks<n>(x, a, b); } } while (0)
 #define K_I(n) do { if constexpr (ALU) { int_blocks<n>(y, yk); } } while (0)
+#define K_S(n) do { if constexpr (VARIANT != 8) { swap_blocks<n>(y); } } while (0)
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
   for (int it = 0; it < iters; it++) {
-    if constexpr (VARIANT == 4) {
+    if constexpr (VARIANT == 7 || VARIANT == 8) {
+      // a DIFFERENT decomposition of the same transforms: register bits exchanged with lane bits 4 and 5 by v_permlane16/32_swap (16 swaps per
+      // bit and 8 points), so the passes are 3 | swap | 2 | LDS | 3 | swap | 2 and back: one LDS exchange per direction instead of two, no
+      // wave-local LDS round trip, no DPP lane-pair stage.  32 stores, ~69 loads, the same f64 count, 128 swaps - 64 DPP moves.  8: without the swaps
+      K_RD(10); K_RD(10); K_RD(3); K_WAIT; K_F(11); K_I(20); K_S(4); K_F(6); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(8); K_RD(8); K_WAIT; K_F(9); K_S(4); K_F(6); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(8); K_RD(8); K_WAIT; K_F(8); K_F(5); K_S(4); K_F(9); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(8); K_RD(6); K_WAIT; K_F(6); K_S(4); K_F(26); K_I(6); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+    } else if constexpr (VARIANT == 4) {
 #pragma unroll
       for (int ph = 0; ph < 4; ph++) {
         K_RD(10); K_RD(9); K_WAIT; K_F(21); K_I(8); K_WR(8); K_WR(4); K_WAIT; __builtin_amdgcn_s_barrier();
@@ -188,7 +202,8 @@ static void run_k(unsigned long long *d_st, double *d_sink, int n_cu, int wg_per
   hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void *>(kern), 256, lds_bytes);
   static const char *names[] = {"as shipped", "exchanges fused into the phase ends", "no LDS operations", "no arithmetic",
                                 "four identical phases, one round trip each", "as shipped + barriers at the wave-local exchanges (six phases)",
-                                "four identical phases, two round trips each"};
+                                "four identical phases, two round trips each",
+                                "permlane decomposition: 3 | swap | 2 | LDS | 3 | swap | 2 (32 stores, 69 loads, 128 swaps)", "permlane decomposition without the swaps"};
   printf("{\"structure\": \"K\", \"variant\": \"%s\", \"workgroups_per_cu\": %d, \"cycles_per_iteration_median_wave\": %.1f, "
          "\"cycles_per_iteration_slowest_wave\": %.1f, \"wall_us_per_iteration\": %.4f, \"cycles_per_cmux_per_cu\": %.0f, "
          "\"implied_clock_ghz\": %.3f, \"resident_workgroups_per_cu_by_occupancy_api\": %d}\n",
@@ -264,6 +279,10 @@ int main() {
   if (getenv("GATE_KERNEL_LIKE") == nullptr || atoi(getenv("GATE_KERNEL_LIKE")) != 0) {
     run_k<0>(d_st, d_sink, n_cu, 1);
     run_k<0>(d_st, d_sink, n_cu, 2);
+    run_k<7>(d_st, d_sink, n_cu, 1);
+    run_k<7>(d_st, d_sink, n_cu, 2);
+    run_k<8>(d_st, d_sink, n_cu, 2);
+    if (getenv("GATE_ONLY_PERMLANE")) return 0;
     run_k<1>(d_st, d_sink, n_cu, 1);
     run_k<1>(d_st, d_sink, n_cu, 2);
     run_k<2>(d_st, d_sink, n_cu, 2);
