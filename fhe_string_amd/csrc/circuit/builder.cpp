@@ -311,6 +311,82 @@ static void tile_wide_levels(Program &prog, size_t max_nodes) {
   prog.level_ptr = lp;
 }
 
+// device rounds of one launch of c bootstraps, in units of a one-per-CU round (2.96 ms on the default set; a two-per-CU round: 4.0 ms)
+static double launch_cost(size_t c) {
+  constexpr size_t kResident = 512, kOnePerCu = 256;
+  if (c == 0) return 0;
+  const size_t full = c / kResident, rem = c % kResident;
+  return 1.35 * (double)full + (rem == 0 ? 0.0 : (rem <= kOnePerCu ? 1.0 : 1.35));
+}
+
+void Builder::pack_levels(const std::vector<char> &live) {
+  const int32_t nn = (int32_t)nodes_.size();
+  int32_t depth = 0;
+  for (int32_t j = 0; j < nn; j++)
+    if (live[j] && nodes_[j].lut >= 0) depth = std::max(depth, nodes_[j].level);
+  if (depth < 2) return;
+  // successors and latest levels (a linear output node constrains nothing: it runs after the last level)
+  std::vector<std::vector<int32_t>> succ(nn);
+  std::vector<int32_t> npred(nn, 0), alap(nn, depth);
+  for (int32_t j = 0; j < nn; j++) {
+    if (!live[j] || nodes_[j].lut < 0) continue;
+    for (const auto &t : nodes_[j].terms)
+      if (t.slot >= n_inputs_) {
+        succ[t.slot - n_inputs_].push_back(j);
+        npred[j]++;
+      }
+  }
+  for (int32_t j = nn - 1; j >= 0; j--) {  // nodes_ is in creation order: consumers come after producers
+    if (!live[j] || nodes_[j].lut < 0) continue;
+    for (int32_t c : succ[j]) alap[j] = std::min(alap[j], alap[c] - 1);
+    if (alap[j] < nodes_[j].level) throw std::logic_error("pack_levels: latest level before earliest");
+  }
+  std::vector<size_t> asap_count(depth + 1, 0);
+  for (int32_t j = 0; j < nn; j++)
+    if (live[j] && nodes_[j].lut >= 0) asap_count[nodes_[j].level]++;
+  double asap_cost = 0;
+  for (int32_t l = 1; l <= depth; l++) asap_cost += launch_cost(asap_count[l]);
+
+  // policy 0: trim a level of >= 512 runnable nodes to whole rounds; policy 1: also trim 257..511 to one one-per-CU round
+  const std::vector<int32_t> npred0 = npred;
+  auto schedule = [&](int policy, std::vector<int32_t> &packed) {
+    npred = npred0;
+    packed.assign(nn, 0);
+    std::vector<int32_t> ready;
+    for (int32_t j = 0; j < nn; j++)
+      if (live[j] && nodes_[j].lut >= 0 && npred[j] == 0) ready.push_back(j);
+    double cost = 0;
+    for (int32_t l = 1; l <= depth; l++) {
+      // least slack first; creation order breaks ties (keeps the schedule deterministic)
+      std::stable_sort(ready.begin(), ready.end(), [&](int32_t a, int32_t b) { return alap[a] < alap[b]; });
+      size_t must = 0;
+      while (must < ready.size() && alap[ready[must]] <= l) must++;
+      size_t take = ready.size();
+      if (take >= 512) take = std::max(must, take / 512 * 512);
+      else if (policy == 1 && take > 256) take = std::max<size_t>(must, 256);
+      std::vector<int32_t> next(ready.begin() + take, ready.end());
+      for (size_t i = 0; i < take; i++) packed[ready[i]] = l;
+      for (size_t i = 0; i < take; i++)
+        for (int32_t c : succ[ready[i]])
+          if (--npred[c] == 0) next.push_back(c);  // runnable from the next level on
+      cost += launch_cost(take);
+      ready.swap(next);
+    }
+    if (!ready.empty()) throw std::logic_error("pack_levels: nodes left after the last level");
+    return cost;
+  };
+  std::vector<int32_t> packed, packed1;
+  double packed_cost = schedule(0, packed);
+  const double cost1 = schedule(1, packed1);
+  if (cost1 + 1e-9 < packed_cost) {
+    packed_cost = cost1;
+    packed.swap(packed1);
+  }
+  if (packed_cost + 1e-9 >= asap_cost) return;
+  for (int32_t j = 0; j < nn; j++)
+    if (live[j] && nodes_[j].lut >= 0) nodes_[j].level = packed[j];
+}
+
 Program Builder::finish(const std::vector<Blk> &outputs, const std::string &name) {
   // 1. materialise outputs.  Results cross the program boundary as CLEAN blocks, like the results
   // of tfhe-rs's default operations: noise of one bootstrap, degree below the message modulus
@@ -349,6 +425,12 @@ Program Builder::finish(const std::vector<Blk> &outputs, const std::string &name
     for (const auto &t : nodes_[j].terms)
       if (t.slot >= n_inputs_ && !live[t.slot - n_inputs_]) stack.push_back(t.slot - n_inputs_);
   }
+  // 2b. launch packing (round 4).  A level of c bootstraps runs in ceil(c / 512) rounds on the device (256 CUs x 2 resident
+  // workgroups; a last round of <= 256 runs one per CU and is shorter), so a level of 600 costs two rounds where 512 now and 88
+  // with the next level may cost one.  Nodes with slack -- not on a longest path -- may run later: list scheduling by latest
+  // start, a level takes everything that must run now and fills up to a whole number of rounds with the least slack first.
+  // Same nodes, same arithmetic, same depth; kept only when the round model says it is cheaper.
+  pack_levels(live);
   // 3. order by level (stable), renumber slots
   std::vector<int32_t> order;
   for (int32_t j = 0; j < (int32_t)nodes_.size(); j++)

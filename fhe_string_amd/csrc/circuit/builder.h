@@ -94,6 +94,7 @@ class Builder {
   Blk tame(const Blk &a, int64_t coef);
 
   Program finish(const std::vector<Blk> &outputs, const std::string &name);
+  void pack_levels(const std::vector<char> &live);  // launch packing by slack (builder.cpp)
 
   // largest input variance of a lookup, in units of one fresh PBS output:
   // 256 for the classic set (sigma_f = 2^49), 34 for the multi-bit sets (sigma_f = 2^50.6)
