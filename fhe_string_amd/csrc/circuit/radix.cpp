@@ -120,7 +120,34 @@ Blk Ops::any_true(std::vector<Blk> v) {
 }
 
 // ---- comparisons -----------------------------------------------------------------------------
-Blk Ops::eq(const Radix &x, const Radix &y) {
+Blk Ops::eq(const Radix &x, const Radix &y) { return all_true(eq_parts(x, y)); }
+
+// (AND of parts) OR c as ONE lookup of parts_0 + ... + parts_{k-1} + k * c >= k (a threshold function of booleans); the
+// pairwise form -- all_true, then a bivariate OR -- when the sum does not fit the block or the noise cap
+Blk Ops::all_or(const std::vector<Blk> &parts, const Blk &c) {
+  std::vector<Blk> w;
+  for (const Blk &x : parts) {
+    if (x.deg > 1) throw std::logic_error("all_or: operand is not a boolean");
+    if (x.trivial()) {
+      if (!x.cst) return c;
+      continue;
+    }
+    w.push_back(x);
+  }
+  if (c.deg > 1) throw std::logic_error("all_or: operand is not a boolean");
+  if (w.empty()) return b.trivial(1);
+  if (c.trivial()) return c.cst ? b.trivial(1) : all_true(w);
+  const uint64_t k = w.size();
+  double noise = (double)(k * k) * c.noise;
+  for (const Blk &x : w) noise += x.noise;
+  if (2 * k >= (uint64_t)b.space() || noise > b.noise_cap()) return bitor_(all_true(w), c);
+  Blk s = b.scale(c, (int64_t)k);
+  for (const Blk &x : w) s = b.add(s, x);
+  return b.pbs(s, [k](uint64_t v) { return v >= k ? 1 : 0; });
+}
+
+// the per-pair equality flags of eq (their AND is the result)
+std::vector<Blk> Ops::eq_parts(const Radix &x, const Radix &y) {
   if (x.size() != y.size()) throw std::logic_error("eq: operand sizes differ");
   // Pack block pairs (lo + M*hi, a 4-bit value) and look up [px - py == 0] on the signed
   // difference: for a negative difference the negacyclic lookup returns -f(16 + d) = 0, so one
@@ -147,7 +174,7 @@ Blk Ops::eq(const Radix &x, const Radix &y) {
       e.back().deg = 1;
     }
   }
-  return all_true(e);
+  return e;
 }
 
 // The signed difference of two packed pairs is one lookup input: if it would carry more than the
@@ -192,6 +219,30 @@ Blk Ops::scalar_eq(const Radix &x, uint64_t c) {
     e.push_back(b.pbs(pairs[j], [cj](uint64_t v) { return v == cj ? 1 : 0; }));
   }
   return all_true(e);
+}
+
+// [x == 0] as a lookup of the plain SUM of the blocks (zero iff every block is zero): one bootstrap for as many blocks as the sum
+// of their degrees fits a block -- a 4-block character in one instead of two packed lookups and an AND (opt-in forms)
+Blk Ops::is_zero(const Radix &x) {
+  std::vector<Blk> flags;
+  Blk s = b.trivial(0);
+  bool open = false;
+  for (const Blk &blk : x) {
+    if (blk.trivial()) {
+      if (blk.cst != 0) return b.trivial(0);
+      continue;
+    }
+    if (open && (s.deg + blk.deg >= (uint32_t)b.space() || s.noise + blk.noise > b.noise_cap())) {
+      flags.push_back(b.pbs(s, [](uint64_t v) { return v == 0 ? 1 : 0; }));
+      s = b.trivial(0);
+      open = false;
+    }
+    s = b.add(s, blk);
+    open = true;
+  }
+  if (open) flags.push_back(b.pbs(s, [](uint64_t v) { return v == 0 ? 1 : 0; }));
+  if (flags.empty()) return b.trivial(1);
+  return all_true(flags);
 }
 
 Blk Ops::scalar_ne(const Radix &x, uint64_t c) {

@@ -31,8 +31,11 @@ class Ops {
 
   // ---- comparisons ----
   Blk eq(const Radix &x, const Radix &y);                  // eq_parallelized
+  std::vector<Blk> eq_parts(const Radix &x, const Radix &y);  // the flags whose AND is eq (one per packed block pair)
+  Blk all_or(const std::vector<Blk> &parts, const Blk &c);    // (AND of parts) OR c in one lookup (opt-in forms)
   Blk scalar_eq(const Radix &x, uint64_t c);               // scalar_eq_parallelized
   Blk scalar_ne(const Radix &x, uint64_t c);               // scalar_ne_parallelized
+  Blk is_zero(const Radix &x);                             // scalar_eq(x, 0) as one lookup of the sum of the blocks (opt-in forms)
   Blk cmp(const Radix &x, const Radix &y, Cmp op);         // lt/le/gt/ge_parallelized
   Blk scalar_cmp(const Radix &x, uint64_t c, Cmp op);      // scalar_{lt,le,gt,ge}_parallelized
 

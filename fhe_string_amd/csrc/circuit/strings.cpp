@@ -75,7 +75,7 @@ struct S {
     return r;
   }
   // compare.rs:15-17
-  Blk is_empty(const Str &s) { return o.scalar_eq(s[0], 0); }
+  Blk is_empty(const Str &s) { return fast ? o.is_zero(s[0]) : o.scalar_eq(s[0], 0); }
 
   // compare.rs:21-45
   Blk eq(const Str &a, const Str &s) {
@@ -238,8 +238,12 @@ struct S {
     Str x = substr_clear(a, i, max_len(a));
     std::vector<Blk> v;
     for (size_t t = 0; t < std::min(x.size(), s.size()); t++) {
-      Blk e = o.eq(x[t], s[t]);
+      if (fast) {  // opt-in forms: eq | is_term as one threshold lookup of the pair flags, is_term as one lookup of the block sum
+        v.push_back(o.all_or(o.eq_parts(x[t], s[t]), o.is_zero(s[t])));  // (same boolean; two bootstraps and two levels less)
+        continue;
+      }
       Blk is_term = o.scalar_eq(s[t], 0);
+      Blk e = o.eq(x[t], s[t]);
       v.push_back(o.bitor_(e, is_term));
     }
     if (max_len(x) < max_len(s)) v.push_back(is_empty(substr_clear(s, max_len(x), max_len(s))));
@@ -297,6 +301,14 @@ struct S {
   // mod.rs:132-156
   Radix len(const Str &s) {
     std::vector<Radix> v;
+    if (fast) {  // opt-in forms: one zero flag per character (a lookup of its block sum), the AND as [z_i + !z_{i-1} == 2]: 2 instead of 7 bootstraps per position
+      std::vector<Blk> z;
+      for (const Radix &c : s) z.push_back(o.is_zero(c));
+      for (size_t i = 1; i < s.size(); i++) {
+        Blk bb = o.all_true({o.bitnot_(z[i - 1]), z[i]});
+        v.push_back(if_then_else_zero(bb, usize(i)));
+      }
+    } else
     for (size_t i = 1; i < s.size(); i++) {
       Blk prev_ne_0 = o.scalar_ne(s[i - 1], 0);
       Blk cur_eq_0 = o.scalar_eq(s[i], 0);
