@@ -448,12 +448,12 @@ def main():
                                 en_i = rad(v[n_sl * (1 + bu_case) + i * bu_case:n_sl * (1 + bu_case) + (i + 1) * bu_case])
                                 val.append(s_text[st_i:en_i] if st_i <= en_i <= len(s_text) else "")
                     else:
-                        val = bool(v[0] & 1) if op == "contains" else (sum(int(v[1 + k] & 3) << (2 * k) for k in range(bu_case)) if v[0] & 1 else -1)
+                        val = bool(v[0] & 1) if op.startswith("contains") else (sum(int(v[1 + k] & 3) << (2 * k) for k in range(bu_case)) if v[0] & 1 else -1)
                     if best is None or d_s < best[0]:
                         best = (d_s, int(st_s.pbs_count))
                 check(lib.fhes_arena_free(ctx, ha, len(a_blk)))
                 check(lib.fhes_arena_free(ctx, hb, len(p_blk)))
-                want = s_text.split(s_pat) if op.startswith("split") else ((s_pat in s_text) if op == "contains" else s_text.find(s_pat))
+                want = s_text.split(s_pat) if op.startswith("split") else ((s_pat in s_text) if op.startswith("contains") else s_text.find(s_pat))
                 return {"op": name, "wall_ms": round(best[0] * 1e3, 3), "pbs_this_rank": best[1], "result_ok": bool(val == want)}
 
             rng4 = np.random.default_rng(0xF4E50004)
@@ -466,7 +466,10 @@ def main():
             cases = [sharded_case("config 2: find, 64-char input / 4-char pattern", "find", text, None, pat, 4, 3),
                      sharded_case("config 4: contains, 1000 chars padded to 1024 / 8-char pattern", "contains", s4, 1024, s4[700:708], 6, 2),
                      sharded_case("config 3: split, 256-char input / 1-char separator (log-depth forms: find_all sharded, the scans and the barrel shifter replicated)",
-                                  "split_logdepth", s3, None, ",", 5, 2)]
+                                  "split_logdepth", s3, None, ",", 5, 2),
+                     # the same operations with the key's opt-in forms (identical decrypted results)
+                     sharded_case("config 2 with the opt-in forms (find_logdepth)", "find_logdepth", text, None, pat, 4, 3),
+                     sharded_case("config 4 with the opt-in forms (contains_logdepth)", "contains_logdepth", s4, 1024, s4[700:708], 6, 2)]
             if os.environ.get("FHES_BENCH_SHARDED_FAITHFUL_SPLIT") == "1":   # ~8 s per repetition: thousands of dependent levels
                 cases.append(sharded_case("config 3: split, faithful circuits (find_all AND the element_at_bool grid sharded; serial scans replicated)", "split", s3, None, ",", 5, 1))
             sharded = {"world": world_size, "transport": "host callbacks over gloo (rehearsal)" if (dist and rehearsal) else "RCCL (ncclAllGather on arena rows)",

@@ -64,14 +64,15 @@ def test_config2_eq_and_contains_blocks(libs):
         assert got == want, (op, b)
 
 
-def test_config4_contains_blocks(libs):
+@pytest.mark.parametrize("form", ["", "_logdepth"])
+def test_config4_contains_blocks(form, libs):
     w = world("default", l=1024)
     bu = num_blocks_usize(1024)
     rng = np.random.default_rng(0xF4E50004)
     s = "".join(chr(c) for c in rng.integers(0x20, 0x7F, size=1000))
     for pat, expect in ((s[700:708], 1), ("\x7f" * 8, 0)):
         want, _ = sc.run_plain("contains", [s, pat], [1024, None], bu)
-        got, _ = device_blocks(w, "contains", [s, pat], [1024, None], bu)
+        got, _ = device_blocks(w, "contains" + form, [s, pat], [1024, None], bu)
         assert got == want == [expect]
 
 
