@@ -371,18 +371,56 @@ static Blk select_block(Builder &b, const Blk &c, const Blk &x, bool when) {
   return b.bivar(c, x, sh, [when](uint64_t cb, uint64_t xv) { return ((cb != 0) == when) ? xv : 0; });
 }
 
+// c ? t : f for two digit blocks (values below the message modulus M) as ONE lookup (round 4).  With u the operand that is looked up and
+// v the one that passes through, w = u - v + (M - 1) lies in [0, 2M - 2] and the lookup g(b, w) = b ? w : M - 1 on b + 2 w gives
+// v + g - (M - 1) = v + b (u - v): the result is v plus one fresh block.  The less noisy operand passes through (the condition is negated
+// for it, which is linear), so a value carried along a chain of selections against fresh operands stays at two units; an operand is
+// re-bootstrapped first when 4 (n_u + n_v) + n_c would pass the cap.  Sets whose space is below 4M - 2 (1_1) take two gated lookups.
+bool Ops::select_fits() const { return 4 * (M - 1) + 1 <= b.space() - 1 && b.noise_cap() >= 9.0; }
+Blk Ops::select(const Blk &c, const Blk &t, const Blk &f, bool may_refresh) {
+  if (c.deg > 1) throw std::logic_error("select: condition is not a boolean");
+  if (c.trivial()) return c.cst ? t : f;
+  if (same_value(t, f)) return t;
+  const int64_t M1 = M - 1;
+  if (t.trivial() && f.trivial()) {  // f + (t - f) c, written with non-negative factors
+    Blk r = b.add(b.scale(b.not_bool(c), f.cst), b.scale(c, t.cst));
+    r.deg = (uint32_t)std::max(t.cst, f.cst);
+    return r;
+  }
+  // inside a serial chain a refresh is a dependent level of its own: callers that are latency-bound (if_then_else) take the two gated
+  // lookups instead when the operands do not fit as they are
+  const bool fits_as_is = t.deg <= (uint32_t)M1 && f.deg <= (uint32_t)M1 && 4.0 * (t.noise + f.noise) + c.noise <= b.noise_cap();
+  if (!select_fits() || (!may_refresh && !fits_as_is)) {
+    Blk a = select_block(b, c, t, true), bb = select_block(b, c, f, false);
+    Blk r = b.add(a, bb);
+    r.deg = std::max(a.deg, bb.deg);  // the two addends are never non-zero together
+    return r;
+  }
+  const bool t_passes = t.noise <= f.noise;  // trivial operands carry no noise
+  Blk u = t_passes ? f : t, v = t_passes ? t : f;
+  const Blk bit = t_passes ? b.not_bool(c) : c;
+  if (u.deg > (uint32_t)M1) u = b.clean(u);
+  if (v.deg > (uint32_t)M1) v = b.clean(v);
+  for (int guard = 0; guard < 2 && 4.0 * (u.noise + v.noise) + bit.noise > b.noise_cap(); guard++) {
+    if (!u.trivial() && (v.trivial() || u.noise >= v.noise)) u = b.clean(u);
+    else v = b.clean(v);
+  }
+  if (4.0 * (u.noise + v.noise) + bit.noise > b.noise_cap()) throw std::logic_error("select: operands too noisy for this parameter set");
+  Blk w = b.add_const(b.sub_raw(u, v), M1);
+  w.deg = (uint32_t)(2 * M1);
+  const Blk in = b.add(b.scale(w, 2), bit);
+  const Blk g = b.pbs(in, [M1](uint64_t x) { return (x & 1) ? (x >> 1) : (uint64_t)M1; });
+  Blk r = b.add_const(b.add(v, g), -M1);
+  r.deg = std::max(u.deg, v.deg);
+  return r;
+}
+
 Radix Ops::if_then_else(const Blk &c, const Radix &t, const Radix &f) {
   if (t.size() != f.size()) throw std::logic_error("if_then_else: operand sizes differ");
   if (c.deg > 1) throw std::logic_error("if_then_else: condition is not a boolean");
   if (c.trivial()) return c.cst ? t : f;
   Radix out;
-  for (size_t i = 0; i < t.size(); i++) {
-    if (same_value(t[i], f[i])) { out.push_back(t[i]); continue; }
-    Blk a = select_block(b, c, t[i], true), bb = select_block(b, c, f[i], false);
-    Blk r = b.add(a, bb);
-    r.deg = std::max(a.deg, bb.deg);  // the two addends are never non-zero together
-    out.push_back(r);
-  }
+  for (size_t i = 0; i < t.size(); i++) out.push_back(select(c, t[i], f[i], /*may_refresh=*/false));
   return out;
 }
 

@@ -41,6 +41,8 @@ class Ops {
 
   // ---- selection ----
   Radix if_then_else(const Blk &c, const Radix &t, const Radix &f);  // if_then_else_parallelized
+  Blk select(const Blk &c, const Blk &t, const Blk &f, bool may_refresh = true);  // c ? t : f for digit blocks: one lookup (radix.cpp)
+  bool select_fits() const;
   Radix zero_unless(const Blk &c, const Radix &x);          // bool-radix * radix (logic.rs:13-16)
 
   // ---- arithmetic (outputs have clean degree, carries propagated) ----

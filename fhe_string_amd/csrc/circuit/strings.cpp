@@ -583,37 +583,9 @@ struct S {
 
   // out[i] = a[(i + index) mod T] (left) or a[(i - index) mod T] (right), a zero-extended to T positions,
   // for i < n_out; elements are radixes of any width (chars, booleans)
-  // b ? u : v for two digit blocks (values below the message modulus M) as ONE lookup (round 4): with w = u - v + (M - 1) in [0, 2M - 2],
-  // the lookup g(b, w) = b ? w : M - 1 on b + 2 w gives v + g - (M - 1) = v + b (u - v).  The result is v plus one fresh block, so its
-  // noise grows by one unit per selection; an operand is re-bootstrapped first when 4 (n_u + n_v) + n_b would pass the cap.
-  bool select_fits() const { return 4 * (o.M - 1) + 1 <= o.b.space() - 1 && o.b.noise_cap() >= 9.0; }
-  Blk select_digit(const Blk &bit, Blk u, Blk v) {
-    Builder &b = o.b;
-    const int64_t M1 = o.M - 1;
-    if (u.terms == v.terms && u.cst == v.cst) return v;
-    if (u.trivial() && v.trivial()) {  // v + (u - v) b, written with non-negative factors
-      Blk r = b.add(b.scale(b.not_bool(bit), v.cst), b.scale(bit, u.cst));
-      r.deg = (uint32_t)std::max(u.cst, v.cst);
-      return r;
-    }
-    if (u.deg > (uint32_t)M1) u = b.clean(u);
-    if (v.deg > (uint32_t)M1) v = b.clean(v);
-    for (int guard = 0; guard < 2 && 4.0 * (u.noise + v.noise) + bit.noise > b.noise_cap(); guard++) {
-      if (!u.trivial() && (v.trivial() || u.noise >= v.noise)) u = b.clean(u);
-      else v = b.clean(v);
-    }
-    if (4.0 * (u.noise + v.noise) + bit.noise > b.noise_cap()) throw std::logic_error("select_digit: operands too noisy for this parameter set");
-    Blk w = b.add_const(b.sub_raw(u, v), M1);
-    w.deg = (uint32_t)(2 * M1);
-    const Blk t = b.add(b.scale(w, 2), bit);
-    const Blk g = b.pbs(t, [M1](uint64_t x) { return (x & 1) ? (x >> 1) : (uint64_t)M1; });
-    Blk r = b.add_const(b.add(v, g), -M1);
-    r.deg = std::max(u.deg, v.deg);
-    return r;
-  }
   // the barrel shifter below with BINARY stages: a digit of `index` is split into its bits (two lookups per digit, shared by all
   // positions) and each bit selects between a position and its neighbour 2^j * stride away -- one lookup per output block and bit, two per
-  // base-4 digit where the 4-way selection takes four
+  // base-4 digit where the 4-way selection takes four (Ops::select: b ? u : v as one lookup of b + 2 (u - v + M - 1))
   std::vector<Radix> rotate_binary(const std::vector<Radix> &a, const Radix &index, size_t T, bool right, size_t n_out) {
     Builder &b = o.b;
     const size_t slots = a.size();
@@ -643,7 +615,7 @@ struct S {
           have[st - 1] = 1;
         }
         const Radix u = value(st - 1, src_i), v = value(st - 1, i);
-        for (size_t q = 0; q < width; q++) out.push_back(select_digit(bits[st - 1], u[q], v[q]));
+        for (size_t q = 0; q < width; q++) out.push_back(o.select(bits[st - 1], u[q], v[q]));
       }
       memo[st][i] = out;
       return out;
@@ -653,7 +625,7 @@ struct S {
     return v;
   }
   std::vector<Radix> rotate_logdepth(const std::vector<Radix> &a, const Radix &index, size_t T, bool right, size_t n_out) {
-    if (select_fits()) return rotate_binary(a, index, T, right, n_out);
+    if (o.select_fits()) return rotate_binary(a, index, T, right, n_out);
     Builder &b = o.b;
     const size_t slots = a.size();
     const size_t width = a.empty() ? 1 : a[0].size();
