@@ -558,6 +558,9 @@ def main():
                                    + ("PARAM_MESSAGE_2_CARRY_2_KS_PBS, l=255 (BASELINE config 2)" if args.params == "classic" else
                                       f"multi-bit 2_2 set, grouping factor {args.params[-1]}, l=255 (parameter family of BASELINE config 5)"),
                        "pbs_per_find": int(pbs_per_find), "levels": int(n_levels), "dependency_depth": int(lib.fhes_program_depth(prog)),
+                       "pbs_per_find_note": "rounds 1-3 compiled this find to 1664 bootstraps; since round 4 if_then_else_parallelized is one lookup per "
+                                            "block instead of two (DESIGN 5.4), same operations and results with fewer bootstraps: `finds_per_s` is the "
+                                            "figure that compares across rounds, `value` counts the bootstraps actually run",
                        "pbs_per_level_of_one_find": level_sizes,
                        "strings_per_step_per_rank": B,
                        "parallelism": f"{world_size} rank(s) x {B} independent strings per step (replicas, no data-path collective); "
