@@ -90,9 +90,11 @@ def cpu_baseline(which, pairs, budget_s=20.0):
     probe = w.encrypt(np.array([5], dtype=np.uint8))[0]
     _, poly = w.lut_poly(lambda x: x)
     w.oracle_pbs(probe, poly)
-    t0 = time.time()
-    w.oracle_pbs(probe, poly)
-    t_pbs = max(time.time() - t0, 1e-3)
+    t_pbs = 1e9
+    for _ in range(3):   # the best of three: one timing alone is at the mercy of the host's other tenants, and it sizes the sample
+        t0 = time.time()
+        w.oracle_pbs(probe, poly)
+        t_pbs = min(t_pbs, max(time.time() - t0, 1e-3))
     S = int(max(1, min(len(pairs), budget_s * cores / (p.n_pbs * t_pbs))))
     ins = [w.encrypt(np.concatenate([string_blocks(t), string_blocks(q)])) for t, q in pairs[:S]]
     t0 = time.time()
