@@ -562,13 +562,14 @@ def main():
                        "pbs_per_find": int(pbs_per_find), "levels": int(n_levels), "dependency_depth": int(lib.fhes_program_depth(prog)),
                        "pbs_per_find_note": "rounds 1-3 compiled this find to 1664 bootstraps; since round 4 if_then_else_parallelized is one lookup per "
                                             "block instead of two (DESIGN 5.4), same operations and results with fewer bootstraps: `finds_per_s` is the "
-                                            "figure that compares across rounds, `value` counts the bootstraps actually run",
+                                            "figure that compares across rounds (`finds_per_s_in_round3_bootstraps` = finds_per_s x 1664), `value` counts the bootstraps actually run",
                        "pbs_per_level_of_one_find": level_sizes,
                        "strings_per_step_per_rank": B,
                        "parallelism": f"{world_size} rank(s) x {B} independent strings per step (replicas, no data-path collective); "
                                       f"position-sharded single-string operations over the same ranks: see `sharded`"},
             "result_ok": bool(ok),
             "finds_per_s": round(B * world_size * args.steps / dt_max, 2),
+            **({"finds_per_s_in_round3_bootstraps": round(B * world_size * args.steps / dt_max * 1664, 1)} if args.params == "classic" else {}),
             "keyswitch": {"path": "i8 matrix product on the matrix cores (v_mfma_i32_16x16x64_i8), exact",
                           "pbs_per_s_rank0_with_valu_keyswitch": round(B * pbs_per_find / dt_valu_ks, 2),
                           "note": "one untimed step of the same batch with the VALU keyswitch kernel (fhes_set_keyswitch_mfma_min(ctx, 0)): same bits"},
