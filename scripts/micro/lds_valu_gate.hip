@@ -111,7 +111,7 @@ template <int N> __device__ __forceinline__ void swap_blocks(unsigned (&y)[8]) {
   if constexpr (N > 0) { SWAP8; swap_blocks<N - 1>(y); }
 }
 template <int VARIANT>
-__global__ __launch_bounds__(256) void kk(unsigned long long *stamps, double *sink, int iters, double a, double b) {
+__global__ __launch_bounds__(VARIANT == 9 ? 512 : 256) void kk(unsigned long long *stamps, double *sink, int iters, double a, double b) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   double x[8];
   unsigned y[8];
@@ -134,7 +134,14 @@ __global__ __launch_bounds__(256) void kk(unsigned long long *stamps, double *si
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
   for (int it = 0; it < iters; it++) {
-    if constexpr (VARIANT == 7 || VARIANT == 8) {
+    if constexpr (VARIANT == 9) {
+      // what a LATENCY build could be worth: ONE bootstrap on 512 threads -- every wave does half of a shipped wave's work in the same four
+      // phases (two waves per SIMD overlap their LDS and VALU phases); optimistic: a 4-point-per-thread transform needs more exchanges
+      K_RD(10); K_WAIT; K_F(6); K_I(10); K_WR(4); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(4); K_WAIT; K_F(5); K_WR(4); K_RD(4); K_WAIT; K_F(5); K_F(2); K_I(2); K_RD(4); K_WAIT; K_WR(4); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(4); K_WAIT; K_F(4); K_F(2); K_I(2); K_F(5); K_WR(4); K_RD(4); K_WAIT; K_F(5); K_WR(4); K_RD(3); K_WAIT; __builtin_amdgcn_s_barrier();
+      K_RD(4); K_WAIT; K_F(12); K_I(3); K_WR(4); K_WAIT; __builtin_amdgcn_s_barrier();
+    } else if constexpr (VARIANT == 7 || VARIANT == 8) {
       // a DIFFERENT decomposition of the same transforms: register bits exchanged with lane bits 4 and 5 by v_permlane16/32_swap (16 swaps per
       // bit and 8 points), so the passes are 3 | swap | 2 | LDS | 3 | swap | 2 and back: one LDS exchange per direction instead of two, no
       // wave-local LDS round trip, no DPP lane-pair stage.  32 stores, ~69 loads, the same f64 count, 128 swaps - 64 DPP moves.  8: without the swaps
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256) void kk(unsigned long long *stamps, double *si
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
-  if ((threadIdx.x & 63) == 0) stamps[(size_t)blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+  if ((threadIdx.x & 63) == 0) stamps[(size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
   sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = x[0] + x[1] + x[2] + x[3] + x[4] + x[5] + x[6] + x[7] + (double)(r[0].x + r[1].y + r[2].z + r[3].w) + (double)(y[0] ^ y[1] ^ y[2] ^ y[3] ^ y[4] ^ y[5] ^ y[6] ^ y[7]);
 }
 
@@ -188,12 +195,12 @@ static void run_k(unsigned long long *d_st, double *d_sink, int n_cu, int wg_per
   float ms = 0;
   for (int rep = 0; rep < 3; rep++) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(n_cu * wg_per_cu), dim3(256), lds_bytes, 0, d_st, d_sink, iters, 1.0000001, 1e-9);
+    hipLaunchKernelGGL(kern, dim3(n_cu * wg_per_cu), dim3(VARIANT == 9 ? 512 : 256), lds_bytes, 0, d_st, d_sink, iters, 1.0000001, 1e-9);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
-  std::vector<unsigned long long> st((size_t)n_cu * wg_per_cu * 4);
+  std::vector<unsigned long long> st((size_t)n_cu * wg_per_cu * (VARIANT == 9 ? 8 : 4));
   hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost);
   std::vector<double> cyc;
   for (size_t i = 0; i < st.size(); i++) cyc.push_back((double)st[i] / iters);
@@ -203,7 +210,8 @@ static void run_k(unsigned long long *d_st, double *d_sink, int n_cu, int wg_per
   static const char *names[] = {"as shipped", "exchanges fused into the phase ends", "no LDS operations", "no arithmetic",
                                 "four identical phases, one round trip each", "as shipped + barriers at the wave-local exchanges (six phases)",
                                 "four identical phases, two round trips each",
-                                "permlane decomposition: 3 | swap | 2 | LDS | 3 | swap | 2 (32 stores, 69 loads, 128 swaps)", "permlane decomposition without the swaps"};
+                                "permlane decomposition: 3 | swap | 2 | LDS | 3 | swap | 2 (32 stores, 69 loads, 128 swaps)", "permlane decomposition without the swaps",
+                                "latency build: one bootstrap on 512 threads, half the work per wave (optimistic)"};
   printf("{\"structure\": \"K\", \"variant\": \"%s\", \"workgroups_per_cu\": %d, \"cycles_per_iteration_median_wave\": %.1f, "
          "\"cycles_per_iteration_slowest_wave\": %.1f, \"wall_us_per_iteration\": %.4f, \"cycles_per_cmux_per_cu\": %.0f, "
          "\"implied_clock_ghz\": %.3f, \"resident_workgroups_per_cu_by_occupancy_api\": %d}\n",
@@ -282,6 +290,7 @@ int main() {
     run_k<7>(d_st, d_sink, n_cu, 1);
     run_k<7>(d_st, d_sink, n_cu, 2);
     run_k<8>(d_st, d_sink, n_cu, 2);
+    run_k<9>(d_st, d_sink, n_cu, 1);
     if (getenv("GATE_ONLY_PERMLANE")) return 0;
     run_k<1>(d_st, d_sink, n_cu, 1);
     run_k<1>(d_st, d_sink, n_cu, 2);
