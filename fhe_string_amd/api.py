@@ -396,7 +396,7 @@ class FheString(_Ct):
 
     def find(self, k, s, logdepth=False):
         """search.rs:23-28.  logdepth=True selects the opt-in first-match scan by prefix counts
-        (same decrypted result, 8 instead of n + 5 dependent levels at 64 characters)."""
+        (same decrypted result, 7 instead of n + 5 dependent levels at 64 characters)."""
         o = _op(k, "find_logdepth" if logdepth else "find", self, s)
         return FheOption(BooleanBlock(o[0]), FheUsize(o[1]))
 
