@@ -312,15 +312,18 @@ static void tile_wide_levels(Program &prog, size_t max_nodes) {
 }
 
 // device rounds of one launch of c bootstraps, in units of a one-per-CU round (2.96 ms on the default set; a two-per-CU round: 4.0 ms)
-static double launch_cost(size_t c) {
-  constexpr size_t kResident = 512, kOnePerCu = 256;
+// (`resident`: workgroups the device holds at once -- 512 for the kernels of N <= 2048, two per CU; 256 for the one-per-CU kernels above)
+static double launch_cost(size_t c, size_t resident) {
+  constexpr size_t kOnePerCu = 256;
   if (c == 0) return 0;
-  const size_t full = c / kResident, rem = c % kResident;
+  const size_t full = c / resident, rem = c % resident;
+  if (resident <= kOnePerCu) return (double)full + (rem ? 1.0 : 0.0);
   return 1.35 * (double)full + (rem == 0 ? 0.0 : (rem <= kOnePerCu ? 1.0 : 1.35));
 }
 
 void Builder::pack_levels(const std::vector<char> &live) {
   const int32_t nn = (int32_t)nodes_.size();
+  const size_t resident = p_.poly_size > 2048 ? 256 : 512;
   int32_t depth = 0;
   for (int32_t j = 0; j < nn; j++)
     if (live[j] && nodes_[j].lut >= 0) depth = std::max(depth, nodes_[j].level);
@@ -345,7 +348,7 @@ void Builder::pack_levels(const std::vector<char> &live) {
   for (int32_t j = 0; j < nn; j++)
     if (live[j] && nodes_[j].lut >= 0) asap_count[nodes_[j].level]++;
   double asap_cost = 0;
-  for (int32_t l = 1; l <= depth; l++) asap_cost += launch_cost(asap_count[l]);
+  for (int32_t l = 1; l <= depth; l++) asap_cost += launch_cost(asap_count[l], resident);
 
   // policy 0: trim a level of >= 512 runnable nodes to whole rounds; policy 1: also trim 257..511 to one one-per-CU round
   const std::vector<int32_t> npred0 = npred;
@@ -362,14 +365,14 @@ void Builder::pack_levels(const std::vector<char> &live) {
       size_t must = 0;
       while (must < ready.size() && alap[ready[must]] <= l) must++;
       size_t take = ready.size();
-      if (take >= 512) take = std::max(must, take / 512 * 512);
+      if (take >= resident) take = std::max(must, take / resident * resident);
       else if (policy == 1 && take > 256) take = std::max<size_t>(must, 256);
       std::vector<int32_t> next(ready.begin() + take, ready.end());
       for (size_t i = 0; i < take; i++) packed[ready[i]] = l;
       for (size_t i = 0; i < take; i++)
         for (int32_t c : succ[ready[i]])
           if (--npred[c] == 0) next.push_back(c);  // runnable from the next level on
-      cost += launch_cost(take);
+      cost += launch_cost(take, resident);
       ready.swap(next);
     }
     if (!ready.empty()) throw std::logic_error("pack_levels: nodes left after the last level");
