@@ -456,6 +456,16 @@ Radix Ops::propagate(std::vector<Blk> s) {
 
 Radix Ops::add(const Radix &x, const Radix &y) {
   if (x.size() != y.size()) throw std::logic_error("add: operand sizes differ");
+  {  // an addend that lives in block 0 only (a boolean widened to a radix: counters)
+    auto low_only = [](const Radix &r) {
+      for (size_t i = 1; i < r.size(); i++)
+        if (!(r[i].trivial() && r[i].cst == 0)) return false;
+      return !r.empty();
+    };
+    Radix fast_out;
+    if (low_only(y) && add_digit(x, y[0], fast_out)) return fast_out;
+    if (low_only(x) && add_digit(y, x[0], fast_out)) return fast_out;
+  }
   std::vector<Blk> s;
   for (size_t i = 0; i < x.size(); i++) s.push_back(b.add(b.tame(x[i], 1), b.tame(y[i], 1)));
   return propagate(s);
@@ -476,7 +486,60 @@ Radix Ops::sub(const Radix &x, const Radix &y) {
   return propagate(s);
 }
 
+// x + y0 for an addend of ONE digit -- a constant 0 < c < M, or an encrypted block such as a boolean (counters: `n + found`) -- on clean
+// blocks, all carries at once (round 4).  Only block 0 can generate a carry; a higher block passes one on iff it holds M - 1.  So the
+// carry into block i is a threshold of a plain SUM:
+//     addend <= 1:  [ (x_0 + y0) + x_1 + ... + x_{i-1} == M + (M - 1)(i - 1) ]          (the sum cannot exceed that value)
+//     otherwise:    g = (x_0 + y0) div M first, then [ g + x_1 + ... + x_{i-1} == 1 + (M - 1)(i - 1) ]
+// -- two (three) dependent levels whatever the width, where the ripple of `propagate` takes one per block; the same number of lookups.
+// Sums that would pass the block's space continue from the last flag.  The serial loops of the reference advance counters by one.
+bool Ops::add_digit(const Radix &x, const Blk &y0, Radix &out) {
+  const size_t B = x.size();
+  const uint64_t m = (uint64_t)M, top = (uint64_t)b.space() - 1;
+  if ((y0.trivial() && y0.cst == 0) || y0.deg >= (uint32_t)M || B < 3 || m + (m - 1) > top) return false;
+  Radix y;
+  for (const Blk &blk : x) {
+    if (blk.trivial()) return false;  // constants fold better through the general path
+    Blk t = b.tame(blk, 1);
+    if (t.deg >= (uint32_t)M) t = b.clean(t);
+    if ((t.noise + 1.0) * (double)B > b.noise_cap()) return false;
+    y.push_back(t);
+  }
+  const Blk a0 = y0.trivial() ? y0 : b.tame(y0, 1);
+  if (a0.noise + y[0].noise > b.noise_cap()) return false;
+  const Blk s0 = b.add(y[0], a0);
+  std::vector<Blk> carry(B);   // carry INTO block i (i >= 1)
+  Blk seed;                    // the running start of a chain: s0 itself (addend <= 1), g, or an earlier flag
+  uint64_t want;               // the value the chain's sum has exactly when every block so far passes the carry on
+  const bool unit = y0.deg <= 1;
+  if (unit) {
+    seed = s0;
+    want = m;
+  } else {
+    seed = b.pbs(s0, [m](uint64_t v) { return v / m; });
+    want = 1;
+  }
+  Blk sum = seed;
+  for (size_t i = 1; i < B; i++) {
+    const uint64_t w = want;
+    carry[i] = (i == 1 && !unit) ? seed : b.pbs(sum, [w](uint64_t v) { return v == w ? 1 : 0; });
+    if (i + 1 == B) break;
+    if (want + (m - 1) > top) {  // restart the chain from this flag
+      sum = carry[i];
+      want = 1;
+    }
+    sum = b.add(sum, y[i]);
+    want += m - 1;
+  }
+  out.clear();
+  out.push_back(b.pbs(s0, [m](uint64_t v) { return v % m; }));
+  for (size_t i = 1; i < B; i++) out.push_back(b.pbs(b.add(y[i], carry[i]), [m](uint64_t v) { return v % m; }));
+  return true;
+}
+
 Radix Ops::scalar_add(const Radix &x, uint64_t c) {
+  Radix fast_out;
+  if (c < (uint64_t)M && add_digit(x, b.trivial(c), fast_out)) return fast_out;
   std::vector<Blk> s;
   for (size_t i = 0; i < x.size(); i++) {
     s.push_back(b.add_const(b.tame(x[i], 1), (int64_t)(c % M)));

@@ -49,6 +49,7 @@ class Ops {
   Radix add(const Radix &x, const Radix &y);               // add_parallelized
   Radix sub(const Radix &x, const Radix &y);               // sub_parallelized (wrapping)
   Radix scalar_add(const Radix &x, uint64_t c);            // scalar_add_parallelized
+  bool add_digit(const Radix &x, const Blk &y0, Radix &out);  // one-digit addend (constant or block 0 only): all carries at once (radix.cpp)
   Radix scalar_sub(const Radix &x, uint64_t c);            // scalar_sub_parallelized (wrapping)
   Radix scalar_mul(const Radix &x, uint64_t c);            // scalar_mul_parallelized
   Radix mul(const Radix &x, const Radix &y);               // mul_parallelized
