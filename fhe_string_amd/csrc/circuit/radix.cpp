@@ -298,6 +298,34 @@ Blk Ops::reduce_signs(std::vector<Blk> signs, Cmp op) {
     }
   }
   if (signs.size() == 1) return b.pbs(signs[0], [op](uint64_t s) { return sign_final(op, std::min<uint64_t>(s, 2)); });
+  // THREE signs per lookup (round 4): with weights 1, 2, 4 (each larger than all lower ones together) the most significant sign that is
+  // not "equal" decides on which side of 1 + 2 + 4 the weighted sum s_0 + 2 s_1 + 4 s_2 <= 14 falls -- one level for up to six blocks
+  // where the pairwise tree takes two; 21 units of noise for clean signs.  Falls through to the pairs when that does not fit the cap.
+  while (signs.size() > 2) {
+    bool fits = true;
+    for (size_t i = 0; i < signs.size() && fits; i += 3) {
+      double noise = 0;
+      for (size_t k = 0; k < 3 && i + k < signs.size(); k++) noise += (double)((1u << k) * (1u << k)) * signs[i + k].noise;
+      fits = noise <= b.noise_cap() && signs[i].deg <= 2;
+    }
+    if (!fits) break;
+    const bool last = signs.size() <= 3;
+    std::vector<Blk> next;
+    for (size_t i = 0; i < signs.size(); i += 3) {
+      const size_t n = std::min<size_t>(3, signs.size() - i);
+      if (n == 1) { next.push_back(signs[i]); continue; }
+      Blk sum = b.trivial(0);
+      for (size_t k = 0; k < n; k++) sum = b.add(sum, b.scale(signs[i + k], (int64_t)1 << k));
+      const uint64_t e = ((uint64_t)1 << n) - 1;
+      next.push_back(b.pbs(sum, [op, last, e](uint64_t v) {
+        const uint64_t sg = v < e ? 0 : (v == e ? 1 : 2);
+        return last ? sign_final(op, sg) : sg;
+      }));
+    }
+    if (last) return next[0];
+    signs = next;
+  }
+  if (signs.size() == 1) return b.pbs(signs[0], [op](uint64_t s) { return sign_final(op, std::min<uint64_t>(s, 2)); });
   while (true) {
     const bool last = signs.size() == 2;
     std::vector<Blk> next;

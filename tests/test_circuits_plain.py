@@ -628,3 +628,32 @@ def test_crate_public_helpers_of_logic_rs_and_mod_rs(libs):
         assert val(prog("scalar_if_then_else_zero", [c], bu).run_plain(np.array([a], dtype="int64"))) == (c if a else 0)
         b1, b2 = rng.randint(0, 1), rng.randint(0, 1)
         assert [int(v) for v in prog("if_then_else_bool", [], bu).run_plain(np.array([a, b1, b2], dtype="int64"))] == [b1 if a else b2]
+
+
+def test_wide_usize_paths_of_round_4(libs):
+    """five and six usize blocks (l = 1023 / 4095: THREE packed pairs per comparison, so `reduce_signs` takes its three-signs-per-lookup
+    form, and the one-digit additions chain their carries through more than four blocks): the serial loops that live on counters and
+    comparisons -- split / rsplit / splitn, replace / replacen, find / rfind, len, lt -- against Python, faithful and opt-in forms"""
+    rnd = random.Random(0xF4E54)
+    for l in (1023, 4095):
+        for trial in range(10):
+            la, lb = rnd.randint(1, 9), rnd.randint(1, 3)
+            a = "".join(rnd.choice("ab,") for _ in range(la))
+            b = a[:lb] if trial % 2 else "".join(rnd.choice("ab,") for _ in range(lb))
+            a_pad, b_pad = rnd.choice([None, la + 2]), rnd.choice([None, lb + 1])
+            ctx = (l, a, a_pad, b, b_pad)
+            for form in ("", "_logdepth"):
+                assert run_plain("split" + form, a, a_pad, b, b_pad, l=l)[0] == rust_split(a, b), ctx
+                # (rsplit of a padded multi-character pattern follows the reference's own loop, not Python: the two forms agree with each other)
+                assert run_plain("rsplit" + form, a, a_pad, b, b_pad, l=l)[0] == run_plain("rsplit", a, a_pad, b, b_pad, l=255)[0], ctx
+                assert run_plain("find" + form, a, a_pad, b, b_pad, l=l)[0] == rust_find(a, b), ctx
+                assert run_plain("rfind" + form, a, a_pad, b, b_pad, l=l)[0] == rust_rfind(a, b), ctx
+                assert run_plain("lt" + form, a, a_pad, b, b_pad, l=l)[0] == (a < b), ctx
+            assert run_plain("len", a, a_pad, l=l)[0] == len(a), ctx
+            got = run_ext("replace", [S(a, a_pad), S(b, b_pad), S("xy", None), {"i": la + 6}], l=l)[0]
+            assert got == a.replace(b, "xy")[:la + 6], ctx
+            n = rnd.randint(0, 3)
+            got = run_ext("replacen", [S(a, a_pad), S(b, b_pad), S("z", None), {"u": n}, {"i": la + 4}], l=l)[0]
+            assert got == a.replace(b, "z", n)[:la + 4], ctx
+            got = run_ext("splitn", [S(a, a_pad), {"u": n}, S(b, b_pad)], l=l)[0]
+            assert got == (a.split(b, n - 1) if n > 0 else []), ctx
