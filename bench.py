@@ -146,6 +146,59 @@ def against_spec(cr, br_rate):
     return out
 
 
+def launch_plan(gpus, env):
+    """What `bench.py --gpus N` has to do in this environment (pure function; tests/test_bench_launch.py):
+      ("run",)          this process is a rank (or the only one) and its world size is what --gpus says
+      ("spawn",)        --gpus N > 1 without a launcher around us: start N ranks as child processes
+      ("error", why)    a launcher's WORLD_SIZE contradicts --gpus: refuse instead of measuring another job"""
+    ws = env.get("WORLD_SIZE")
+    if gpus < 1:
+        return ("error", f"--gpus {gpus}: need at least one")
+    if ws is None or ws == "":
+        return ("run",) if gpus == 1 else ("spawn",)
+    try:
+        ws = int(ws)
+    except ValueError:
+        return ("error", f"WORLD_SIZE={ws!r} is not a number")
+    if ws != gpus:
+        return ("error", f"--gpus {gpus} but the launcher started WORLD_SIZE={ws} ranks: refusing to report n_gpus={ws} for a --gpus {gpus} run")
+    return ("run",)
+
+
+def spawn_ranks(gpus, argv):
+    """Starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process (this process
+    has not imported torch or touched HIP), lets rank 0's JSON line through on stdout and returns the launcher's exit code
+    (non-zero as soon as any rank fails: torch.distributed.run tears the others down)."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL across processes needs it)
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("[bench] starting %d ranks: %s\n" % (gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    seen_line = False
+    for out in proc.stdout:                                # rank 0 prints ONE JSON line; anything else goes to stderr
+        if out.lstrip().startswith("{") and '"n_gpus"' in out:
+            sys.stdout.write(out)
+            sys.stdout.flush()
+            seen_line = True
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and not seen_line:
+        sys.stderr.write("[bench] the ranks exited 0 without a JSON line\n")
+        rc = 5
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,9 +212,28 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="independent (input, pattern) pairs per step and rank (levels of 5-7 bootstraps become launches of 1280-1792: whole multiples of the 256 CUs)")
     args = ap.parse_args()
 
+    # ---- `--gpus N` is a promise about the world size ----
+    # Decided BEFORE torch or any HIP call: a process that has initialised the GPU must never be replaced or re-executed,
+    # so the N ranks are CHILD processes of this one (python -m torch.distributed.run) and this process only relays.
+    plan = launch_plan(args.gpus, os.environ)
+    if plan[0] == "error":
+        sys.stderr.write(f"[bench] {plan[1]}\n")
+        sys.exit(2)
+    if plan[0] == "spawn":
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("FHES_BENCH_LAUNCH_ONLY") == "1":
+        # test hook (tests/test_bench_launch.py): prove the launch path without a device -- every rank reports and leaves
+        fail = os.environ.get("FHES_BENCH_FAIL_RANK")
+        if fail is not None and int(fail) == rank:
+            sys.stderr.write(f"[bench rank {rank}] asked to fail (FHES_BENCH_FAIL_RANK)\n")
+            sys.exit(7)
+        if rank == 0:
+            print(json.dumps({"launch_only": True, "n_gpus": world_size, "gpus_arg": args.gpus}), flush=True)
+        return
 
     import torch
     dist = None

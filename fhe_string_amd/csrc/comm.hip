@@ -70,10 +70,16 @@ RcclApi *rccl() {
       names.push_back(dir + "librccl.so");
     }
     names.push_back("/opt/rocm/lib/librccl.so.1");
-    std::string seen;
+    // FHES_RCCL_LIB names the one library to try (a site with RCCL elsewhere; tests/test_abi.py points it at nothing)
+    if (const char *only = getenv("FHES_RCCL_LIB")) names.assign(1, std::string(only));
+    std::string seen, load_error;
     for (const std::string &name : names) {
       void *h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
-      if (!h) continue;
+      if (!h) {
+        const char *e = dlerror();   // ONE call: glibc hands the message out once and clears it
+        if (load_error.empty()) load_error = e ? e : (name + ": not found");
+        continue;
+      }
       const LibId theirs = lib_of(dlsym(h, "hipGetDeviceCount"));
       if (!ours.ok || !theirs.ok || ours.same(theirs)) {   // (a runtime we cannot identify is taken on trust, as before)
         api.lib = h;
@@ -85,7 +91,7 @@ RcclApi *rccl() {
       dlclose(h);
     }
     if (!api.lib) {
-      api.error = seen.empty() ? std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found")
+      api.error = seen.empty() ? "cannot load librccl: " + (load_error.empty() ? std::string("not found") : load_error)
                                : "every librccl in reach is bound to another HIP runtime than this library (" + ours.path +
                                      "): " + seen + " -- two ROCm runtimes in one process (e.g. PyTorch's bundled one next to /opt/rocm); "
                                      "load this library after the framework that brings its own runtime, or make one runtime visible";
@@ -267,7 +273,7 @@ int fhes_comm_unique_id(uint8_t id[FHES_COMM_ID_BYTES]) {
   static_assert(sizeof(ncclUniqueId) == FHES_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
   if (!id) return fail(FHES_ERR_INVALID, "null argument");
   RcclApi *a = rccl();
-  if (!a) return fail(FHES_ERR_NO_DEVICE, "RCCL unavailable");
+  if (!a) return fail(FHES_ERR_STATE, "RCCL unavailable: %s", rccl_error().c_str());
   ncclUniqueId u;
   FHES_NCCL(a->GetUniqueId(&u));
   memcpy(id, &u, sizeof(u));

@@ -172,3 +172,26 @@ def test_integration_doc_matches_the_header(libs):
     declared = set(declared_symbols())
     for fn in re.findall(r"pub fn (fhes_\w+)\(", doc):
         assert fn in declared, f"INTEGRATION.md declares {fn}, the header does not"
+
+
+def test_no_librccl_in_reach_is_a_clean_error_not_a_crash():
+    """with no loadable librccl the error message was built from a second dlerror() call (NULL) -> segfault.
+    The binding happens once per process, so the probe runs in a child with FHES_RCCL_LIB pointed at nothing."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from fhe_string_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "rc = lib.fhes_comm_unique_id(buf)\n"
+        "assert rc < 0, rc\n"
+        "msg = lib.fhes_last_error().decode()\n"
+        "assert 'librccl' in msg and 'no-such-dir' in msg, msg\n"
+        "assert lib.fhes_rccl_library_path() == b''\n"
+        "print('clean:', msg)\n")
+    env = dict(os.environ, FHES_RCCL_LIB="/no-such-dir/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-1500:])
+    assert "clean:" in r.stdout
