@@ -50,7 +50,9 @@ struct fhes_ctx {
   int device = 0;
   int n_cus = 256;
   uint64_t uid = 0;          // unique per context (program images are keyed by it, not by address)
-  std::atomic<unsigned> attr_done{0};  // bit v: max-dynamic-LDS attribute set for blind-rotate variant v on this device
+  std::mutex attr_mu;                              // kernel function -> dynamic-LDS size its attribute was set to (engine.hip: ensure_dyn_lds)
+  std::map<const void *, size_t> attr_lds;
+  int lat_max = 0;   // launches of at most this many bootstraps take the latency build of the classic blind rotate (0: never)
   hipStream_t stream = nullptr;   // the main lane's stream (== main.stream)
   // Locking: `mu` guards the host-side state (arena free list, LUT registry, lanes, stats).  A program run
   // holds it while it sets up and while it cleans up, NOT while it queues its launches; `arena_rw` is held

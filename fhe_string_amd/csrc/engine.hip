@@ -12,6 +12,7 @@
 #include <set>
 
 #include "kernels.hip.h"
+#include "kernel_br_lat.hip.h"
 
 namespace fhes {
 
@@ -460,16 +461,25 @@ static int launch_keyswitch(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per kernel FUNCTION (and device): remembered per context by the function's
+// address and the size asked for, so that two instantiations never share a flag (the interleaved and plain
+// multi-bit builds did) and a larger request for the same function is set again.
+static int ensure_dyn_lds(fhes_ctx *ctx, const void *fn, size_t lds) {
+  std::lock_guard<std::mutex> g(ctx->attr_mu);
+  auto it = ctx->attr_lds.find(fn);
+  if (it != ctx->attr_lds.end() && it->second >= lds) return FHES_OK;
+  FHES_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ctx->attr_lds[fn] = lds;
+  return FHES_OK;
+}
+
 template <int LOGN>
 static int launch_br_v1(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
   const size_t lds = (size_t)2 * N * 8 + (size_t)2 * M * 16 + (size_t)((ctx->dims.n + 1 + 3) & ~3) * 4;
   auto kern = dev::blind_rotate_v1_kernel<LOGN, 23>;
-  if (!(ctx->attr_done & (1u << 1))) {  // per context: the attribute is per device
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ctx->attr_done |= 1u << 1;
-  }
+  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena,
                      ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_f,
                      ctx->lut_polys, ctx->twist, ctx->tw, ctx->psi);
@@ -485,12 +495,7 @@ static int launch_br_mb(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
   const size_t lds = (size_t)2 * SLOTS * 16 + (size_t)M * 16 + (size_t)(M / 2) * 16 + (size_t)M * 16 + (size_t)((n_deg + 7) & ~7) * 2;
   auto kern = dev::blind_rotate_mb_kernel<LOGN, BL, G, PIPE, LAT, ILV>;
-  const unsigned bit = 8 + 4 * (G - 2) + (PIPE ? 1 : 0) + (LAT ? 2 : 0);  // per context: one base per parameter set (and one key layout)
-  if (!(ctx->attr_done & (1u << bit))) {
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ctx->attr_done |= 1u << bit;
-  }
+  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena,
                      ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
                      ctx->lut_polys, ctx->twist_inv, ctx->tw, ctx->root, ctx->psi, ctx->cdpp);
@@ -505,14 +510,23 @@ static int launch_br_v5(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   constexpr int SLOTS = M;
   const size_t lds = (size_t)2 * N * 8 + (size_t)2 * SLOTS * 16 + (size_t)2 * (M / 2) * 16;  // N = 2048: exactly 80 KB, two per CU
   auto kern = dev::blind_rotate_v5_kernel<LOGN, BL, PRIO>;
-  if (!(ctx->attr_done & (1u << (20 + PRIO)))) {
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ctx->attr_done |= 1u << (20 + PRIO);
-  }
+  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena,
                      ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
                      ctx->lut_polys, ctx->twist_inv64, ctx->tw, ctx->psi, ctx->cdpp);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
+// the latency build of the classic blind rotate (kernel_br_lat.hip.h): ONE bootstrap on 512 threads, one workgroup per CU
+template <int BL = 23>
+static int launch_br_lat(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_lat<18>(ctx, lane, d);
+  auto kern = dev::blind_rotate_lat_kernel<BL>;
+  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), dev::kLatLdsBytes)) return rc;
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(dev::kLatThreads), dev::kLatLdsBytes, lane.stream, d, ctx->arena,
+                     ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e, ctx->lut_polys, ctx->twist_inv64,
+                     ctx->tw, ctx->psi);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
@@ -533,10 +547,7 @@ static int launch_br_v8(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
     FHES_HIP(hipMalloc(&lane.gen_scratch, need));
     lane.gen_scratch_bytes = need;
   }
-  if (ABL != 0 || !(ctx->attr_done & (1u << 26))) {
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (ABL == 0) ctx->attr_done |= 1u << 26;
-  }
+  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena, ctx->ct_stride, lane.ks_out, ctx->ks_stride,
                      ctx->dims.n, ctx->bsk_e, ctx->lut_polys, ctx->twist_inv64, ctx->tw, ctx->psi, ctx->cdpp,
                      reinterpret_cast<ulonglong2 *>(lane.gen_scratch));
@@ -570,22 +581,15 @@ static int launch_br_gen_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
     lane.gen_scratch_bytes = need;
   }
   const size_t lds = gen_lds_bytes(dm, resident);
-  const unsigned bit = 1u << (2 + (LOGN - 8));  // bits 2..7 (bit 29: the LDS-resident form, one shape per context)
   if (resident) {
     auto kern = dev::blind_rotate_gen_kernel<LOGN, true>;
-    if (!(ctx->attr_done & (1u << 29))) {
-      FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      ctx->attr_done |= 1u << 29;
-    }
+    if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(d.v_count), dim3((dm.k + 1) * (M / 8)), lds, lane.stream, d, ctx->arena, ctx->ct_stride,
                        lane.ks_out, ctx->ks_stride, dm.n, dm.k, dm.L, dm.pbs_base_log, ctx->bsk_f, ctx->lut_polys, ctx->twist,
                        ctx->tw, ctx->psi, (unsigned char *)nullptr, per);
   } else {
     auto kern = dev::blind_rotate_gen_kernel<LOGN, false>;
-    if (!(ctx->attr_done & bit)) {
-      FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      ctx->attr_done |= bit;
-    }
+    if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(d.v_count), dim3((dm.k + 1) * (M / 8)), lds, lane.stream, d, ctx->arena, ctx->ct_stride,
                        lane.ks_out, ctx->ks_stride, dm.n, dm.k, dm.L, dm.pbs_base_log, ctx->bsk_f, ctx->lut_polys, ctx->twist,
                        ctx->tw, ctx->psi, lane.gen_scratch, per);
@@ -609,11 +613,7 @@ static int launch_br_big_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   }
   const size_t lds = (size_t)2 * M * 16 + (size_t)2 * 512 * 16 + (size_t)((dm.n + 1 + 3) & ~3) * 4;
   auto kern = dev::blind_rotate_big_kernel<LOGN, LV>;
-  const unsigned bit = 1u << (LOGN == 12 ? 30 : 31);   // one parameter set per context: one level count
-  if (!(ctx->attr_done & bit)) {
-    FHES_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ctx->attr_done |= bit;
-  }
+  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 8), lds, lane.stream, d, ctx->arena, ctx->ct_stride, lane.ks_out, ctx->ks_stride,
                      dm.n, dm.pbs_base_log, ctx->bsk_f, ctx->lut_polys, ctx->twist, ctx->tw, ctx->psi, lane.gen_scratch, per);
   FHES_HIP(hipGetLastError());
@@ -665,7 +665,12 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   }
   if (!fast_shape(ctx->p) || ctx->br_variant == 12) return launch_br_gen(ctx, lane, d);  // 12: the generic kernel on a 2_2 set (tests)
   int variant = ctx->br_variant;
-  if (variant == 0) variant = 7;  // every launch size
+  // 2: the latency build (one bootstrap on 512 threads, one workgroup per CU); 3: the throughput build whatever the launch size
+  if (variant == 2 || (variant == 0 && ctx->lat_max > 0 && d.v_count <= ctx->lat_max && ctx->dims.N == 2048)) {
+    if (ctx->dims.N != 2048) return fail(FHES_ERR_UNSUPPORTED, "the latency build of the blind rotate is written for N = 2048");
+    return launch_br_lat<>(ctx, lane, d);
+  }
+  if (variant == 0 || variant == 3) variant = 7;
   if (variant != 1 && (variant < 5 || variant > 10) && variant != 13 && variant != 14)
     return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d does not exist (1, 5, 6, 7, 8; 9, 10, 13 and 14 are timing-only ablations)", variant);
   if (variant == 8) {
@@ -846,6 +851,10 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
     ctx->n_cus = prop.multiProcessorCount;
   }
+  // launches of at most one workgroup per CU take the latency build (kernel_br_lat.hip.h); FHES_LAT_MAX=0 keeps the throughput
+  // build for every size, another number moves the switch-over (developer knob, scripts/lat_probe.py)
+  ctx->lat_max = ctx->n_cus;
+  if (const char *e6 = getenv("FHES_LAT_MAX")) ctx->lat_max = atoi(e6) < 0 ? 0 : atoi(e6);
   if (const char *e5 = getenv("FHES_KS_MFMA_MIN")) ctx->ks_mfma_min = atoi(e5);  // developer knob: 0 = VALU keyswitch only, 1 = always MFMA
   if (const char *e3 = getenv("FHES_KS_TB")) ctx->ks_tb = atoi(e3);  // developer knob: 8 / 16 force the tile height
   if (const char *e2 = getenv("FHES_KS_MIN_CPS")) {

@@ -1,0 +1,367 @@
+// kernel_br_lat.hip.h -- the LATENCY build of the classic blind rotate (round 5; k = 1, one level, N = 2048).
+//
+// One call of the reference's API is a chain of dependent levels of 3-4 bootstraps (the serial loops mod.rs:341-349,
+// search.rs:91-109, split.rs:274-319): every level costs one whole blind rotate on 3-4 of the 256 CUs.  The throughput kernel
+// (blind_rotate_v5_kernel: 256 threads, 8 points per thread, two workgroups per CU) alone on a CU has ONE wave per SIMD, and
+// a wave that has issued its LDS stores issues no arithmetic until they are through: the CU's LDS pipe and its VALUs take turns
+// (3.8 k + 4.0 k cycles per CMUX + barriers = 9.2 k).  Here ONE bootstrap runs on 512 threads -- two waves per SIMD, each with
+// half the work, covering each other's LDS time -- with 4 points per thread:
+//
+//   * 256 threads per output polynomial (half r = tid >> 8), wave w = (tid >> 6) & 3, lane l; a transform is five 2-bit register
+//     passes A..E (E: one stage) and the lane-pair stage.  Between them the data is re-laid out
+//         A -> B   through LDS across the four waves of a half (workgroup barrier),
+//         B -> C   inside a wave WITHOUT LDS: v_permlane32_swap / v_permlane16_swap transpose a register bit with lane bit 5 / 4,
+//         C -> D   through LDS inside a wave (no barrier: the LDS operations of one wave execute in order),
+//         D -> E   v_permlane32_swap,
+//     so a transform costs the same two LDS round trips per point as the throughput kernel's three 3-bit passes;
+//   * with 4 points per thread the state is 16 + 16 + 32 registers (own accumulator words, points, GGSW rows), so EVERY
+//     twiddle of every pass, the lane-pair constants and the untwist factors stay in registers for the whole loop: no table
+//     reads from LDS at all;
+//   * one workgroup per CU has 128 KB of LDS to itself: the image of -acc, two exchange buffers and the spectrum hand-over
+//     buffer are separate, the image is in plain coefficient order (rotated 8-byte reads of consecutive lanes are consecutive
+//     words: conflict-free, where the throughput kernel pays 76 conflict cycles per wave for its in-place image).
+//   * four workgroup barriers per CMUX, as in the throughput kernel (each is a true all-to-all dependence).
+//
+// Arithmetic: DESIGN.md section 4, statement by statement the butterflies of blind_rotate_v5_kernel on the same operands in
+// the same stage order -- the same bits (tests/test_gpu_pbs.py compares every variant with the oracle word for word).
+// Index model of the layouts, swizzles and transposes, checked against a plain stage-by-stage transform and against the LDS
+// bank rules: scripts/model/lat_layouts.py.
+//
+// Layouts (p = point index, bits p9..p0; e = register, bits e1 e0; l = lane, bits l5..l0):
+//   L_A  e = (p9, p8)   q = tid & 255 = p7..p0
+//   L_B  w = (p9, p8)   e = (p7, p6)   l5 = p4, l4 = p5, l3..l0 = p3..p0
+//   L_C  w = (p9, p8)   e = (p5, p4)   l5 = p6, l4 = p7, l3..l0 = p3..p0          (L_B with e0 <-> l5, e1 <-> l4)
+//   L_D  w = (p9, p8)   e = (p3, p2)   l5 = p1, l4..l1 = p7..p4, l0 = p0
+//   L_E  w = (p9, p8)   e = (p3, p1)   l5 = p2, l4..l1 = p7..p4, l0 = p0          (L_D with e0 <-> l5)
+#pragma once
+#include "kernels.hip.h"
+
+namespace fhes {
+namespace dev {
+
+__device__ __forceinline__ void lat_swap32(double &a, double &b) {  // register bit <-> lane bit 5
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void lat_swap16(double &a, double &b) {  // register bit <-> lane bit 4
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// e0 <-> l5 on both register pairs
+__device__ __forceinline__ void lat_transpose_e0_l5(double2 (&x)[4]) {
+  lat_swap32(x[0].x, x[1].x); lat_swap32(x[0].y, x[1].y);
+  lat_swap32(x[2].x, x[3].x); lat_swap32(x[2].y, x[3].y);
+}
+// e1 <-> l4
+__device__ __forceinline__ void lat_transpose_e1_l4(double2 (&x)[4]) {
+  lat_swap16(x[0].x, x[2].x); lat_swap16(x[0].y, x[2].y);
+  lat_swap16(x[1].x, x[3].x); lat_swap16(x[1].y, x[3].y);
+}
+
+// forward 2-bit pass: the stage of the higher index bit (e1) first; hi = its twiddle (the block does not depend on e), lo0 / lo1
+// the twiddles of the lower stage for e1 = 0 / 1
+__device__ __forceinline__ void lat_fwd_pass(double2 (&x)[4], double2 hi, double2 lo0, double2 lo1) {
+  fwd_butterfly(x[0], x[2], hi);
+  fwd_butterfly(x[1], x[3], hi);
+  fwd_butterfly(x[0], x[1], lo0);
+  fwd_butterfly(x[2], x[3], lo1);
+}
+// inverse 2-bit pass: the stage of the lower index bit (e0) first; lo = its twiddle (depends on the bits below only), hi0 / hi1
+// the twiddles of the higher stage for e0 = 0 / 1
+__device__ __forceinline__ void lat_inv_pass(double2 (&x)[4], double2 lo, double2 hi0, double2 hi1) {
+  inv_butterfly(x[0], x[1], lo);
+  inv_butterfly(x[2], x[3], lo);
+  inv_butterfly(x[0], x[2], hi0);
+  inv_butterfly(x[1], x[3], hi1);
+}
+__device__ __forceinline__ void lat_fwd_stage0_dpp(double2 (&x)[4], const double2 (&c)[4]) {  // fft_fwd_stage0_dpp on 4 points
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double px = dpp_swap1(x[e].x), py = dpp_swap1(x[e].y);
+    double re = __builtin_fma(c[e].x, px, x[e].x);
+    re = __builtin_fma(-c[e].y, py, re);
+    double im = __builtin_fma(c[e].x, py, x[e].y);
+    im = __builtin_fma(c[e].y, px, im);
+    x[e] = make_double2(re, im);
+  }
+}
+__device__ __forceinline__ void lat_inv_stage0_dpp(double2 (&x)[4], double sgn) {  // fft_stage_bit0_dpp on 4 points
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double px = dpp_swap1(x[e].x), py = dpp_swap1(x[e].y);
+    x[e].x = __builtin_fma(x[e].x, sgn, px);
+    x[e].y = __builtin_fma(x[e].y, sgn, py);
+  }
+}
+
+constexpr int kLatThreads = 512;
+constexpr size_t kLatLdsBytes = (size_t)2 * 2048 * 8 + (size_t)3 * 2 * 1024 * 16;  // image + X1 + X2 + S = 128 KB
+
+// LAT_ABL: timing-only ablations for the lab book (FHES_LAB builds; WRONG results): 1 = without the LDS exchanges and the
+// spectrum hand-over, 2 = without the butterflies
+template <int BL, int LAT_ABL = 0>
+__global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride, int n_small,
+    const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
+    const double2 *__restrict__ twist_inv /* twist / (M * 2^64): torus_from_f64_pair */, const double2 *__restrict__ tw,
+    const double2 *__restrict__ psi) {
+  constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2;
+  static_assert(BL >= 1 && BL <= 31, "single-level digit must fit the high dword");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t *img_all = reinterpret_cast<uint64_t *>(smem_raw);                       // [2][N]   image of -acc, plain order
+  double2 *x1_all = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);      // [2][M]   A <-> B exchanges
+  double2 *x2_all = x1_all + 2 * M;                                                 // [2][M]   C <-> D exchanges (wave-local)
+  double2 *s_all = x2_all + 2 * M;                                                  // [2][M]   spectra for the other half
+
+  const int tid = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(tid >> 8);        // half = output polynomial
+  const int w = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);  // wave inside the half = (p9, p8) in layouts B..E
+  const int q = tid & 255;
+  const int l = tid & 63;
+  const int l0 = l & 1, l4 = (l >> 4) & 1, l5 = (l >> 5) & 1, lo4 = l & 15;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+
+  uint64_t *img = img_all + (size_t)r * N;
+  double2 *x1 = x1_all + (size_t)r * M;
+  double2 *x2 = x2_all + (size_t)r * M;
+  double2 *s_r = s_all + (size_t)r * M;
+  const double2 *s_o = s_all + (size_t)(1 - r) * M;
+
+  // ---- slots of this thread in every layout (element indices inside a half's buffer) ----
+  const int blk16 = w * 16 + ((l >> 1) & 15);                 // p >> 4 in layouts D / E
+  int sA[4], sB[4], sC[4], sD[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sA[e] = q + 256 * e;
+    sB[e] = w * 256 + e * 64 + l4 * 32 + l5 * 16 + lo4;
+    sC[e] = fswz(w * 256 + l4 * 128 + l5 * 64 + e * 16 + lo4);
+    sD[e] = fswz(blk16 * 16 + e * 4 + l5 * 2 + l0);
+  }
+
+  // ---- every twiddle of both transforms, once (registers for the whole loop) ----
+  // forward: psi[2^s + block], s = number of stages done so far, block = the index bits above the stage's bit
+  const double2 fA_hi = psi[1], fA_lo0 = psi[2], fA_lo1 = psi[3];
+  const double2 fB_hi = psi[4 + w], fB_lo0 = psi[8 + 2 * w], fB_lo1 = psi[8 + 2 * w + 1];
+  const int blkC = w * 4 + l4 * 2 + l5;                       // p >> 6 in layout C
+  const double2 fC_hi = psi[16 + blkC], fC_lo0 = psi[32 + 2 * blkC], fC_lo1 = psi[32 + 2 * blkC + 1];
+  const double2 fD_hi = psi[64 + blk16], fD_lo0 = psi[128 + 2 * blk16], fD_lo1 = psi[128 + 2 * blk16 + 1];
+  const double2 fE_0 = psi[256 + blk16 * 4 + l5], fE_1 = psi[256 + blk16 * 4 + 2 + l5];   // stage of p1: block = (p >> 2)
+  double2 cd[4];                                              // lane-pair stage: t on even lanes, (-t.x, t.y) on odd lanes
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double2 t = psi[512 + blk16 * 8 + (e >> 1) * 4 + l5 * 2 + (e & 1)];
+    cd[e] = l0 ? make_double2(-t.x, t.y) : t;
+  }
+  // inverse: tw[(index bits below the stage's bit) << (9 - bit)]
+  const double sgn = l0 ? -1.0 : 1.0;
+  const double2 iE = tw[l0 << 8];
+  const int low2 = l5 * 2 + l0;                               // (p1, p0) in layout D
+  const double2 iD_lo = tw[low2 << 7], iD_hi0 = tw[low2 << 6], iD_hi1 = tw[(4 + low2) << 6];
+  const double2 iC_lo = tw[lo4 << 5], iC_hi0 = tw[lo4 << 4], iC_hi1 = tw[(16 + lo4) << 4];
+  const int low6 = l4 * 32 + l5 * 16 + lo4;                   // p5..p0 in layout B
+  const double2 iB_lo = tw[low6 << 3], iB_hi0 = tw[low6 << 2], iB_hi1 = tw[(64 + low6) << 2];
+  const double2 iA_lo = tw[q << 1], iA_hi0 = tw[q], iA_hi1 = tw[256 + q];
+  double2 twi[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) twi[e] = twist_inv[q + 256 * e];
+
+  // ---- Fourier key in the engine layout [i][row][col][e8][128] (bsk_to_engine_layout_kernel): the point p of layout E
+  // sits at e8 = (p3 p2 p1) = e1 * 4 + l5 * 2 + e0, position (p >> 4) * 2 + p0 = w * 32 + (l & 31) ----
+  const __amdgpu_buffer_rsrc_t rs_g =
+      __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_small * 4 * M * 16), 0x00020000);
+  const unsigned voff_g = (unsigned)((r * 8 + l5 * 2) * 128 + w * 32 + (l & 31)) * 16u;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  auto modswitch_of = [&](uint64_t v) __attribute__((always_inline)) {
+    return (int)((((v >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  };
+
+  // ---- accumulator: acc = (0, X^{-b~} LUT); registers and image hold -acc ----
+  uint64_t nlo[4], nhi[4];
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - modswitch_of(ks[n_small])) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = q + 256 * e;
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      nlo[e] = (uint64_t)0 - v0;
+      nhi[e] = (uint64_t)0 - v1;
+      img[p] = nlo[e];
+      img[p + M] = nhi[e];
+    }
+  }
+  __syncthreads();
+
+  constexpr uint64_t ROUND = (uint64_t)1 << (63 - BL);
+  int a_next = modswitch_of(ks[0]);
+  for (int i = 0; i < n_small; ++i) {
+    const int a = a_next;
+    double2 x[4];
+    // ---- digits of X^a acc - acc at the own coefficients p (re) and p + M (im) ----
+    {
+      uint64_t va[4], vb[4];
+      int m0v[4], m1v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned s0 = (unsigned)(q + 256 * e - a) & (unsigned)(2 * N - 1);
+        const unsigned s1 = (s0 + (unsigned)M) & (unsigned)(2 * N - 1);
+        // the image holds -acc: the operand is +acc[s] = -image when the rotation did NOT wrap, -acc[s] = image when it did
+        m0v[e] = (int)((s0 >> LOGN) & 1u) - 1;   // -1: negate
+        m1v[e] = (int)((s1 >> LOGN) & 1u) - 1;
+        va[e] = img[s0 & (unsigned)(N - 1)];
+        vb[e] = img[s1 & (unsigned)(N - 1)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint64_t dd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m32 = h == 0 ? m0v[e] : m1v[e];
+          const uint64_t v = h == 0 ? va[e] : vb[e];
+          const uint64_t mm = ((uint64_t)(uint32_t)m32 << 32) | (uint64_t)(uint32_t)m32;
+          const uint64_t kk = ROUND | (uint64_t)(uint32_t)(m32 & 1);
+          dd[h] = add64(add64(v ^ mm, h == 0 ? nlo[e] : nhi[e]), kk);
+        }
+        const double d0 = (double)((int)(uint32_t)(dd[0] >> 32) >> (32 - BL));
+        const double d1 = (double)((int)(uint32_t)(dd[1] >> 32) >> (32 - BL));
+        x[e] = make_double2(d0, d1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t ks_next = ks[i + 1];
+    // GGSW rows of this iteration: requested a whole forward transform ahead
+    double2 g0[4], g1[4];
+    {
+      const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned eo = (unsigned)(((e >> 1) * 4 + (e & 1)) * 128 * 16);
+        g0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)(0 * 16 * 128 * 16) + eo);
+        g1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)(1 * 16 * 128 * 16) + eo);
+      }
+    }
+    // ---- forward transform ----
+    if (LAT_ABL != 2) lat_fwd_pass(x, fA_hi, fA_lo0, fA_lo1);                  // bits 9, 8
+    if (LAT_ABL != 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x1[sA[e]] = x[e];
+    }
+    a_next = modswitch_of(ks_next);
+    asm volatile("" : "+s"(a_next));
+    __syncthreads();  // B1 (also: every rotated read of the image is done)
+    if (LAT_ABL != 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = x1[sB[e]];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (LAT_ABL != 2) lat_fwd_pass(x, fB_hi, fB_lo0, fB_lo1);                  // bits 7, 6
+    lat_transpose_e0_l5(x);
+    lat_transpose_e1_l4(x);                                                     // -> L_C
+    if (LAT_ABL != 2) lat_fwd_pass(x, fC_hi, fC_lo0, fC_lo1);                  // bits 5, 4
+    if (LAT_ABL != 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x2[sC[e]] = x[e];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = x2[sD[e]];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (LAT_ABL != 2) lat_fwd_pass(x, fD_hi, fD_lo0, fD_lo1);                  // bits 3, 2
+    lat_transpose_e0_l5(x);                                                     // -> L_E
+    if (LAT_ABL != 2) {
+      fwd_butterfly(x[0], x[1], fE_0);                                          // bit 1
+      fwd_butterfly(x[2], x[3], fE_1);
+      lat_fwd_stage0_dpp(x, cd);                                                // bit 0
+    }
+    if (LAT_ABL != 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_r[e * 256 + q] = x[e];
+    }
+    __syncthreads();  // B3
+    // ---- external product: D0 G[0][r] + D1 G[1][r] ----
+    if (LAT_ABL == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = ext_mac(x[e], x[e], g0[e], g1[e]);
+    } else if (r == 0) {
+      double2 oth[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) oth[e] = s_o[e * 256 + q];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = ext_mac(x[e], oth[e], g0[e], g1[e]);
+      asm volatile("; end of form r = 0");
+    } else {
+      double2 oth[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) oth[e] = s_o[e * 256 + q];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = ext_mac(oth[e], x[e], g0[e], g1[e]);
+      asm volatile("; end of form r = 1");
+    }
+    // ---- inverse transform ----
+    if (LAT_ABL != 2) {
+      lat_inv_stage0_dpp(x, sgn);                                               // bit 0
+      inv_butterfly(x[0], x[1], iE);                                            // bit 1
+      inv_butterfly(x[2], x[3], iE);
+    }
+    lat_transpose_e0_l5(x);                                                     // -> L_D
+    if (LAT_ABL != 2) lat_inv_pass(x, iD_lo, iD_hi0, iD_hi1);                  // bits 2, 3
+    if (LAT_ABL != 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x2[sD[e]] = x[e];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = x2[sC[e]];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (LAT_ABL != 2) lat_inv_pass(x, iC_lo, iC_hi0, iC_hi1);                  // bits 4, 5
+    lat_transpose_e0_l5(x);
+    lat_transpose_e1_l4(x);                                                     // -> L_B
+    if (LAT_ABL != 2) lat_inv_pass(x, iB_lo, iB_hi0, iB_hi1);                  // bits 6, 7
+    if (LAT_ABL != 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x1[sB[e]] = x[e];
+    }
+    __syncthreads();  // B5
+    if (LAT_ABL != 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = x1[sA[e]];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (LAT_ABL != 2) lat_inv_pass(x, iA_lo, iA_hi0, iA_hi1);                  // bits 8, 9
+    // ---- untwist (negated factors: -y), round, nacc += rint(-y); the image goes back ----
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double2 v = cmul_conj(x[e], make_double2(-twi[e].x, -twi[e].y));
+      nlo[e] = add64(torus_from_f64_pair(v.x), nlo[e]);
+      nhi[e] = add64(torus_from_f64_pair(v.y), nhi[e]);
+      img[q + 256 * e] = nlo[e];
+      img[q + 256 * e + M] = nhi[e];
+    }
+    __syncthreads();  // B6
+  }
+
+  // ---- sample extract from the image of -acc: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+  for (int j = tid; j < N; j += kLatThreads) {
+    const int jj = (j == 0) ? 0 : N - j;
+    const uint64_t v = img_all[jj];
+    out[j] = (j == 0) ? (uint64_t)0 - v : v;
+  }
+  if (tid == 0) out[N] = (uint64_t)0 - img_all[N];
+}
+
+}  // namespace dev
+}  // namespace fhes
