@@ -1,5 +1,6 @@
 // builder.cpp -- see builder.h
 #include "builder.h"
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -311,19 +312,23 @@ static void tile_wide_levels(Program &prog, size_t max_nodes) {
   prog.level_ptr = lp;
 }
 
-// device rounds of one launch of c bootstraps, in units of a one-per-CU round (2.96 ms on the default set; a two-per-CU round: 4.0 ms)
-// (`resident`: workgroups the device holds at once -- 512 for the kernels of N <= 2048, two per CU; 256 for the one-per-CU kernels above)
-static double launch_cost(size_t c, size_t resident) {
+// device rounds of one launch of c bootstraps, in units of a one-per-CU round
+// (`resident`: workgroups the device holds at once -- 512 for the kernels of N <= 2048, two per CU; 256 for the one-per-CU kernels above;
+//  `full_round`: a two-per-CU round in those units.  Classic 2_2 sets since round 5: 4.0 ms against 2.45-2.7 ms for the latency build
+//  that serves launches of <= 256 (kernel_br_lat.hip.h) = 1.55; multi-bit sets and round 4: 4.0 against 2.96 ms = 1.35)
+static double launch_cost(size_t c, size_t resident, double full_round) {
   constexpr size_t kOnePerCu = 256;
   if (c == 0) return 0;
   const size_t full = c / resident, rem = c % resident;
   if (resident <= kOnePerCu) return (double)full + (rem ? 1.0 : 0.0);
-  return 1.35 * (double)full + (rem == 0 ? 0.0 : (rem <= kOnePerCu ? 1.0 : 1.35));
+  return full_round * (double)full + (rem == 0 ? 0.0 : (rem <= kOnePerCu ? 1.0 : full_round));
 }
 
 void Builder::pack_levels(const std::vector<char> &live) {
   const int32_t nn = (int32_t)nodes_.size();
   const size_t resident = p_.poly_size > 2048 ? 256 : 512;
+  double full_round = (p_.grouping_factor <= 1 && p_.poly_size == 2048 && p_.glwe_dim == 1 && p_.pbs_level == 1) ? 1.55 : 1.35;
+  if (const char *e = getenv("FHES_PACK_FULL_ROUND")) full_round = atof(e) > 1.0 ? atof(e) : full_round;   // developer knob (A/B of the round model)
   int32_t depth = 0;
   for (int32_t j = 0; j < nn; j++)
     if (live[j] && nodes_[j].lut >= 0) depth = std::max(depth, nodes_[j].level);
@@ -348,7 +353,7 @@ void Builder::pack_levels(const std::vector<char> &live) {
   for (int32_t j = 0; j < nn; j++)
     if (live[j] && nodes_[j].lut >= 0) asap_count[nodes_[j].level]++;
   double asap_cost = 0;
-  for (int32_t l = 1; l <= depth; l++) asap_cost += launch_cost(asap_count[l], resident);
+  for (int32_t l = 1; l <= depth; l++) asap_cost += launch_cost(asap_count[l], resident, full_round);
 
   // policy 0: trim a level of >= 512 runnable nodes to whole rounds; policy 1: also trim 257..511 to one one-per-CU round
   const std::vector<int32_t> npred0 = npred;
@@ -372,7 +377,7 @@ void Builder::pack_levels(const std::vector<char> &live) {
       for (size_t i = 0; i < take; i++)
         for (int32_t c : succ[ready[i]])
           if (--npred[c] == 0) next.push_back(c);  // runnable from the next level on
-      cost += launch_cost(take, resident);
+      cost += launch_cost(take, resident, full_round);
       ready.swap(next);
     }
     if (!ready.empty()) throw std::logic_error("pack_levels: nodes left after the last level");

@@ -52,6 +52,7 @@ struct fhes_ctx {
   uint64_t uid = 0;          // unique per context (program images are keyed by it, not by address)
   std::mutex attr_mu;                              // kernel function -> dynamic-LDS size its attribute was set to (engine.hip: ensure_dyn_lds)
   std::map<const void *, size_t> attr_lds;
+  unsigned long long *lat_stamps = nullptr;   // lab: phase stamps of the stamped latency build (variant 26)
   int lat_max = 0;   // launches of at most this many bootstraps take the latency build of the classic blind rotate (0: never)
   hipStream_t stream = nullptr;   // the main lane's stream (== main.stream)
   // Locking: `mu` guards the host-side state (arena free list, LUT registry, lanes, stats).  A program run

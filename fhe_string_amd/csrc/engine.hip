@@ -519,14 +519,21 @@ static int launch_br_v5(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
 }
 
 // the latency build of the classic blind rotate (kernel_br_lat.hip.h): ONE bootstrap on 512 threads, one workgroup per CU
-template <int BL = 23>
+template <int BL = 23, int OPT = 0>
 static int launch_br_lat(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
-  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_lat<18>(ctx, lane, d);
-  auto kern = dev::blind_rotate_lat_kernel<BL>;
+  if (BL == 23 && (OPT & 3) == 0 && ctx->dims.pbs_base_log == 18) return launch_br_lat<18, OPT>(ctx, lane, d);
+  auto kern = dev::blind_rotate_lat_kernel<BL, OPT>;
   if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), dev::kLatLdsBytes)) return rc;
+  if ((OPT >> 7) & 1) {   // lab: phase stamps of the first 256 workgroups, written to $FHES_LAT_STAMPS when the context goes away
+    if (d.v_count > 256) return fail(FHES_ERR_INVALID, "the stamped latency build takes launches of at most 256 bootstraps");
+    if (!ctx->lat_stamps) {
+      FHES_HIP(hipMalloc(&ctx->lat_stamps, (size_t)256 * 8 * dev::kLatStamps * 8));
+      FHES_HIP(hipMemset(ctx->lat_stamps, 0, (size_t)256 * 8 * dev::kLatStamps * 8));
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(dev::kLatThreads), dev::kLatLdsBytes, lane.stream, d, ctx->arena,
                      ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e, ctx->lut_polys, ctx->twist_inv64,
-                     ctx->tw, ctx->psi);
+                     ctx->tw, ctx->psi, ctx->lat_stamps);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
@@ -668,7 +675,20 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   // 2: the latency build (one bootstrap on 512 threads, one workgroup per CU); 3: the throughput build whatever the launch size
   if (variant == 2 || (variant == 0 && ctx->lat_max > 0 && d.v_count <= ctx->lat_max && ctx->dims.N == 2048)) {
     if (ctx->dims.N != 2048) return fail(FHES_ERR_UNSUPPORTED, "the latency build of the blind rotate is written for N = 2048");
-    return launch_br_lat<>(ctx, lane, d);
+    return launch_br_lat<23, dev::lat_opt(0, 0, 0, 1)>(ctx, lane, d);
+  }
+  if (variant >= 20 && variant <= 26) {   // lab builds of the latency kernel (scripts/r05_probe*.sh)
+    if (ctx->dims.N != 2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the lab builds exist for the default set only");
+    using dev::lat_opt;
+    switch (variant) {
+      case 20: return launch_br_lat<23, lat_opt(0, 0, 0, 0)>(ctx, lane, d);
+      case 21: return launch_br_lat<23, lat_opt(0, 0, 1, 0)>(ctx, lane, d);   // half 0 at high priority
+      case 22: return launch_br_lat<23, lat_opt(0, 0, 2, 0)>(ctx, lane, d);   // half 1 at high priority
+      case 23: return launch_br_lat<23, lat_opt(0, 0, 0, 1)>(ctx, lane, d);   // GGSW rows a whole iteration ahead
+      case 24: return launch_br_lat<23, lat_opt(0, 0, 1, 1)>(ctx, lane, d);
+      case 25: return launch_br_lat<23, lat_opt(0, 1, 0, 0)>(ctx, lane, d);   // half barriers through LDS flags
+      default: return launch_br_lat<23, lat_opt(0, 0, 0, 0, 1)>(ctx, lane, d);  // phase stamps
+    }
   }
   if (variant == 0 || variant == 3) variant = 7;
   if (variant != 1 && (variant < 5 || variant > 10) && variant != 13 && variant != 14)
@@ -917,6 +937,15 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
   }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->lat_stamps) {   // lab: the stamped latency build leaves its record behind
+    if (const char *path = getenv("FHES_LAT_STAMPS")) {
+      std::vector<unsigned long long> h((size_t)256 * 8 * dev::kLatStamps);
+      if (hipMemcpy(h.data(), ctx->lat_stamps, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+      }
+    }
+    (void)hipFree(ctx->lat_stamps);
+  }
   (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e_base ? ctx->bsk_e_base : (void *)ctx->bsk_e);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->twist_inv64); (void)hipFree(ctx->root); (void)hipFree(ctx->psi); (void)hipFree(ctx->odd_fix); (void)hipFree(ctx->cdpp); (void)hipFree(ctx->lut_polys);
   (void)hipDeviceSynchronize();
@@ -1148,7 +1177,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  if (v < 0 || v == 11 || v > 14) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
+  if (v < 0 || v == 11 || (v > 14 && v < 20) || v > 26) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
   if (v == 9 || v == 10 || v == 13 || v == 14) {  // timing-only ablations compute WRONG results: a developer has to ask for them by name
     const char *e = getenv("FHES_DEV_ABLATIONS");
     if (!e || std::string(e) != "1")

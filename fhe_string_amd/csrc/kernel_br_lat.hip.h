@@ -99,23 +99,50 @@ __device__ __forceinline__ void lat_inv_stage0_dpp(double2 (&x)[4], double sgn) 
 }
 
 constexpr int kLatThreads = 512;
-constexpr size_t kLatLdsBytes = (size_t)2 * 2048 * 8 + (size_t)3 * 2 * 1024 * 16;  // image + X1 + X2 + S = 128 KB
+// image (32 KB) | X: both exchanges of a half (32 KB; the wave-local C <-> D exchange re-uses the region the wave has just read or
+// is about to write) | S: spectra for the other half, double-buffered by iteration parity (64 KB) | flags of the half barriers (2 KB)
+constexpr size_t kLatLdsBytes = (size_t)2 * 2048 * 8 + (size_t)2 * 1024 * 16 + (size_t)2 * 2 * 1024 * 16 + 2048;
+
+// Barrier among the four waves of ONE half (SYNC = 1).  Of the four barriers of a CMUX only one is a dependence between the
+// halves (the spectra meet in the external product); the exchanges A <-> B and the image of -acc are a half's own.  gfx950 has one
+// s_barrier per workgroup, so a half's barrier is a flag per wave in LDS: the LDS operations of a wave execute in order, so
+// a wave's flag store lands after its data stores, and a wave that has read every flag >= epoch reads the data behind them.
+// Every lane keeps its own flag word (slot [lane][wave]: no EXEC games, the poll is one conflict-free ds_read_b128).
+__device__ __forceinline__ void lat_half_barrier(unsigned flags_lane /* byte address of this lane's 4 flags */, unsigned w, unsigned epoch) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(flags_lane + 4u * w), "v"(epoch) : "memory");
+  for (int spin = 0; spin < (1 << 22); ++spin) {   // bounded: a broken build ends with wrong bits, never with a hung GPU
+    fhes_u32x4 f;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(flags_lane) : "memory");
+    const unsigned m = min(min(f.x, f.y), min(f.z, f.w));
+    if (__builtin_amdgcn_readfirstlane(m) >= epoch) break;   // every lane of a wave stores the same epoch: lane 0 speaks for all
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
 
 // LAT_ABL: timing-only ablations for the lab book (FHES_LAB builds; WRONG results): 1 = without the LDS exchanges and the
 // spectrum hand-over, 2 = without the butterflies
-template <int BL, int LAT_ABL = 0>
+// SYNC: 0 = four workgroup barriers per CMUX; 1 = B1 / B5 / B6 among the waves of a half only (lat_half_barrier), B3 for all;
+// 2 = timing-only ablation WITHOUT B1 / B5 / B6 (racy: wrong results)
+// OPT packs the lab switches: bits 0-1 LAT_ABL, bits 2-3 SYNC, bits 4-5 PRIO (1: the waves of half 0 at high priority for the
+// whole kernel, 2: those of half 1), bit 6 GPF (the GGSW rows of iteration i + 1 requested right behind the external product of
+// iteration i -- a whole iteration ahead, into the registers that have just died -- instead of at the top of iteration i + 1)
+constexpr int lat_opt(int abl, int sync, int prio, int gpf, int stamp = 0) { return abl | (sync << 2) | (prio << 4) | (gpf << 6) | (stamp << 7); }
+constexpr int kLatStamps = 32, kLatStampIter = 300;   // bit 7 STAMP: every wave records s_memtime at the marked points of ONE iteration (lab)
+template <int BL, int OPT = 0>
 __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride, int n_small,
     const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
     const double2 *__restrict__ twist_inv /* twist / (M * 2^64): torus_from_f64_pair */, const double2 *__restrict__ tw,
-    const double2 *__restrict__ psi) {
+    const double2 *__restrict__ psi, unsigned long long *__restrict__ stamps = nullptr) {
   constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2;
+  constexpr int LAT_ABL = OPT & 3, SYNC = (OPT >> 2) & 3, PRIO = (OPT >> 4) & 3, GPF = (OPT >> 6) & 1, STAMP = (OPT >> 7) & 1;
   static_assert(BL >= 1 && BL <= 31, "single-level digit must fit the high dword");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t *img_all = reinterpret_cast<uint64_t *>(smem_raw);                       // [2][N]   image of -acc, plain order
-  double2 *x1_all = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);      // [2][M]   A <-> B exchanges
-  double2 *x2_all = x1_all + 2 * M;                                                 // [2][M]   C <-> D exchanges (wave-local)
-  double2 *s_all = x2_all + 2 * M;                                                  // [2][M]   spectra for the other half
+  double2 *x1_all = reinterpret_cast<double2 *>(smem_raw + (size_t)2 * N * 8);      // [2][M]   A <-> B exchanges ...
+  double2 *x2_all = x1_all;                                                         //          ... and C <-> D (wave-local, same region)
+  double2 *s_all = x1_all + 2 * M;                                                  // [2 parities][2][M]   spectra for the other half
+  const unsigned flags0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw + (unsigned)(2 * N * 8 + 6 * M * 16);
 
   const int tid = threadIdx.x;
   const int r = __builtin_amdgcn_readfirstlane(tid >> 8);        // half = output polynomial
@@ -129,8 +156,26 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
   uint64_t *img = img_all + (size_t)r * N;
   double2 *x1 = x1_all + (size_t)r * M;
   double2 *x2 = x2_all + (size_t)r * M;
-  double2 *s_r = s_all + (size_t)r * M;
+  double2 *s_r = s_all + (size_t)r * M;              // + parity * 2 M
   const double2 *s_o = s_all + (size_t)(1 - r) * M;
+  const unsigned flags_lane = flags0 + (unsigned)r * 1024u + (unsigned)l * 16u;
+  if (SYNC == 1) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(flags_lane + 4u * (unsigned)w), "v"(0u) : "memory");
+  }
+  unsigned epoch = 0;
+  int it_now = -1;
+#define FHES_LAT_STAMP(k)                                                                                         \
+  do {                                                                                                            \
+    if (STAMP && it_now == kLatStampIter) {                                                                       \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                 \
+      if (l == 0) stamps[((size_t)blockIdx.x * 8 + (size_t)(tid >> 6)) * kLatStamps + (k)] = t_;                   \
+    }                                                                                                             \
+  } while (0)
+#define FHES_LAT_HALF_BARRIER()                                           \
+  do {                                                                    \
+    if (SYNC == 0) __syncthreads();                                       \
+    else if (SYNC == 1) lat_half_barrier(flags_lane, (unsigned)w, ++epoch); \
+  } while (0)
 
   // ---- slots of this thread in every layout (element indices inside a half's buffer) ----
   const int blk16 = w * 16 + ((l >> 1) & 15);                 // p >> 4 in layouts D / E
@@ -204,8 +249,23 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
 
   constexpr uint64_t ROUND = (uint64_t)1 << (63 - BL);
   int a_next = modswitch_of(ks[0]);
+  if (PRIO == 1) { if (r == 0) __builtin_amdgcn_s_setprio(3); }
+  if (PRIO == 2) { if (r == 1) __builtin_amdgcn_s_setprio(3); }
+  double2 g0[4], g1[4];
+  auto load_ggsw = [&](int it) __attribute__((always_inline)) {
+    const unsigned so = (unsigned)it * (unsigned)(4 * M * 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned eo = (unsigned)(((e >> 1) * 4 + (e & 1)) * 128 * 16);
+      g0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)(0 * 16 * 128 * 16) + eo);
+      g1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)(1 * 16 * 128 * 16) + eo);
+    }
+  };
+  if (GPF) load_ggsw(0);
   for (int i = 0; i < n_small; ++i) {
     const int a = a_next;
+    it_now = i;
+    FHES_LAT_STAMP(0);
     double2 x[4];
     // ---- digits of X^a acc - acc at the own coefficients p (re) and p + M (im) ----
     {
@@ -240,26 +300,21 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
     const uint64_t ks_next = ks[i + 1];
-    // GGSW rows of this iteration: requested a whole forward transform ahead
-    double2 g0[4], g1[4];
-    {
-      const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned eo = (unsigned)(((e >> 1) * 4 + (e & 1)) * 128 * 16);
-        g0[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)(0 * 16 * 128 * 16) + eo);
-        g1[e] = buf_load_d2(rs_g, voff_g, so + (unsigned)(1 * 16 * 128 * 16) + eo);
-      }
-    }
+    // GGSW rows of this iteration: requested a whole forward transform ahead (GPF: a whole iteration ahead, below)
+    if (!GPF) load_ggsw(i);
     // ---- forward transform ----
+    FHES_LAT_STAMP(1);
     if (LAT_ABL != 2) lat_fwd_pass(x, fA_hi, fA_lo0, fA_lo1);                  // bits 9, 8
+    FHES_LAT_STAMP(2);
     if (LAT_ABL != 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x1[sA[e]] = x[e];
     }
     a_next = modswitch_of(ks_next);
     asm volatile("" : "+s"(a_next));
-    __syncthreads();  // B1 (also: every rotated read of the image is done)
+    FHES_LAT_STAMP(3);
+    FHES_LAT_HALF_BARRIER();  // B1: the half's own (also: every rotated read of its image is done)
+    FHES_LAT_STAMP(4);
     if (LAT_ABL != 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[e] = x1[sB[e]];
@@ -269,6 +324,7 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     lat_transpose_e0_l5(x);
     lat_transpose_e1_l4(x);                                                     // -> L_C
     if (LAT_ABL != 2) lat_fwd_pass(x, fC_hi, fC_lo0, fC_lo1);                  // bits 5, 4
+    FHES_LAT_STAMP(5);
     if (LAT_ABL != 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x2[sC[e]] = x[e];
@@ -277,6 +333,7 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
       for (int e = 0; e < 4; ++e) x[e] = x2[sD[e]];
       __builtin_amdgcn_sched_barrier(0);
     }
+    FHES_LAT_STAMP(6);
     if (LAT_ABL != 2) lat_fwd_pass(x, fD_hi, fD_lo0, fD_lo1);                  // bits 3, 2
     lat_transpose_e0_l5(x);                                                     // -> L_E
     if (LAT_ABL != 2) {
@@ -284,11 +341,15 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
       fwd_butterfly(x[2], x[3], fE_1);
       lat_fwd_stage0_dpp(x, cd);                                                // bit 0
     }
+    FHES_LAT_STAMP(7);
     if (LAT_ABL != 1) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s_r[e * 256 + q] = x[e];
+      for (int e = 0; e < 4; ++e) s_r[(i & 1) * 2 * M + e * 256 + q] = x[e];
     }
-    __syncthreads();  // B3
+    FHES_LAT_STAMP(8);
+    __syncthreads();  // B3: the one dependence between the halves.  S alternates between two buffers: with the halves free of
+                      // each other in between, a half may write its next spectrum while the other still reads this one
+    FHES_LAT_STAMP(9);
     // ---- external product: D0 G[0][r] + D1 G[1][r] ----
     if (LAT_ABL == 1) {
 #pragma unroll
@@ -296,7 +357,7 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     } else if (r == 0) {
       double2 oth[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) oth[e] = s_o[e * 256 + q];
+      for (int e = 0; e < 4; ++e) oth[e] = s_o[(i & 1) * 2 * M + e * 256 + q];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[e] = ext_mac(x[e], oth[e], g0[e], g1[e]);
@@ -304,12 +365,14 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     } else {
       double2 oth[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) oth[e] = s_o[e * 256 + q];
+      for (int e = 0; e < 4; ++e) oth[e] = s_o[(i & 1) * 2 * M + e * 256 + q];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[e] = ext_mac(oth[e], x[e], g0[e], g1[e]);
       asm volatile("; end of form r = 1");
     }
+    FHES_LAT_STAMP(10);
+    if (GPF) load_ggsw(i + 1 < n_small ? i + 1 : i);   // (the last request is a repeat: in range, unused)
     // ---- inverse transform ----
     if (LAT_ABL != 2) {
       lat_inv_stage0_dpp(x, sgn);                                               // bit 0
@@ -318,6 +381,7 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     }
     lat_transpose_e0_l5(x);                                                     // -> L_D
     if (LAT_ABL != 2) lat_inv_pass(x, iD_lo, iD_hi0, iD_hi1);                  // bits 2, 3
+    FHES_LAT_STAMP(11);
     if (LAT_ABL != 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x2[sD[e]] = x[e];
@@ -326,21 +390,26 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
       for (int e = 0; e < 4; ++e) x[e] = x2[sC[e]];
       __builtin_amdgcn_sched_barrier(0);
     }
+    FHES_LAT_STAMP(12);
     if (LAT_ABL != 2) lat_inv_pass(x, iC_lo, iC_hi0, iC_hi1);                  // bits 4, 5
     lat_transpose_e0_l5(x);
     lat_transpose_e1_l4(x);                                                     // -> L_B
     if (LAT_ABL != 2) lat_inv_pass(x, iB_lo, iB_hi0, iB_hi1);                  // bits 6, 7
+    FHES_LAT_STAMP(13);
     if (LAT_ABL != 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x1[sB[e]] = x[e];
     }
-    __syncthreads();  // B5
+    FHES_LAT_STAMP(14);
+    FHES_LAT_HALF_BARRIER();  // B5: the half's own
+    FHES_LAT_STAMP(15);
     if (LAT_ABL != 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[e] = x1[sA[e]];
       __builtin_amdgcn_sched_barrier(0);
     }
     if (LAT_ABL != 2) lat_inv_pass(x, iA_lo, iA_hi0, iA_hi1);                  // bits 8, 9
+    FHES_LAT_STAMP(16);
     // ---- untwist (negated factors: -y), round, nacc += rint(-y); the image goes back ----
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -350,8 +419,13 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
       img[q + 256 * e] = nlo[e];
       img[q + 256 * e + M] = nhi[e];
     }
-    __syncthreads();  // B6
+    FHES_LAT_STAMP(17);
+    FHES_LAT_HALF_BARRIER();  // B6: the half's own (a half rotates its own polynomial)
+    FHES_LAT_STAMP(18);
   }
+#undef FHES_LAT_HALF_BARRIER
+#undef FHES_LAT_STAMP
+  __syncthreads();
 
   // ---- sample extract from the image of -acc: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
   uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;

@@ -157,7 +157,7 @@ def test_all_blind_rotate_variants_agree(libs):
     outs = np.arange(h_out, h_out + count, dtype=np.int32)
     ref = np.stack([w.oracle_pbs(cts[i], poly) for i in range(4)])
     try:
-        for variant in (1, 2, 3, 5, 6, 7, 8):   # 2: the latency build (512 threads), 3: the throughput build at any size
+        for variant in (1, 2, 3, 5, 6, 7, 8, 20, 21, 22, 23, 24, 25):   # 2: the latency build (512 threads; 20 / 21: its two barrier forms), 3: the throughput build at any size
             check(w.lib.fhes_set_kernel_variant(ctx, variant))
             check(w.lib.fhes_pbs_batch(ctx, count, ptr(term_ptr), ptr(term_idx), ptr(term_coef), ptr(consts),
                                        ptr(lut_ids), ptr(outs)))
