@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FHES_LIB: developer knob -- another build of the same library (compiler-flag A/B runs, scripts/flag_ab.sh)
-LIB_PATH = os.environ.get("FHES_LIB") or os.path.join(_HERE, "libfhe_string_amd.so")
+LIB_PATH = os.environ.get("FHES_LIB") or os.path.join(_HERE, "libfhe_string_amd_lab.so" if os.environ.get("FHES_LAB") == "1" else "libfhe_string_amd.so")
 
 
 class Params(C.Structure):

@@ -10,7 +10,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "fhe_string_amd", "csrc")
-LIB = os.path.join(ROOT, "fhe_string_amd", "libfhe_string_amd.so")
+# FHES_LAB=1: the lab build (-DFHES_LAB) with the retired kernel variants, timing-only ablations and developer knobs the
+# scripts/ use; a separate file, never what the tests or the bench load unless FHES_LAB=1 is set for them as well
+LAB = os.environ.get("FHES_LAB") == "1"
+LIB = os.path.join(ROOT, "fhe_string_amd", "libfhe_string_amd_lab.so" if LAB else "libfhe_string_amd.so")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -45,7 +48,7 @@ def _all_deps():
 def build_product(force=False, verbose=True):
     if not force and not _newer(LIB, _all_deps()):
         return LIB
-    cmd = [HIPCC] + HIP_FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + product_sources()
+    cmd = [HIPCC] + HIP_FLAGS + (["-DFHES_LAB"] if LAB else []) + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + product_sources()
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -474,6 +474,7 @@ static int ensure_dyn_lds(fhes_ctx *ctx, const void *fn, size_t lds) {
   return FHES_OK;
 }
 
+#ifdef FHES_LAB
 template <int LOGN>
 static int launch_br_v1(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
@@ -486,6 +487,7 @@ static int launch_br_v1(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
+#endif  // FHES_LAB
 
 template <int LOGN, int G, bool PIPE, bool LAT = false, int BL = 23, bool ILV = false>
 static int launch_br_mb(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
@@ -538,6 +540,7 @@ static int launch_br_lat(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+#ifdef FHES_LAB
 // variant 8: three workgroups per CU (48 KB of LDS, <= 168 registers); N = 2048 only
 template <int BL = 23, int ABL = 0>
 static int launch_br_v8(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
@@ -561,6 +564,7 @@ static int launch_br_v8(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
+#endif  // FHES_LAB
 
 // generic shapes (k <= 3, L <= 3, N = 256 .. 8192): blind_rotate_gen_kernel with its per-workgroup global scratch
 static size_t gen_scratch_per_wg(const Dims &d) {
@@ -605,7 +609,7 @@ static int launch_br_gen_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 // N = 8192 (glwe_dim 1): one thread group per ciphertext, products accumulated in registers (blind_rotate_big_kernel);
-// FHES_GEN_BIG=0 keeps the generic kernel (the tests compare the two)
+// (a lab build keeps the generic kernel at this size behind FHES_GEN_BIG=0)
 template <int LOGN, int LV>
 static int launch_br_big_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   constexpr int N = 1 << LOGN, M = N / 2;
@@ -627,8 +631,12 @@ static int launch_br_big_n(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 static bool use_big_kernel(const Dims &dm) {
-  static const bool off = getenv("FHES_GEN_BIG") && atoi(getenv("FHES_GEN_BIG")) == 0;
-  return !off && dm.k == 1 && dm.N == 8192;
+#ifdef FHES_LAB   // FHES_GEN_BIG=0: the generic kernel at N = 8192 (spills 48 / 114 registers: lab only since round 5)
+  if (const char *e = getenv("FHES_GEN_BIG")) {
+    if (atoi(e) == 0) return false;
+  }
+#endif
+  return dm.k == 1 && dm.N == 8192;
 }
 static int launch_br_gen(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   if (use_big_kernel(ctx->dims)) {
@@ -644,15 +652,22 @@ static int launch_br_gen(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
     case 1024: return launch_br_gen_n<10>(ctx, lane, d);
     case 2048: return launch_br_gen_n<11>(ctx, lane, d);
     case 4096: return launch_br_gen_n<12>(ctx, lane, d);
+#ifdef FHES_LAB
     case 8192: return launch_br_gen_n<13>(ctx, lane, d);
+#endif
     default: return fail(FHES_ERR_UNSUPPORTED, "poly_size %d", ctx->dims.N);
   }
 }
 
-// variant: 0 = auto (variant 7), 1 = the simple kernel, 5 / 6 / 7 = the throughput kernel with three wave-priority
-// policies (5: head of an iteration at high priority, 6: static by wave slot, 7: no hints -- the default since the
-// schedule trims of round 3: 0.1 / 0.5 / 1.2 % ahead of 5 at 16 384 / 5 120 / 1 536 ciphertexts in alternating runs);
-// all produce the same bits.  (Variants 2-4 of earlier rounds are gone.)
+// Blind-rotate builds of the classic 2_2 sets.  The PRODUCT library holds what `fhes_set_kernel_variant(ctx, 0)` can choose
+// (VERDICT r4 item 8):
+//   0   auto: the latency build for launches of at most one workgroup per CU (ctx->lat_max), the throughput build above
+//   2   the latency build (kernel_br_lat.hip.h: one bootstrap on 512 threads; N = 2048)
+//   3   the throughput build at every launch size (blind_rotate_v5_kernel, no priority hints; 7 = its number of rounds 2-4)
+//   12  the generic kernel on a 2_2 set (the second implementation the tests compare with)
+// A lab build (-DFHES_LAB: FHES_LAB=1 python -m fhe_string_amd.build, scripts/) also carries the simple reference kernel (1),
+// the two wave-priority policies of the throughput kernel (5, 6), variant 8 (three workgroups per CU, 28 % slower) and the
+// timing-only ablations with WRONG results (9, 10, 13, 14; 20-26: switches of the latency build).  All correct ones: same bits.
 static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   if (ctx->dims.g > 1) {
     // multi-bit parameter sets: one kernel in three builds -- latency (launches of at most one
@@ -670,51 +685,45 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
     if (ctx->dims.N == 2048) return lat ? launch_br_mb<11, 2, true, true>(ctx, lane, d) : launch_br_mb<11, 2, false>(ctx, lane, d);
     return lat ? launch_br_mb<8, 2, true, true>(ctx, lane, d) : launch_br_mb<8, 2, false>(ctx, lane, d);
   }
-  if (!fast_shape(ctx->p) || ctx->br_variant == 12) return launch_br_gen(ctx, lane, d);  // 12: the generic kernel on a 2_2 set (tests)
-  int variant = ctx->br_variant;
-  // 2: the latency build (one bootstrap on 512 threads, one workgroup per CU); 3: the throughput build whatever the launch size
-  if (variant == 2 || (variant == 0 && ctx->lat_max > 0 && d.v_count <= ctx->lat_max && ctx->dims.N == 2048)) {
-    if (ctx->dims.N != 2048) return fail(FHES_ERR_UNSUPPORTED, "the latency build of the blind rotate is written for N = 2048");
+  if (!fast_shape(ctx->p) || ctx->br_variant == 12) return launch_br_gen(ctx, lane, d);
+  const int variant = ctx->br_variant;
+  const bool n2048 = ctx->dims.N == 2048;
+  if (variant == 2 || (variant == 0 && n2048 && ctx->lat_max > 0 && d.v_count <= ctx->lat_max)) {
+    if (!n2048) return fail(FHES_ERR_UNSUPPORTED, "the latency build of the blind rotate is written for N = 2048");
     return launch_br_lat<23, dev::lat_opt(0, 0, 0, 1)>(ctx, lane, d);
   }
-  if (variant >= 20 && variant <= 26) {   // lab builds of the latency kernel (scripts/r05_probe*.sh)
-    if (ctx->dims.N != 2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the lab builds exist for the default set only");
+  if (variant == 0 || variant == 3 || variant == 7) return n2048 ? launch_br_v5<11, 2>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
+#ifdef FHES_LAB
+  if (variant >= 20 && variant <= 26) {   // switches of the latency build (scripts/r05_probe*.sh)
+    if (!n2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the lab builds exist for the default set only");
     using dev::lat_opt;
     switch (variant) {
       case 20: return launch_br_lat<23, lat_opt(0, 0, 0, 0)>(ctx, lane, d);
-      case 21: return launch_br_lat<23, lat_opt(0, 0, 1, 0)>(ctx, lane, d);   // half 0 at high priority
-      case 22: return launch_br_lat<23, lat_opt(0, 0, 2, 0)>(ctx, lane, d);   // half 1 at high priority
-      case 23: return launch_br_lat<23, lat_opt(0, 0, 0, 1)>(ctx, lane, d);   // GGSW rows a whole iteration ahead
-      case 24: return launch_br_lat<23, lat_opt(0, 0, 1, 1)>(ctx, lane, d);
-      case 25: return launch_br_lat<23, lat_opt(0, 1, 0, 0)>(ctx, lane, d);   // half barriers through LDS flags
+      case 21: return launch_br_lat<23, lat_opt(0, 1, 0, 0)>(ctx, lane, d);     // half barriers through LDS flags
+      case 22: return launch_br_lat<23, lat_opt(0, 2, 0, 0)>(ctx, lane, d);     // WRONG results: no half barriers
+      case 23: return launch_br_lat<23, lat_opt(1, 0, 0, 0)>(ctx, lane, d);     // WRONG results: no LDS exchanges
+      case 24: return launch_br_lat<23, lat_opt(2, 0, 0, 0)>(ctx, lane, d);     // WRONG results: no butterflies
+      case 25: return launch_br_lat<23, lat_opt(0, 0, 1, 1)>(ctx, lane, d);     // half 0 at high priority
       default: return launch_br_lat<23, lat_opt(0, 0, 0, 0, 1)>(ctx, lane, d);  // phase stamps
     }
   }
-  if (variant == 0 || variant == 3) variant = 7;
-  if (variant != 1 && (variant < 5 || variant > 10) && variant != 13 && variant != 14)
-    return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d does not exist (1, 5, 6, 7, 8; 9, 10, 13 and 14 are timing-only ablations)", variant);
   if (variant == 8) {
-    if (ctx->dims.N != 2048) return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant 8 is written for N = 2048");
+    if (!n2048) return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant 8 is written for N = 2048");
     return launch_br_v8<>(ctx, lane, d);
   }
   if (variant == 13 || variant == 14) {  // timing-only ablations of variant 8 (WRONG results)
-    if (ctx->dims.N != 2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the ablation builds exist for the default set only");
+    if (!n2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the ablation builds exist for the default set only");
     return variant == 13 ? launch_br_v8<23, 1>(ctx, lane, d) : launch_br_v8<23, 2>(ctx, lane, d);
   }
-  if (ctx->dims.pbs_base_log != 23 && variant == 1)
-    return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant 1 is instantiated for pbs_base_log 23 only");
-  if (ctx->dims.N == 2048) {
-    switch (variant) {
-      case 1: return launch_br_v1<11>(ctx, lane, d);
-      case 5: return launch_br_v5<11, 0>(ctx, lane, d);
-      case 6: return launch_br_v5<11, 1>(ctx, lane, d);
-      case 7: return launch_br_v5<11, 2>(ctx, lane, d);
-      case 9: return launch_br_v5<11, 4>(ctx, lane, d);   // timing-only ablation: no LDS exchanges (WRONG results)
-      default: return launch_br_v5<11, 5>(ctx, lane, d);  // timing-only ablation: no butterflies (WRONG results)
-    }
+  if (variant == 1) {
+    if (ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant 1 is instantiated for pbs_base_log 23 only");
+    return n2048 ? launch_br_v1<11>(ctx, lane, d) : launch_br_v1<8>(ctx, lane, d);
   }
-  if (variant > 7) return fail(FHES_ERR_UNSUPPORTED, "the ablation builds exist for N = 2048 only");
-  return variant == 1 ? launch_br_v1<8>(ctx, lane, d) : variant == 5 ? launch_br_v5<8>(ctx, lane, d) : variant == 6 ? launch_br_v5<8, 1>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
+  if (variant == 5) return n2048 ? launch_br_v5<11, 0>(ctx, lane, d) : launch_br_v5<8, 0>(ctx, lane, d);
+  if (variant == 6) return n2048 ? launch_br_v5<11, 1>(ctx, lane, d) : launch_br_v5<8, 1>(ctx, lane, d);
+  if ((variant == 9 || variant == 10) && n2048) return variant == 9 ? launch_br_v5<11, 4>(ctx, lane, d) : launch_br_v5<11, 5>(ctx, lane, d);
+#endif
+  return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d is not in this build (0, 2, 3, 7, 12; a lab build has the others)", variant);
 }
 
 static int take_event(fhes_ctx *ctx, hipEvent_t *e) {
@@ -1033,13 +1042,16 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
     FHES_HIP(hipGetLastError());
     if (fast_shape(ctx->p)) {  // the register-order layout of the throughput kernels
       if (!ctx->bsk_e) {
-        // developer knob (round-4 experiment: does the multi-bit kernel's rate depend on where the key lies?): FHES_BSK_E_PAD bytes in
-        // front of the engine-layout key.  The padded allocation is released through bsk_e_base.
-        const char *pad_s = getenv("FHES_BSK_E_PAD");
-        const size_t pad = pad_s ? (size_t)strtoull(pad_s, nullptr, 0) & ~(size_t)255 : 0;
+        size_t pad = 0;
+#ifdef FHES_LAB   // round-4 experiment (does the multi-bit kernel's rate depend on where the key lies?): FHES_BSK_E_PAD bytes, at
+                  // most 1 GiB, in front of the engine-layout key; the padded allocation is released through bsk_e_base
+        if (const char *pad_s = getenv("FHES_BSK_E_PAD")) pad = std::min<size_t>((size_t)strtoull(pad_s, nullptr, 0) & ~(size_t)255, (size_t)1 << 30);
+#endif
         FHES_HIP(hipMalloc(&ctx->bsk_e_base, npoly * d.M * 16 + pad));
         ctx->bsk_e = reinterpret_cast<double2 *>(reinterpret_cast<unsigned char *>(ctx->bsk_e_base) + pad);
+#ifdef FHES_LAB
         if (getenv("FHES_DEBUG_ADDR")) fprintf(stderr, "[fhes] bsk_e at %p (%zu bytes, pad %zu)\n", (void *)ctx->bsk_e, npoly * d.M * 16, pad);
+#endif
       }
       // multi-bit keys: the 2^g GGSWs of a group interleaved row by row (round 4: g = 3 runs 7-10 % faster from it in alternating
       // same-run launches, profiles/r04_ab_multibit_layout.txt).  Default: on for g = 3; FHES_MB_INTERLEAVE=0 / 1 forces it.
@@ -1177,12 +1189,21 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  if (v < 0 || v == 11 || (v > 14 && v < 20) || v > 26) return fail(FHES_ERR_INVALID, "unknown blind-rotate variant %d", v);
-  if (v == 9 || v == 10 || v == 13 || v == 14) {  // timing-only ablations compute WRONG results: a developer has to ask for them by name
+  const bool product = v == 0 || v == 2 || v == 3 || v == 7 || v == 12;
+#ifdef FHES_LAB
+  const bool wrong = v == 9 || v == 10 || v == 13 || v == 14 || (v >= 22 && v <= 24);   // timing-only ablations
+  const bool lab = v == 1 || v == 5 || v == 6 || v == 8 || wrong || (v >= 20 && v <= 26);
+  if (wrong) {   // a developer has to ask for wrong results by name
     const char *e = getenv("FHES_DEV_ABLATIONS");
     if (!e || std::string(e) != "1")
-      return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variants 9 / 10 / 13 / 14 are timing-only ablations with wrong results (set FHES_DEV_ABLATIONS=1)");
+      return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d is a timing-only ablation with wrong results (set FHES_DEV_ABLATIONS=1)", v);
   }
+#else
+  const bool lab = false;
+#endif
+  if (!product && !lab)
+    return fail(v < 0 || v > 26 ? FHES_ERR_INVALID : FHES_ERR_UNSUPPORTED,
+                "blind-rotate variant %d is not in this build (0 = auto, 2 = latency build, 3 / 7 = throughput build, 12 = generic kernel)", v);
   ctx->br_variant = v;
   return FHES_OK;
 }

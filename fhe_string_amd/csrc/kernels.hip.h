@@ -547,6 +547,7 @@ __global__ __launch_bounds__(256) void linear_kernel(NodeDesc d, uint64_t *__res
 // K2+K3 (variant 1): blind rotate + sample extract, one workgroup (2 * M/8 threads) per
 // ciphertext, k = 1, pbs_level = 1.  LDS: acc u64[2][N] | fbuf double2[2][M] | a_tilde.
 // ------------------------------------------------------------------------------------------
+#ifdef FHES_LAB  // the simple reference build (variant 1): lab only since round 5
 template <int LOGN, int BL>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) void blind_rotate_v1_kernel(NodeDesc d, uint64_t *__restrict__ arena, int ct_stride,
                                        const uint64_t *__restrict__ ks_out, int ks_stride,
@@ -648,6 +649,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8)) vo
   if (tid == 0) out[N] = acc[N];
 }
 
+#endif  // FHES_LAB
 // ------------------------------------------------------------------------------------------
 // K2+K3 (generic): blind rotate + sample extract for EVERY classic parameter shape the public constructor
 // accepts (`generate_keys_with_params(p: ClassicPBSParameters, l)`, /root/reference/src/lib.rs:50-62):
@@ -1543,6 +1545,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 2)
   if (tid == 0) out[N] = (uint64_t)0 - img[(size_t)2 * M + image_word<LOGM>(0)];
 }
 
+#ifdef FHES_LAB  // variant 8 (three workgroups per CU: measured 28 % slower, profiles/r04_probe5_variant8.txt): lab only since round 5
 // ------------------------------------------------------------------------------------------
 // K2+K3 (variant 8, round 4): variant 5 on a diet -- THREE workgroups per CU.  The synthetic kernel with variant 5's
 // instruction counts (scripts/micro/lds_valu_gate.hip, structure "K") says what a third resident workgroup is worth: 4.3-4.6 k
@@ -1867,6 +1870,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 3)
   }
   if (tid == 0) out[N] = (uint64_t)0 - img[(size_t)2 * M + image_word<LOGM>(0)];
 }
+#endif  // FHES_LAB
 
 // ------------------------------------------------------------------------------------------
 // K4: multi-bit blind rotate (grouping factor G = 2 or 3) + sample extract.  Same transforms,

@@ -156,8 +156,13 @@ def test_all_blind_rotate_variants_agree(libs):
     lut_ids = np.full(count, lid, dtype=np.int32)
     outs = np.arange(h_out, h_out + count, dtype=np.int32)
     ref = np.stack([w.oracle_pbs(cts[i], poly) for i in range(4)])
+    # the product library: 0 = auto (the latency build at this launch size), 2 = the latency build (one bootstrap on 512 threads),
+    # 3 / 7 = the throughput build, 12 = the generic kernel (an independent implementation); a lab build (FHES_LAB=1) adds the
+    # retired ones: 1 the simple kernel, 5 / 6 priority policies, 8 three workgroups per CU, 20 / 21 / 25 switches of the latency build
+    lab = os.environ.get("FHES_LAB") == "1"
+    variants = (12, 0, 2, 3, 7) + ((1, 5, 6, 8, 20, 21, 25) if lab else ())
     try:
-        for variant in (1, 2, 3, 5, 6, 7, 8, 20, 21, 22, 23, 24, 25):   # 2: the latency build (512 threads; 20 / 21: its two barrier forms), 3: the throughput build at any size
+        for variant in variants:
             check(w.lib.fhes_set_kernel_variant(ctx, variant))
             check(w.lib.fhes_pbs_batch(ctx, count, ptr(term_ptr), ptr(term_idx), ptr(term_coef), ptr(consts),
                                        ptr(lut_ids), ptr(outs)))
@@ -165,14 +170,15 @@ def test_all_blind_rotate_variants_agree(libs):
             check(w.lib.fhes_arena_download(ctx, h_out, count, ptr(res)))
             assert np.array_equal(res[:4], ref), f"variant {variant} differs from the oracle"
             assert list(w.decrypt(res)) == [(5 * int(v) + 3) % 16 for v in vals], f"variant {variant}"
-            if variant == 1:
+            if variant == variants[0]:
                 first = res
             else:
-                assert np.array_equal(res, first), f"variant {variant} differs from variant 1"
-        # the timing-only ablation builds (wrong results by construction) are refused unless a developer asks by name
-        if os.environ.get("FHES_DEV_ABLATIONS") != "1":
-            for variant in (9, 10):
-                assert w.lib.fhes_set_kernel_variant(ctx, variant) != 0
+                assert np.array_equal(res, first), f"variant {variant} differs from the generic kernel"
+        # what is not in the build is refused, and so are the timing-only ablations (wrong results by construction) unless a
+        # developer asks by name
+        refused = (9, 10, 13, 14, 22, 23, 24) if (lab and os.environ.get("FHES_DEV_ABLATIONS") != "1") else (() if lab else (1, 5, 6, 8, 9, 10, 13, 14, 20, 26))
+        for variant in refused + (11, 99, -1):
+            assert w.lib.fhes_set_kernel_variant(ctx, variant) != 0, variant
     finally:
         check(w.lib.fhes_set_kernel_variant(ctx, 0))
     check(w.lib.fhes_arena_free(ctx, h_in, count))
