@@ -22,6 +22,10 @@ mod trim;
 /// Owned handle of an engine ciphertext object.
 pub(crate) struct Ct(pub(crate) *mut ffi::FhesCt);
 
+// The reference's own signatures need its ciphertext types to be `Sync` (`index_of_unchecked<T: Sync>`, mod.rs:292; `&FheString`
+// shared by rayon workers, search.rs:34-40).  The engine object changes residency behind `&self` (first use as an operand
+// uploads, decrypt downloads): those changes are serialised inside the object (csrc/objects.cpp, `fhes_ct::mu`), everything
+// else is read-only, so shared access from several threads is sound.
 unsafe impl Send for Ct {}
 unsafe impl Sync for Ct {}
 
@@ -63,8 +67,12 @@ impl Ct {
 }
 
 impl Clone for Ct {
+    /// Device-side copy (`fhes_ct_clone`): a device-resident object is duplicated in the arena, nothing crosses PCIe; the
+    /// reference clones ciphertexts freely (compare.rs:155-160, mod.rs:250-263, split.rs:322-325).
     fn clone(&self) -> Self {
-        Ct::from_bytes(&self.to_bytes()).expect("ciphertext blob round trip")
+        let h = unsafe { ffi::fhes_ct_clone(self.0) };
+        assert!(!h.is_null(), "{}", last_error());
+        Ct(h)
     }
 }
 

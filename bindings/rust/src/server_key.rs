@@ -54,18 +54,29 @@ impl ServerKey {
         assert!(rc == 0, "{}", last_error());
     }
 
-    /// serde (server_key.rs:11 derives it): standard-domain key material as one blob.  The device holds the keys in
-    /// the Fourier domain only, so the blob is made from the client key (`fhes_server_key_serialize`).
-    pub fn serialize_from(ck: &ClientKey) -> Vec<u8> {
-        let n = unsafe { ffi::fhes_server_key_serialize(ck.k, std::ptr::null_mut(), 0) };
+    /// serde (server_key.rs:11 derives it): THIS key as one blob of standard-domain words -- whether it was made from a
+    /// client key, restored from a blob or received by a key broadcast; no client key needed (`fhes_server_key_serialize`).
+    pub fn to_bytes(&self) -> Vec<u8> {
+        let n = unsafe { ffi::fhes_server_key_serialize(self.k, std::ptr::null_mut(), 0) };
         assert!(n > 0, "{}", last_error());
         let mut buf = vec![0u8; n as usize];
-        let m = unsafe { ffi::fhes_server_key_serialize(ck.k, buf.as_mut_ptr(), n) };
+        let m = unsafe { ffi::fhes_server_key_serialize(self.k, buf.as_mut_ptr(), n) };
         assert!(m == n, "{}", last_error());
         buf
     }
 
-    /// Restores a key on `device` from a blob of [`ServerKey::serialize_from`]; needs no client key.
+    /// The same blob made on the client, where the key was generated, without a device
+    /// (`fhes_client_key_serialize_server_key`).
+    pub fn serialize_from(ck: &ClientKey) -> Vec<u8> {
+        let n = unsafe { ffi::fhes_client_key_serialize_server_key(ck.k, std::ptr::null_mut(), 0) };
+        assert!(n > 0, "{}", last_error());
+        let mut buf = vec![0u8; n as usize];
+        let m = unsafe { ffi::fhes_client_key_serialize_server_key(ck.k, buf.as_mut_ptr(), n) };
+        assert!(m == n, "{}", last_error());
+        buf
+    }
+
+    /// Restores a key on `device` from a blob of [`ServerKey::to_bytes`] / [`ServerKey::serialize_from`]; needs no client key.
     pub fn from_bytes(data: &[u8], device: i32) -> Result<Self, Box<dyn std::error::Error>> {
         let k = unsafe { ffi::fhes_server_key_deserialize(data.as_ptr(), data.len() as i64, device) };
         if k.is_null() {
@@ -89,6 +100,13 @@ impl Drop for ServerKey {
 impl Debug for ServerKey {
     fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
         f.debug_struct("ServerKey").finish()
+    }
+}
+
+#[cfg(feature = "serde")]
+impl serde::Serialize for ServerKey {
+    fn serialize<S: serde::Serializer>(&self, s: S) -> Result<S::Ok, S::Error> {
+        serde::Serialize::serialize(&self.to_bytes(), s)
     }
 }
 

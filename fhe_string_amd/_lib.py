@@ -22,7 +22,7 @@ class Stats(C.Structure):
                 ("arena_capacity", C.c_uint64), ("arena_in_use", C.c_uint64),
                 ("last_ks_ms", C.c_double), ("last_br_ms", C.c_double),
                 ("total_ks_ms", C.c_double), ("total_br_ms", C.c_double),
-                ("timed_launches", C.c_uint64)]
+                ("timed_launches", C.c_uint64), ("host_bytes_up", C.c_uint64), ("host_bytes_down", C.c_uint64)]
 
 
 class FheError(RuntimeError):
@@ -111,6 +111,9 @@ SIGNATURES = {
     "fhes_ct_slice": (_P, [_P, _P, C.c_int32, C.c_int32]),
     "fhes_ct_concat": (_P, [_P, _P, C.c_int32]),
     "fhes_server_key_serialize": (C.c_int64, [_P, _P, C.c_int64]),
+    "fhes_client_key_serialize_server_key": (C.c_int64, [_P, _P, C.c_int64]),
+    "fhes_ct_clone": (_P, [_P]),
+    "fhes_download_keys": (C.c_int, [_P, _P, _P]),
     "fhes_server_key_deserialize": (_P, [_P, C.c_int64, C.c_int32]),
     "fhes_string_op": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _i32p]),
     # multi-GPU (one process per GPU)

@@ -103,13 +103,21 @@ class ServerKey:
         self.num_blocks_char = client_key.num_blocks_char
         self.params = client_key.params
 
+    def to_bytes(self):
+        """server_key.rs:11 (`#[derive(Serialize)] struct ServerKey`): THIS key -- made from a client key, restored from a blob or
+        received by a key broadcast -- as one versioned blob of standard-domain words (fhes_server_key_serialize; no client key)."""
+        n = check(_L().fhes_server_key_serialize(self._h, None, 0))
+        buf = (C.c_uint8 * n)()
+        check(_L().fhes_server_key_serialize(self._h, buf, n))
+        return bytes(buf)
+
     @staticmethod
     def serialize(client_key):
-        """server_key.rs:11 (`#[derive(Serialize)]`): the standard-domain bootstrapping and keyswitching keys of `client_key`
-        as one versioned blob (fhes_server_key_serialize; 170 MB for the default set)."""
-        n = check(_L().fhes_server_key_serialize(client_key._h, None, 0))
+        """The same blob made on the CLIENT, where the key was generated, without a device
+        (fhes_client_key_serialize_server_key; 109 MB for the default set)."""
+        n = check(_L().fhes_client_key_serialize_server_key(client_key._h, None, 0))
         buf = (C.c_uint8 * n)()
-        check(_L().fhes_server_key_serialize(client_key._h, buf, n))
+        check(_L().fhes_client_key_serialize_server_key(client_key._h, buf, n))
         return bytes(buf)
 
     @staticmethod
@@ -196,6 +204,13 @@ class _Ct:
         deg, noi = (C.c_uint8 * n)(), (C.c_uint8 * n)()
         check(_L().fhes_ct_block_meta(self._h, deg, noi))
         return list(deg), list(noi)
+
+    def clone(self):
+        """`Clone` (the reference clones ciphertexts freely: compare.rs:155-160, mod.rs:250-263): a device-resident object is
+        copied on the device (fhes_ct_clone), nothing crosses PCIe"""
+        return type(self)(check_ptr(_L().fhes_ct_clone(self._h)))
+
+    __copy__ = clone
 
     def to_bytes(self):
         n = check(_L().fhes_ct_serialize(self._h, None, 0))

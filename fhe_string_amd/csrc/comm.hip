@@ -450,6 +450,10 @@ int fhes_comm_broadcast_keys(fhes_comm *c, int32_t root) {
   if (rc == FHES_OK && has_pk) ctx->ks_n_wb = n_wb;
   if (rc == FHES_OK) rc = dev_broadcast(c, ctx->ksk_bias, bias_b, root);
   if (rc == FHES_OK) rc = dev_broadcast(c, ctx->bsk_f, bsk_b, root);
+  {   // the standard-domain words travel too (same size: N u64 per polynomial = M double2), so that every rank can serialise its key
+    if (!ctx->bsk_std) FHES_HIP(hipMalloc(&ctx->bsk_std, bsk_b));
+    if (rc == FHES_OK) rc = dev_broadcast(c, ctx->bsk_std, bsk_b, root);
+  }
   if (rc == FHES_OK && has_e) rc = dev_broadcast(c, ctx->bsk_e, bsk_b, root);
   if (rc == FHES_OK && d.g > 1) {  // the layout of a multi-bit key (engine.h: mb_ilv) belongs to the key: it travels with it
     uint64_t *flag = nullptr;

@@ -53,6 +53,7 @@ struct fhes_ctx {
   std::mutex attr_mu;                              // kernel function -> dynamic-LDS size its attribute was set to (engine.hip: ensure_dyn_lds)
   std::map<const void *, size_t> attr_lds;
   unsigned long long *lat_stamps = nullptr;   // lab: phase stamps of the stamped latency build (variant 26)
+  std::atomic<uint64_t> host_bytes_up{0}, host_bytes_down{0};   // ciphertext bytes moved over PCIe by arena upload / download
   int lat_max = 0;   // launches of at most this many bootstraps take the latency build of the classic blind rotate (0: never)
   hipStream_t stream = nullptr;   // the main lane's stream (== main.stream)
   // Locking: `mu` guards the host-side state (arena free list, LUT registry, lanes, stats).  A program run
@@ -96,6 +97,7 @@ struct fhes_ctx {
   int ks_stride = 0;
   int8_t *ksk_pk = nullptr;  // keyswitch key as signed byte planes in MFMA B-fragment order (keyswitch_mfma_kernel)
   int ks_n_wb = 0;           // blocks of 16 key words: ceil((n + 1) / 16)
+  uint64_t *bsk_std = nullptr;  // standard-domain bootstrapping key as uploaded (what `ServerKey: Serialize` hands out again; round 5)
   double2 *bsk_f = nullptr;  // canonical [n_ggsw][2][2][M]   (multi-bit: [n/g][2^g][2][2][M])
   double2 *bsk_e = nullptr;  // engine layout for blind-rotate variants 2/3 and multi-bit: [n_ggsw][2][2][8][M/8]
   double2 *twist = nullptr, *tw = nullptr;

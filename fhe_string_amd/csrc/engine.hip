@@ -955,7 +955,7 @@ void fhes_ctx_destroy(fhes_ctx *ctx) {
     }
     (void)hipFree(ctx->lat_stamps);
   }
-  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_e_base ? ctx->bsk_e_base : (void *)ctx->bsk_e);
+  (void)hipFree(ctx->arena); (void)hipFree(ctx->ksk); (void)hipFree(ctx->ksk_bias); (void)hipFree(ctx->bsk_f); (void)hipFree(ctx->bsk_std); (void)hipFree(ctx->bsk_e_base ? ctx->bsk_e_base : (void *)ctx->bsk_e);
   (void)hipFree(ctx->twist); (void)hipFree(ctx->tw); (void)hipFree(ctx->twist_inv); (void)hipFree(ctx->twist_inv64); (void)hipFree(ctx->root); (void)hipFree(ctx->psi); (void)hipFree(ctx->odd_fix); (void)hipFree(ctx->cdpp); (void)hipFree(ctx->lut_polys);
   (void)hipDeviceSynchronize();
   auto drop_lane = [](Lane &l) {
@@ -1024,8 +1024,10 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
   // bootstrapping key -> Fourier domain on the device
   {
     const size_t npoly = (size_t)d.n_ggsw * d.L * (d.k + 1) * (d.k + 1);
-    uint64_t *tmp = nullptr;
-    FHES_HIP(hipMalloc(&tmp, npoly * d.N * 8));
+    // the standard-domain words stay on the device (48.6 MB of 288 GB for the default set): a server that RECEIVED its key can
+    // hand it out again -- `#[derive(Serialize)] struct ServerKey`, server_key.rs:11 -- without a client key (fhes_download_keys)
+    if (!ctx->bsk_std) FHES_HIP(hipMalloc(&ctx->bsk_std, npoly * d.N * 8));
+    uint64_t *tmp = ctx->bsk_std;
     FHES_HIP(hipMemcpy(tmp, bsk, npoly * d.N * 8, hipMemcpyHostToDevice));
     if (!ctx->bsk_f) FHES_HIP(hipMalloc(&ctx->bsk_f, npoly * d.M * 16));
     const size_t lds = (size_t)d.M * 16;
@@ -1067,9 +1069,23 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
       FHES_HIP(hipGetLastError());
     }
     FHES_HIP(hipStreamSynchronize(ctx->stream));
-    FHES_HIP(hipFree(tmp));
   }
   ctx->keys_loaded = true;
+  return FHES_OK;
+}
+
+// The inverse of fhes_upload_keys: the standard-domain bootstrapping key exactly as it was uploaded (or received by a key
+// broadcast) and the keyswitching key without its row padding -- the words a server-side `ServerKey::serialize` writes.
+int fhes_download_keys(fhes_ctx *ctx, uint64_t *bsk, uint64_t *ksk) {
+  if (!ctx || !bsk || !ksk) return fail(FHES_ERR_INVALID, "null argument");
+  if (!ctx->keys_loaded || !ctx->bsk_std || !ctx->ksk) return fail(FHES_ERR_STATE, "no server keys on this context");
+  MainLaneHold hold(ctx);
+  FHES_HIP(hipSetDevice(ctx->device));
+  const Dims &d = ctx->dims;
+  const size_t npoly = (size_t)d.n_ggsw * d.L * (d.k + 1) * (d.k + 1);
+  FHES_HIP(hipMemcpy(bsk, ctx->bsk_std, npoly * d.N * 8, hipMemcpyDeviceToHost));
+  const size_t rows = (size_t)d.big * d.ks_level, w = (size_t)(d.n + 1) * 8;
+  FHES_HIP(hipMemcpy2D(ksk, w, ctx->ksk, (size_t)ctx->ks_stride * 8, w, rows, hipMemcpyDeviceToHost));
   return FHES_OK;
 }
 
@@ -1105,6 +1121,7 @@ int fhes_arena_upload(fhes_ctx *ctx, int32_t first, int32_t count, const uint64_
   FHES_HIP(hipMemcpy2DAsync(ctx->arena + (size_t)first * ctx->ct_stride, (size_t)ctx->ct_stride * 8, host, w, w,
                             count, hipMemcpyHostToDevice, ctx->stream));
   FHES_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->host_bytes_up += (uint64_t)w * (uint64_t)count;
   return FHES_OK;
 }
 
@@ -1118,6 +1135,7 @@ int fhes_arena_download(fhes_ctx *ctx, int32_t first, int32_t count, uint64_t *h
   FHES_HIP(hipMemcpy2DAsync(host, w, ctx->arena + (size_t)first * ctx->ct_stride, (size_t)ctx->ct_stride * 8, w,
                             count, hipMemcpyDeviceToHost, ctx->stream));
   FHES_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->host_bytes_down += (uint64_t)w * (uint64_t)count;
   return FHES_OK;
 }
 
@@ -1167,6 +1185,8 @@ int fhes_get_stats(fhes_ctx *ctx, fhes_stats *out) {
   if (rc) return rc;
   ctx->stats.arena_capacity = (uint64_t)ctx->capacity;
   ctx->stats.arena_in_use = (uint64_t)ctx->in_use;
+  ctx->stats.host_bytes_up = ctx->host_bytes_up.load();
+  ctx->stats.host_bytes_down = ctx->host_bytes_down.load();
   *out = ctx->stats;
   return FHES_OK;
 }
@@ -1178,6 +1198,8 @@ int fhes_reset_stats(fhes_ctx *ctx) {
   int rc = collect_timing_locked(ctx);
   if (rc) return rc;
   ctx->stats = fhes_stats{};
+  ctx->host_bytes_up = 0;
+  ctx->host_bytes_down = 0;
   return FHES_OK;
 }
 

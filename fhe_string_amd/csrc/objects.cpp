@@ -31,6 +31,10 @@ struct fhes_ct {
   std::vector<uint64_t> host;  // [n_blocks][ct_words] when present
   fhes_ctx *ctx = nullptr;     // device residency
   int32_t handle = -1;
+  // Residency changes (first use as an operand uploads, decrypt / serialise of a result downloads) happen behind shared
+  // references -- the reference shares `&FheString` across rayon workers (search.rs:34-40) and the Rust crate declares its
+  // handle `Sync` -- so they are serialised inside the object.  A leaf lock: taken after fhes_server_key::mu.
+  std::mutex mu;
 };
 
 static uint64_t ipow(uint64_t b, int e) {
@@ -41,6 +45,7 @@ static uint64_t ipow(uint64_t b, int e) {
 
 static int ensure_device(fhes_server_key *sk, fhes_ct *c) {
   if (c->n_blocks == 0) return FHES_OK;  // an empty object owns no rows
+  std::lock_guard<std::mutex> own(c->mu);
   if (c->handle >= 0) {
     if (c->ctx != sk->ctx) return fail(FHES_ERR_INVALID, "ciphertext belongs to another server key");
     return FHES_OK;
@@ -61,6 +66,7 @@ static int ensure_device(fhes_server_key *sk, fhes_ct *c) {
 }
 
 static int ensure_host(fhes_ct *c) {
+  std::lock_guard<std::mutex> own(c->mu);
   if (!c->host.empty()) return FHES_OK;
   if (c->handle < 0 || !c->ctx) return fail(FHES_ERR_INVALID, "ciphertext has no data");
   c->host.resize((size_t)c->n_blocks * c->ct_words);
@@ -304,6 +310,41 @@ fhes_ct *fhes_ct_concat(fhes_server_key *sk, fhes_ct *const *parts, int32_t n_pa
   return gather_blocks(sk, src);
 }
 
+// `Clone`: a device-resident object is copied on the device (the linear kernel: out = 1 * ct), a host-only one on the host
+fhes_ct *fhes_ct_clone(const fhes_ct *ct) {
+  if (!ct) { fail(FHES_ERR_INVALID, "null argument"); return nullptr; }
+  auto *c = new fhes_ct;
+  std::lock_guard<std::mutex> own(const_cast<fhes_ct *>(ct)->mu);   // against a concurrent first upload / download of the source
+  c->n_blocks = ct->n_blocks;
+  c->ct_words = ct->ct_words;
+  c->degree = ct->degree;
+  c->noise = ct->noise;
+  c->ctx = ct->ctx;
+  if (ct->handle < 0 || ct->n_blocks == 0) {   // not on a device (fresh from the client or from a blob), or empty
+    c->host = ct->host;
+    return c;
+  }
+  const int32_t n = ct->n_blocks;
+  const int32_t h = fhes_arena_alloc(ct->ctx, n);
+  if (h < 0) { delete c; return nullptr; }
+  std::vector<int32_t> term_ptr(n + 1), term_idx(n), outs(n);
+  std::vector<int64_t> coef(n, 1);
+  std::vector<uint64_t> consts(n, 0);
+  for (int32_t i = 0; i < n; i++) {
+    term_ptr[i] = i;
+    term_idx[i] = ct->handle + i;
+    outs[i] = h + i;
+  }
+  term_ptr[n] = n;
+  if (fhes_linear_batch(ct->ctx, n, term_ptr.data(), term_idx.data(), coef.data(), consts.data(), outs.data())) {
+    fhes_arena_free(ct->ctx, h, n);
+    delete c;
+    return nullptr;
+  }
+  c->handle = h;   // the host copy, if the source has one, is not duplicated: it is fetched on demand like any result's
+  return c;
+}
+
 static int decrypt_values(const fhes_client_key *ck, fhes_ct *c, std::vector<uint8_t> *vals) {
   // a ciphertext object may come out of a blob (fhes_ct_deserialize): its width must be this key's
   fhes_params kp;
@@ -367,6 +408,7 @@ int fhes_bool_decrypt(const fhes_client_key *ck, fhes_ct *b, int32_t *out) {
 }
 
 static void default_meta(fhes_ct *ct) {  // objects built before metadata existed / results: clean blocks
+  std::lock_guard<std::mutex> own(ct->mu);
   if ((int32_t)ct->degree.size() != ct->n_blocks) ct->degree.assign((size_t)ct->n_blocks, 3);
   if ((int32_t)ct->noise.size() != ct->n_blocks) ct->noise.assign((size_t)ct->n_blocks, 1);
 }
@@ -428,28 +470,50 @@ fhes_ct *fhes_ct_deserialize(const uint8_t *buf, int64_t len) {
 }
 
 // ---- ServerKey blob (server_key.rs:11) -----------------------------------------------------------
-int64_t fhes_server_key_serialize(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len) {
+static constexpr int64_t kSkHead = 4 + 4 + 4 + (int64_t)sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8;
+static_assert((4 + 4 + 4 + sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8) % 4 == 0, "header layout");
+
+// header of a server-key blob; returns the write position behind it
+static uint8_t *sk_blob_head(uint8_t *buf, const fhes_params &p, int32_t nbc, int32_t nbu, int64_t bw, int64_t kw) {
+  const uint32_t version = 2, kind = 3;
+  const uint64_t l = ipow((uint64_t)1 << p.message_bits, nbu) - 1;  // max_len of the key (mod.rs:435)
+  uint8_t *w = buf;
+  auto put = [&](const void *src, size_t n) { memcpy(w, src, n); w += n; };
+  put("FHES", 4); put(&version, 4); put(&kind, 4); put(&p, sizeof p); put(&l, 8); put(&nbc, 4); put(&nbu, 4); put(&bw, 8); put(&kw, 8);
+  return w;
+}
+
+// server side: the words the device received (fhes_download_keys), no client key
+int64_t fhes_server_key_serialize(const fhes_server_key *sk, uint8_t *buf, int64_t buf_len) {
+  if (!sk || !sk->ctx) return fail(FHES_ERR_INVALID, "null argument");
+  const int64_t bw = fhes_bsk_words(&sk->p), kw = fhes_ksk_words(&sk->p);
+  const int64_t total = kSkHead + (bw + kw) * 8;
+  if (!buf) return total;
+  if (buf_len < total) return fail(FHES_ERR_INVALID, "buffer too small (%lld needed)", (long long)total);
+  uint8_t *w = sk_blob_head(buf, sk->p, sk->nb_char, sk->nb_usize, bw, kw);
+  std::vector<uint64_t> bsk((size_t)bw), ksk((size_t)kw);   // aligned staging (the payload sits at a 4-byte boundary)
+  int rc = fhes_download_keys(sk->ctx, bsk.data(), ksk.data());
+  if (rc) return rc;
+  memcpy(w, bsk.data(), (size_t)bw * 8);
+  memcpy(w + (size_t)bw * 8, ksk.data(), (size_t)kw * 8);
+  return total;
+}
+
+// client side: the same blob made where the key was generated, without a device
+int64_t fhes_client_key_serialize_server_key(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len) {
   if (!ck) return fail(FHES_ERR_INVALID, "null argument");
   fhes_params p;
   fhes_client_key_params(ck, &p);
   const int64_t bw = fhes_bsk_words(&p), kw = fhes_ksk_words(&p);
-  const int64_t head = 4 + 4 + 4 + (int64_t)sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8;
-  const int64_t total = head + (bw + kw) * 8;
+  const int64_t total = kSkHead + (bw + kw) * 8;
   if (!buf) return total;
   if (buf_len < total) return fail(FHES_ERR_INVALID, "buffer too small (%lld needed)", (long long)total);
-  const uint32_t version = 2, kind = 3;
-  const uint64_t l = ipow((uint64_t)1 << p.message_bits, fhes_client_key_num_blocks_usize(ck)) - 1;  // max_len of the key (mod.rs:435)
-  const int32_t nbc = fhes_client_key_num_blocks_char(ck), nbu = fhes_client_key_num_blocks_usize(ck);
-  uint8_t *w = buf;
-  auto put = [&](const void *src, size_t n) { memcpy(w, src, n); w += n; };
-  put("FHES", 4); put(&version, 4); put(&kind, 4); put(&p, sizeof p); put(&l, 8); put(&nbc, 4); put(&nbu, 4); put(&bw, 8); put(&kw, 8);
-  // the key material is generated straight into the blob (8-byte alignment of the payload: head is a multiple of 8)
-  static_assert((4 + 4 + 4 + sizeof(fhes_params) + 8 + 4 + 4 + 8 + 8) % 4 == 0, "header layout");
+  uint8_t *w = sk_blob_head(buf, p, fhes_client_key_num_blocks_char(ck), fhes_client_key_num_blocks_usize(ck), bw, kw);
   std::vector<uint64_t> bsk((size_t)bw), ksk((size_t)kw);
   int rc = fhes_client_key_make_server_keys(ck, bsk.data(), ksk.data());
   if (rc) return rc;
-  put(bsk.data(), (size_t)bw * 8);
-  put(ksk.data(), (size_t)kw * 8);
+  memcpy(w, bsk.data(), (size_t)bw * 8);
+  memcpy(w + (size_t)bw * 8, ksk.data(), (size_t)kw * 8);
   return total;
 }
 

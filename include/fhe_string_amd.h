@@ -140,12 +140,17 @@ typedef struct fhes_stats {
   double total_ks_ms;        /* accumulated while timing is enabled                 */
   double total_br_ms;
   uint64_t timed_launches;   /* launch pairs included in total_*_ms                 */
+  uint64_t host_bytes_up;    /* ciphertext bytes fhes_arena_upload moved host -> device   (round 5) */
+  uint64_t host_bytes_down;  /* ciphertext bytes fhes_arena_download moved device -> host           */
 } fhes_stats;
 
 fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device);
 void fhes_ctx_destroy(fhes_ctx *ctx);
 /* BSK is transformed to the Fourier domain on the device (kernel bsk_to_fourier). */
 int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk);
+/* The inverse: the standard-domain words exactly as uploaded (or received by fhes_comm_broadcast_keys); bsk[fhes_bsk_words],
+ * ksk[fhes_ksk_words].  What a server-side `ServerKey: Serialize` (/root/reference/src/server_key.rs:11) writes. */
+int fhes_download_keys(fhes_ctx *ctx, uint64_t *bsk, uint64_t *ksk);
 /* Register f: [0,2^(msg+carry)) -> [0,2^(msg+carry)); returns lut id >= 0. */
 int32_t fhes_lut_register(fhes_ctx *ctx, const uint64_t *table, int32_t n_entries);
 /* Ciphertext arena: contiguous handle ranges of big-key LWE ciphertexts. */
@@ -312,10 +317,19 @@ int fhes_ct_block_meta(const fhes_ct *ct, uint8_t *degree, uint8_t *noise);
  * concatenation of objects (e.g. one BooleanBlock per character -> the "L" operand of "find_pred" /
  * "rfind_pred").  Device-side copies; the caller destroys the result. */
 fhes_ct *fhes_ct_slice(fhes_server_key *sk, fhes_ct *ct, int32_t first, int32_t count);
+/* `Clone` of a ciphertext object (the reference clones freely: compare.rs:155-160, mod.rs:250-263, split.rs:322-325).  A
+ * device-resident object is copied ON the device (new arena rows, no PCIe traffic: fhes_stats.host_bytes_* do not move); an
+ * object that only exists in host memory is copied there.  The caller destroys the result. */
+fhes_ct *fhes_ct_clone(const fhes_ct *ct);
 fhes_ct *fhes_ct_concat(fhes_server_key *sk, fhes_ct *const *parts, int32_t n_parts);
-/* ServerKey blob (server_key.rs:11 derives serde): the standard-domain key material plus the block counts;
- * deserialising uploads it to `device` (Fourier transform on the device) and needs no client key. */
-int64_t fhes_server_key_serialize(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len);
+/* ServerKey blob (/root/reference/src/server_key.rs:11: `#[derive(Serialize, Deserialize)] struct ServerKey`): the
+ * standard-domain key material plus the block counts.  fhes_server_key_serialize works on the SERVER's object -- created from a
+ * client key, restored from a blob or filled by a key broadcast: the device keeps the standard-domain words next to the
+ * Fourier-domain ones -- and needs no client key; serialise -> deserialise -> serialise gives identical bytes.
+ * fhes_client_key_serialize_server_key makes the same blob on a machine WITHOUT a device (the client that generated the key;
+ * round 1-4's fhes_server_key_serialize).  Deserialising uploads to `device` (Fourier transform on the device). */
+int64_t fhes_server_key_serialize(const fhes_server_key *sk, uint8_t *buf, int64_t buf_len);
+int64_t fhes_client_key_serialize_server_key(const fhes_client_key *ck, uint8_t *buf, int64_t buf_len);
 fhes_server_key *fhes_server_key_deserialize(const uint8_t *buf, int64_t len, int32_t device);
 
 /* Generic operation dispatch: op names and operand order as in fhes_op_signature.  `args` are

@@ -10,6 +10,7 @@ extern "C" {
 fhes_ctx *fhes_ctx_create(const fhes_params *, int32_t) { fail(FHES_ERR_NO_DEVICE, "sanitizer harness: no HIP device"); return nullptr; }
 void fhes_ctx_destroy(fhes_ctx *) {}
 int fhes_upload_keys(fhes_ctx *, const uint64_t *, const uint64_t *) { return fail(FHES_ERR_NO_DEVICE, "sanitizer harness: no HIP device"); }
+int fhes_download_keys(fhes_ctx *, uint64_t *, uint64_t *) { return fail(FHES_ERR_NO_DEVICE, "sanitizer harness: no HIP device"); }
 int32_t fhes_arena_alloc(fhes_ctx *, int32_t) { return fail(FHES_ERR_NO_DEVICE, "sanitizer harness: no HIP device"); }
 int fhes_arena_free(fhes_ctx *, int32_t, int32_t) { return FHES_OK; }
 int fhes_arena_upload(fhes_ctx *, int32_t, int32_t, const uint64_t *) { return fail(FHES_ERR_NO_DEVICE, "sanitizer harness: no HIP device"); }

@@ -183,8 +183,19 @@ int main() {
   }
   std::vector<uint8_t> ct_blob(s ? (size_t)fhes_ct_serialize(s, nullptr, 0) : 0);
   if (s) EXPECT(fhes_ct_serialize(s, ct_blob.data(), (int64_t)ct_blob.size()) == (int64_t)ct_blob.size(), "ct serialise");
-  std::vector<uint8_t> sk_blob((size_t)fhes_server_key_serialize(ck, nullptr, 0));
-  EXPECT(fhes_server_key_serialize(ck, sk_blob.data(), (int64_t)sk_blob.size()) == (int64_t)sk_blob.size(), "server key serialise");
+  if (s) {   // Clone of an object that lives in host memory: an independent copy with the same bytes (the device path: tests/test_gpu_serde.py)
+    fhes_ct *dup = fhes_ct_clone(s);
+    EXPECT(dup != nullptr, "clone of a host object: %s", fhes_last_error());
+    if (dup) {
+      std::vector<uint8_t> dup_blob((size_t)fhes_ct_serialize(dup, nullptr, 0));
+      EXPECT(fhes_ct_serialize(dup, dup_blob.data(), (int64_t)dup_blob.size()) == (int64_t)dup_blob.size() && dup_blob == ct_blob, "clone differs from its source");
+      fhes_ct_destroy(dup);
+    }
+    EXPECT(fhes_ct_clone(nullptr) == nullptr, "clone of NULL accepted");
+  }
+  EXPECT(fhes_server_key_serialize(nullptr, nullptr, 0) < 0, "server-side serialise of a NULL key accepted");
+  std::vector<uint8_t> sk_blob((size_t)fhes_client_key_serialize_server_key(ck, nullptr, 0));
+  EXPECT(fhes_client_key_serialize_server_key(ck, sk_blob.data(), (int64_t)sk_blob.size()) == (int64_t)sk_blob.size(), "server key serialise");
 
   // ---- serialisers: malformed input ----
   const size_t params_head = 12 + sizeof(fhes_params) + 64;

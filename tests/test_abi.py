@@ -130,10 +130,10 @@ def test_serialisation_round_trips(libs):
     assert k1.to_bytes() == b1                                                # encrypting changed nothing that is serialised
     # ServerKey blob (server_key.rs:11): header + standard-domain BSK + KSK; deserialising needs a device
     p = toy_params()
-    n = lib.fhes_server_key_serialize(ck._h, None, 0)
+    n = lib.fhes_client_key_serialize_server_key(ck._h, None, 0)
     assert n == 12 + C.sizeof(Params) + 8 + 4 + 4 + 8 + 8 + 8 * (lib.fhes_bsk_words(C.byref(p)) + lib.fhes_ksk_words(C.byref(p)))
     buf = (C.c_uint8 * n)()
-    assert lib.fhes_server_key_serialize(ck._h, buf, n) == n and bytes(buf[:4]) == b"FHES"
+    assert lib.fhes_client_key_serialize_server_key(ck._h, buf, n) == n and bytes(buf[:4]) == b"FHES"
     assert not lib.fhes_server_key_deserialize(buf, n, 0)                     # no HIP device here: fails loudly
     assert not lib.fhes_server_key_deserialize(buf, n - 8, 0) and b"truncated" in lib.fhes_last_error()
 

@@ -85,3 +85,54 @@ def test_corrupted_server_key_blob_is_refused_on_a_machine_with_a_device(libs):
     s = api.FheString.new(ck, "abcabc")
     assert s.find(sk, api.FheString.new(ck, "ca")).decrypt(ck) == 2
     sk.close()
+
+
+def test_a_server_that_received_its_key_can_serialise_it_again(libs):
+    """`#[derive(Serialize, Deserialize)] struct ServerKey` (/root/reference/src/server_key.rs:11): the SERVER's object
+    serialises, with no client key in reach.  deserialise -> serialise gives identical bytes, a key made
+    from a client key on this machine gives the client-side blob's bytes, and the re-serialised key still computes."""
+    ck = api.ClientKey(api.default_params(), 255, SEED)
+    client_blob = api.ServerKey.serialize(ck)            # made where the key was generated: no device involved
+    sk = api.ServerKey.from_bytes(client_blob)           # the server: all it ever sees is this blob
+    again = sk.to_bytes()
+    assert again == client_blob, "deserialise -> serialise changed the blob"
+    direct = api.ServerKey(ck)                           # a key created from the client key serialises to the same bytes
+    assert direct.to_bytes() == client_blob
+    direct.close()
+    sk.close()
+    sk3 = api.ServerKey.from_bytes(again)
+    a, pat = api.FheString.new(ck, TEXT), api.FheString.new(ck, "lazy")
+    assert a.find(sk3, pat).decrypt(ck) == TEXT.find("lazy")
+    sk3.close()
+
+
+def test_clone_stays_on_the_device(libs):
+    """`Clone` of a ciphertext object (compare.rs:155-160, mod.rs:250-263, split.rs:322-325 clone freely): identical words,
+    independent rows, and not one byte over PCIe."""
+    import ctypes as C
+    from fhe_string_amd._lib import Stats, check, load
+    lib = load()
+    ck = api.ClientKey(api.default_params(), 255, SEED)
+    sk = api.ServerKey(ck)
+    a, pat = api.FheString.new(ck, TEXT), api.FheString.new(ck, "fox")
+    host_only = a.clone()                                # before any operation the object lives in host memory: copied there
+    assert host_only.to_bytes() == a.to_bytes()
+    r = a.find(sk, pat)                                  # operands are on the device now, the result was born there
+    ctx = sk.ctx
+
+    def moved():
+        st = Stats()
+        check(lib.fhes_get_stats(ctx, C.byref(st)))
+        return int(st.host_bytes_up), int(st.host_bytes_down)
+
+    before = moved()
+    a2, idx2 = a.clone(), r.val.clone()
+    assert moved() == before, "a device-side clone moved bytes over PCIe"
+    assert a2.to_bytes() == a.to_bytes() and idx2.to_bytes() == r.val.to_bytes()
+    assert moved()[1] > before[1]                        # (the comparison itself downloads: the counter does count)
+    # independent objects: the clone outlives its source and is an operand like any other
+    want = r.val.decrypt(ck)
+    del a, r
+    assert a2.decrypt(ck) == TEXT and idx2.decrypt(ck) == want == TEXT.find("fox")
+    assert a2.find(sk, pat).decrypt(ck) == want
+    sk.close()
