@@ -489,18 +489,28 @@ static int launch_br_v1(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
 }
 #endif  // FHES_LAB
 
-template <int LOGN, int G, bool PIPE, bool LAT = false, int BL = 23, bool ILV = false>
+template <int LOGN, int G, bool PIPE, bool LAT = false, int BL = 23, bool ILV = false, bool SCAL = false>
 static int launch_br_mb(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
-  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_mb<LOGN, G, PIPE, LAT, 18, ILV>(ctx, lane, d);
+  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_mb<LOGN, G, PIPE, LAT, 18, ILV, SCAL>(ctx, lane, d);
+  // launches of at most one workgroup per CU take the uniform monomial factors through the scalar cache (kernels.hip.h, SCAL)
+  if (!SCAL && d.v_count <= ctx->n_cus && ctx->br_variant != 3) return launch_br_mb<LOGN, G, PIPE, LAT, BL, ILV, true>(ctx, lane, d);
   constexpr int N = 1 << LOGN, M = N / 2;
   const int n_deg = (ctx->dims.n / G) * ((1 << G) - 1);
   constexpr int SLOTS = (M >= 128 ? M / 128 : 1) * 142;
   const size_t lds = (size_t)2 * SLOTS * 16 + (size_t)M * 16 + (size_t)(M / 2) * 16 + (size_t)M * 16 + (size_t)((n_deg + 7) & ~7) * 2;
-  auto kern = dev::blind_rotate_mb_kernel<LOGN, BL, G, PIPE, LAT, ILV>;
+  auto kern = dev::blind_rotate_mb_kernel<LOGN, BL, G, PIPE, LAT, ILV, SCAL>;
   if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
+#ifdef FHES_LAB
+  static const int lab_root_mask = getenv("FHES_MB_ROOT_MASK") ? atoi(getenv("FHES_MB_ROOT_MASK")) : -1;
+  static const int lab_group_mask = getenv("FHES_MB_GROUP_MASK") ? atoi(getenv("FHES_MB_GROUP_MASK")) : -1;
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena,
+                     ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
+                     ctx->lut_polys, ctx->twist_inv, ctx->tw, ctx->root, ctx->psi, ctx->cdpp, lab_root_mask, lab_group_mask);
+#else
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(M / 4), lds, lane.stream, d, ctx->arena,
                      ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e,
                      ctx->lut_polys, ctx->twist_inv, ctx->tw, ctx->root, ctx->psi, ctx->cdpp);
+#endif
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }

@@ -1883,8 +1883,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), 3)
 // Mapping as variant 3: 256 threads = two halves (output polynomial r) x 128 threads x 8 points,
 // two workgroups per CU.  Every exchange is written in place (a thread writes the slots it read),
 // so an iteration has 6 barriers and none at its end.
-// The Fourier image of X^d at spectrum slot p is root[(E(p) * d) mod 2N], E(p) = 1 - 4*bitrev(p),
-// root[t] = exp(i*pi*t/N): slot p holds the evaluation at twist * exp(-2*pi*i*bitrev(p)/M).
+// The Fourier image of X^d at spectrum slot p is exp(i pi E(p) d / N), E(p) = 1 - 4*bitrev(p) (slot p holds the evaluation at
+// twist * exp(-2*pi*i*bitrev(p)/M)); since round 5 it is taken as the PRODUCT of two entries of root[t] = exp(i*pi*t/N) whose
+// exponents split E(p) d along fixed bits of bitrev(p) (oracle_blind_rotate_multibit): one gather per monomial
+// and thread plus scalar loads, where the single-entry form cost eight gathers.
 // LDS: fbuf double2[2][M] | stage twiddle tables double2[M/2] | degrees u16[(n/G) * (2^G - 1)]
 // ------------------------------------------------------------------------------------------
 // acc += g * w with the operation order of cmul
@@ -1928,13 +1930,24 @@ __device__ __forceinline__ void load_inv_twiddles_tab_all(double2 (&w)[7], int q
 // LAT = true: the latency build -- one workgroup per CU (512 registers per lane), pass twiddles and
 // twist factors in registers (as variant 2), always with the bundle pipeline.
 // ILV (round-4 layout A/B, g = 3 throughput build only): the 2^G GGSWs of a group interleaved row by row in the key
-template <int LOGN, int BL, int G, bool PIPE, bool LAT, bool ILV = false>
+// SCAL: the workgroup-uniform monomial factors through the scalar cache (launches of at most one workgroup per CU: 2.34 against
+// 2.66 ms per g = 3 bootstrap) instead of as one-address vector loads (wide launches: 157 against 127 k PBS/s for g = 2)
+template <int LOGN, int BL, int G, bool PIPE, bool LAT, bool ILV = false, bool SCAL = false>
 __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LAT ? 1 : 2) void blind_rotate_mb_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out,
     int ks_stride, int n_small, const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
     const double2 *__restrict__ twist_inv /* twist / M */, const double2 *__restrict__ tw,
     const double2 *__restrict__ root /* [2N] */, const double2 *__restrict__ psi /* forward twiddles [M] */,
-    const double2 *__restrict__ cdpp /* [8][M/8] */) {
+    const double2 *__restrict__ cdpp /* [8][M/8] */
+#ifdef FHES_LAB   // timing-only probes (WRONG results unless both are -1): the monomial factors from a table cut down to
+                  // `lab_root_mask + 1` entries, every step reading the key of group `j AND lab_group_mask` -- what would the
+                  // gathers / the key stream cost if they hit close by?
+    , int lab_root_mask, int lab_group_mask
+#endif
+    ) {
+#ifndef FHES_LAB
+  constexpr int lab_root_mask = -1, lab_group_mask = -1;
+#endif
   constexpr bool ilv = ILV;
   constexpr int N = 1 << LOGN, M = N / 2, LOGM = LOGN - 1, TP = M / 8;
   constexpr int NP = (LOGM - 1) / 3, NC = 1 << G;
@@ -2040,17 +2053,39 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
   // G = 3 always (72 -> 84 k PBS/s) and for G = 2 when a launch leaves one workgroup per CU (2.83 vs
   // 3.03 ms per PBS); in wide G = 2 launches the key stream is the limit either way and the plain
   // order keeps the kernel spill-free (122 vs 105 k PBS/s)
-  constexpr int NBATCH = (8 / EB) * NCB, QB = NBATCH / 4;
+  constexpr int NBATCH = (8 / EB) * NCB, QB = NBATCH / 4, NEB = 8 / EB;
   double2 b0[8], b1[8];
-  double2 tg0[EB][CB], tg1[EB][CB], tww[EB][CB];
+  double2 tg0[EB][CB], tg1[EB][CB];
+  // Monomial factors: W_c[p] = root[deg_c (1 - 4 b_S)] * root[-4 deg_c b_L] with b = bitrev(p) split
+  // into b_S (the three bits a thread's eight points differ in: the same for the whole workgroup -> a SCALAR load per point
+  // and monomial) and b_L (the thread's own: ONE gather per monomial, `rw`, where the single-entry form root[E(p) deg_c] took
+  // eight).  The gathers were what bound these kernels: 64 lanes x 64 lines of a 64 KB table, two thirds of them L2 requests
+  // (profiles/r05_probe8_multibit_bounds.txt: g = 3 84 -> 153 k PBS/s with the gathers hitting close by).
+  double2 rw[CB];   // batches run c-range by c-range (all points of c in [cb, cb + CB) before the next range): CB factors live
   int deg[NC];
+  const int lexp = (sexp0 - 1) & (2 * N - 1);   // -4 b_L of this thread (e = 0: the e bits of bitrev(p) are b_S)
   auto bundle_degrees = [&](int jn) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 1; c < NC; ++c) deg[c] = __builtin_amdgcn_readfirstlane((int)degs[jn * (NC - 1) + (c - 1)]);  // uniform -> SGPR
   };
+  // the workgroup-uniform factor of monomial c at register e: root[deg_c (1 - 4 (bitrev3(e) << (LOGM - 4)))]
+  // (requested as a VECTOR load of one address -- a single line for the texture unit, counted by vmcnt like the key rows it
+  // travels with: as a scalar load it drained the LDS counter at every use, 127 instead of 134 k PBS/s for g = 2.  `zlane` is a
+  // zero the compiler cannot see through.)
+  int zlane = 0;
+  if (!SCAL) asm volatile("" : "+v"(zlane));
+  auto mono_scalar = [&](int c, int e) __attribute__((always_inline)) {
+    const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);  // constant after unrolling
+    return root[((deg[c] - br3 * (deg[c] << (LOGM - 1 - LO_C))) & (2 * N - 1)) + zlane];
+  };
   auto bundle_issue = [&](int jn, int k) __attribute__((always_inline)) {
-    const int eb = (k / NCB) * EB, cb = 1 + (k % NCB) * CB;
-    const unsigned so = (unsigned)jn * (unsigned)(NC * 4 * M * 16);
+    const int eb = (k % NEB) * EB, cb = 1 + (k / NEB) * CB;
+    const unsigned so = (unsigned)(jn & lab_group_mask) * (unsigned)(NC * 4 * M * 16);
+    if (k % NEB == 0) {   // first batch of a c-range: its lane factors (the previous range's last batch has been consumed)
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc)
+        if (cb + cc < NC) rw[cc] = root[(lexp * deg[cb + cc]) & (2 * N - 1) & lab_root_mask];
+    }
 #pragma unroll
     for (int ee = 0; ee < EB; ++ee) {
       const int e = eb + ee;
@@ -2062,23 +2097,22 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
       for (int cc = 0; cc < CB; ++cc) {
         const int c = cb + cc;
         if (c >= NC) continue;
-        const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);  // constant after unrolling
-        tww[ee][cc] = root[(sexp0 * deg[c] - br3 * (deg[c] << (LOGM - 1 - LO_C))) & (2 * N - 1)];
         tg0[ee][cc] = buf_load_d2(rs_g, voff_g, goff(so, c, 0, e));
         tg1[ee][cc] = buf_load_d2(rs_g, voff_g, goff(so, c, 1, e));
       }
     }
   };
   auto bundle_consume = [&](int k) __attribute__((always_inline)) {
-    const int eb = (k / NCB) * EB, cb = 1 + (k % NCB) * CB;
+    const int eb = (k % NEB) * EB, cb = 1 + (k / NEB) * CB;
 #pragma unroll
     for (int ee = 0; ee < EB; ++ee) {
       const int e = eb + ee;
 #pragma unroll
       for (int cc = 0; cc < CB; ++cc) {
         if (cb + cc >= NC) continue;
-        b0[e] = cfma(tg0[ee][cc], tww[ee][cc], b0[e]);
-        b1[e] = cfma(tg1[ee][cc], tww[ee][cc], b1[e]);
+        const double2 w = cmul(mono_scalar(cb + cc, e), rw[cc]);
+        b0[e] = cfma(tg0[ee][cc], w, b0[e]);
+        b1[e] = cfma(tg1[ee][cc], w, b1[e]);
       }
     }
   };
@@ -2102,7 +2136,10 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
     const int jn = j + 1 < n_groups ? j + 1 : j;  // the last step rebuilds its own bundle (unused)
     if (!PIPE) {  // plain order: two points at a time, loads and multiply-adds of a batch together
       bundle_degrees(j);
-      const unsigned so = (unsigned)j * (unsigned)(NC * 4 * M * 16);
+      const unsigned so = (unsigned)(j & lab_group_mask) * (unsigned)(NC * 4 * M * 16);
+      double2 rall[NC];   // the lane factors of all monomials of the group: one gather each
+#pragma unroll
+      for (int c = 1; c < NC; ++c) rall[c] = root[(lexp * deg[c]) & (2 * N - 1) & lab_root_mask];
 #pragma unroll
       for (int eb = 0; eb < 8; eb += 2) {
 #pragma unroll
@@ -2111,8 +2148,7 @@ __global__ __launch_bounds__(((1 << LOGN) / 8) < 64 ? 64 : ((1 << LOGN) / 8), LA
           b1[e] = buf_load_d2(rs_g, voff_g, goff(so, 0, 1, e));
 #pragma unroll
           for (int c = 1; c < NC; ++c) {
-                const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);  // constant after unrolling
-            const double2 w = root[(sexp0 * deg[c] - br3 * (deg[c] << (LOGM - 1 - LO_C))) & (2 * N - 1)];
+            const double2 w = cmul(mono_scalar(c, e), rall[c]);
             const double2 g0 = buf_load_d2(rs_g, voff_g, goff(so, c, 0, e));
             const double2 g1 = buf_load_d2(rs_g, voff_g, goff(so, c, 1, e));
             b0[e] = cfma(g0, w, b0[e]);

@@ -966,7 +966,25 @@ void oracle_blind_rotate_multibit(const oracle_ctx *c, const uint64_t *small, co
         if ((cc >> (g - 1 - t)) & 1) sum += small[(size_t)j * g + t];
       const int deg = (int)modswitch1(sum, log2n);
       const cplx *Gc = G0 + (size_t)cc * L * kp1 * kp1 * M;
-      for (int m = 0; m < M; m++) W[m] = c->root[(int)(((long)c->slot_exp[m] * deg) % (2 * N))];
+      /* Fourier image of X^deg at slot m: the exponent E(m) * deg, E(m) = 1 - 4 b, b = bitrev(m), is split
+       * along FIXED bit positions of b -- b_S = the three bits [LOGM-4, LOGM-2], b_L = the rest -- and the factor is the PRODUCT of
+       * two table entries, W = root[deg (1 - 4 b_S)] * root[-4 deg b_L] (the multiply of 4.2).  Exact to one rounding more than a
+       * single entry; the point is the device: a thread's eight slots share b_L (one gather per monomial instead of eight) and
+       * b_S is the same for a whole workgroup (scalar loads). */
+      {
+        int logm = 0;
+        while ((1 << logm) < M) logm++;
+        const long two_n = 2L * N;
+        const int smask = logm >= 4 ? (7 << (logm - 4)) : 0;
+        for (int m = 0; m < M; m++) {
+          const long b = (((two_n + 1 - (long)c->slot_exp[m]) % two_n) / 4);   /* slot_exp[m] = (1 - 4 b) mod 2N */
+          const long bs = b & smask, bl = b - bs;
+          const cplx a = c->root[(int)((((1 - 4 * bs) % two_n + two_n) * (long)deg) % two_n)];
+          const cplx w = c->root[(int)((((-4 * bl) % two_n + two_n) * (long)deg) % two_n)];
+          W[m].re = fma(a.re, w.re, -(a.im * w.im));
+          W[m].im = fma(a.re, w.im, a.im * w.re);
+        }
+      }
       for (int q = 0; q < L * kp1 * kp1; q++) {
         int m = 0;
 #if ORACLE_HAVE_AVX2

@@ -104,6 +104,19 @@ sq = {}
 for sub in ("sqa", "sqb"):
     for k, v in pmc_all(sub).items():
         sq.setdefault(k, {}).update({(c if not c.startswith("_") else f"{sub}{c}"): x for c, x in v.items()})
+# L2 pass (round 5): hit rate and fabric read requests per kernel, batched launches only
+try:
+    tcc = {c: pmc("tcc", c, BATCHED_WGS) for c in ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_EA0_RDREQ_sum")}
+    for k in kern:
+        if k in tcc["TCC_HIT_sum"] and k in tcc["TCC_MISS_sum"]:
+            n, hit = tcc["TCC_HIT_sum"][k]
+            _, miss = tcc["TCC_MISS_sum"][k]
+            kern[k]["l2"] = {"batched_launches": n, "hit_per_launch": hit / n, "miss_per_launch": miss / n,
+                             "hit_rate": hit / (hit + miss) if (hit + miss) else None,
+                             "req_per_launch": tcc["TCC_REQ_sum"].get(k, [1, 0])[1] / n,
+                             "fabric_rdreq_per_launch": tcc["TCC_EA0_RDREQ_sum"].get(k, [1, 0])[1] / n}
+except (ValueError, KeyError, OSError):
+    pass
 bench_line = None
 p = os.path.join(src, "bench_line.json")
 if os.path.exists(p) and os.path.getsize(p):
