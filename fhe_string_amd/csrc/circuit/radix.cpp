@@ -305,8 +305,13 @@ Blk Ops::reduce_signs(std::vector<Blk> signs, Cmp op) {
     bool fits = true;
     for (size_t i = 0; i < signs.size() && fits; i += 3) {
       double noise = 0;
-      for (size_t k = 0; k < 3 && i + k < signs.size(); k++) noise += (double)((1u << k) * (1u << k)) * signs[i + k].noise;
-      fits = noise <= b.noise_cap() && signs[i].deg <= 2;
+      uint64_t deg = 0;   // of the weighted sum: every sign of the triple must be a sign (<= 2), and the sum must fit the lookup
+      for (size_t k = 0; k < 3 && i + k < signs.size(); k++) {
+        noise += (double)((1u << k) * (1u << k)) * signs[i + k].noise;
+        fits = fits && signs[i + k].deg <= 2;
+        deg += (uint64_t)signs[i + k].deg << k;
+      }
+      fits = fits && noise <= b.noise_cap() && deg < (uint64_t)b.space();
     }
     if (!fits) break;
     const bool last = signs.size() <= 3;
@@ -525,16 +530,36 @@ bool Ops::add_digit(const Radix &x, const Blk &y0, Radix &out) {
   const size_t B = x.size();
   const uint64_t m = (uint64_t)M, top = (uint64_t)b.space() - 1;
   if ((y0.trivial() && y0.cst == 0) || y0.deg >= (uint32_t)M || B < 3 || m + (m - 1) > top) return false;
-  Radix y;
+  // ---- dry run: the exact noise of every sum the chain feeds to a lookup, BEFORE a node is emitted.  Anything the
+  // caps do not admit goes the general way (propagate) instead of failing the compilation inside Builder::pbs; a block whose degree
+  // reaches the message modulus carries a real carry that `clean` (v % M) would drop: the general path propagates it. ----
+  const double cap = b.noise_cap();
+  auto tamed_noise = [&](const Blk &blk) { return blk.noise > cap / 2 ? 1.0 : blk.noise; };   // Builder::tame(blk, 1)
+  std::vector<double> yn;
   for (const Blk &blk : x) {
     if (blk.trivial()) return false;  // constants fold better through the general path
-    Blk t = b.tame(blk, 1);
-    if (t.deg >= (uint32_t)M) t = b.clean(t);
-    if ((t.noise + 1.0) * (double)B > b.noise_cap()) return false;
-    y.push_back(t);
+    if (blk.deg >= (uint32_t)M) return false;
+    yn.push_back(tamed_noise(blk));
+    if (yn.back() + 1.0 > cap) return false;   // the digit lookup of y[i] + carry[i]
   }
+  const double a0n = y0.trivial() ? 0.0 : tamed_noise(y0);
+  {
+    const bool unit_ = y0.deg <= 1;
+    const double s0n = yn[0] + a0n;
+    if (s0n > cap) return false;               // looked up for the low digit (and for the carry when the addend exceeds 1)
+    double sum_n = unit_ ? s0n : 1.0;
+    uint64_t want_ = unit_ ? m : 1;
+    for (size_t i = 1; i < B; i++) {
+      if (!(i == 1 && !unit_) && sum_n > cap) return false;   // carry[i] = [sum == want]
+      if (i + 1 == B) break;
+      if (want_ + (m - 1) > top) { sum_n = 1.0; want_ = 1; }
+      sum_n += yn[i];
+      want_ += m - 1;
+    }
+  }
+  Radix y;
+  for (const Blk &blk : x) y.push_back(b.tame(blk, 1));
   const Blk a0 = y0.trivial() ? y0 : b.tame(y0, 1);
-  if (a0.noise + y[0].noise > b.noise_cap()) return false;
   const Blk s0 = b.add(y[0], a0);
   std::vector<Blk> carry(B);   // carry INTO block i (i >= 1)
   Blk seed;                    // the running start of a chain: s0 itself (addend <= 1), g, or an earlier flag

@@ -52,6 +52,7 @@ struct fhes_ctx {
   uint64_t uid = 0;          // unique per context (program images are keyed by it, not by address)
   std::mutex attr_mu;                              // kernel function -> dynamic-LDS size its attribute was set to (engine.hip: ensure_dyn_lds)
   std::map<const void *, size_t> attr_lds;
+  std::vector<double2 *> lab_bsk_e;   // lab (FHES_BSK_E_CANDIDATES): copies of the engine-layout key at other addresses
   unsigned long long *lat_stamps = nullptr;   // lab: phase stamps of the stamped latency build (variant 26)
   std::atomic<uint64_t> host_bytes_up{0}, host_bytes_down{0};   // ciphertext bytes moved over PCIe by arena upload / download
   int lat_max = 0;   // launches of at most this many bootstraps take the latency build of the classic blind rotate (0: never)

@@ -1079,6 +1079,23 @@ int fhes_upload_keys(fhes_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
       FHES_HIP(hipGetLastError());
     }
     FHES_HIP(hipStreamSynchronize(ctx->stream));
+#ifdef FHES_LAB   // lab: K copies of the engine-layout key in allocations of their own (does the rate follow the PLACEMENT of the key?
+                  // fhes_set_kernel_variant(ctx, 100 + i) switches to copy i; scripts/r05_probe12.sh)
+    if (const char *e = getenv("FHES_BSK_E_CANDIDATES")) {
+      const int K = atoi(e);
+      if (ctx->bsk_e && ctx->lab_bsk_e.empty() && K > 1 && K <= 16) {
+        ctx->lab_bsk_e.push_back(ctx->bsk_e);
+        for (int i = 1; i < K; i++) {
+          double2 *q = nullptr;
+          void *hole = nullptr;
+          if (getenv("FHES_BSK_E_HOLES")) (void)hipMalloc(&hole, (size_t)(1 + i) * 3 * 1024 * 1024 + 4096 * i);   // perturb the allocator between candidates (leaked on purpose)
+          FHES_HIP(hipMalloc(&q, npoly * d.M * 16));
+          FHES_HIP(hipMemcpy(q, ctx->bsk_e, npoly * d.M * 16, hipMemcpyDeviceToDevice));
+          ctx->lab_bsk_e.push_back(q);
+        }
+      }
+    }
+#endif
   }
   ctx->keys_loaded = true;
   return FHES_OK;
@@ -1223,6 +1240,12 @@ int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
   const bool product = v == 0 || v == 2 || v == 3 || v == 7 || v == 12;
 #ifdef FHES_LAB
+  if (v >= 100 && v < 100 + (int)ctx->lab_bsk_e.size()) {   // lab: switch to another copy of the engine-layout key
+    (void)hipDeviceSynchronize();
+    ctx->bsk_e = ctx->lab_bsk_e[(size_t)(v - 100)];
+    fprintf(stderr, "[fhes lab] bsk_e copy %d at %p\n", v - 100, (void *)ctx->bsk_e);
+    return FHES_OK;
+  }
   const bool wrong = v == 9 || v == 10 || v == 13 || v == 14 || (v >= 22 && v <= 24);   // timing-only ablations
   const bool lab = v == 1 || v == 5 || v == 6 || v == 8 || wrong || (v >= 20 && v <= 26);
   if (wrong) {   // a developer has to ask for wrong results by name

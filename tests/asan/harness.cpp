@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "../../fhe_string_amd/csrc/circuit/radix.h"
 #include "../../fhe_string_amd/csrc/circuit/strings.h"
 #include "../../fhe_string_amd/csrc/common.h"
 
@@ -88,6 +89,115 @@ static void circuits(const fhes_params &p, const char *label) {
   printf("circuits (%s): %d programs compiled\n", label, n_ok);
 }
 
+// plain evaluation of a compiled program: node = lut[(sum coef * slot + cst)], what the device computes on message values
+static std::vector<int64_t> eval_plain(const fhes::circ::Program &pr, const std::vector<int64_t> &in) {
+  std::vector<int64_t> v(in);
+  v.resize((size_t)pr.n_inputs + pr.nodes.size(), 0);
+  const int64_t space = 1ll << (pr.params.message_bits + pr.params.carry_bits);
+  for (size_t j = 0; j < pr.nodes.size(); j++) {
+    const auto &nd = pr.nodes[j];
+    int64_t x = nd.cst;
+    for (const auto &t : nd.terms) x += t.coef * v[(size_t)t.slot];
+    if (nd.lut >= 0) {
+      EXPECT(x >= 0 && x < space, "plain evaluation: lookup input %lld outside the plaintext space", (long long)x);
+      x = pr.luts[(size_t)nd.lut][(size_t)(x & (space - 1))];
+    }
+    v[(size_t)pr.n_inputs + j] = x;
+  }
+  std::vector<int64_t> out;
+  for (int32_t s : pr.out_slots) out.push_back(v[(size_t)s]);
+  return out;
+}
+
+// Ops::add_digit / scalar_add with operands whose noise sits near half the cap (the counters of the serial loops
+// after a chain of selections).  Whatever the caps do not admit must take the general path -- never throw out of Builder::pbs
+// -- and the emitted circuit must add correctly.  Operand blocks: input + z_1 + ... + z_k with z = lookup(other input, 0):
+// the value and degree of the input, k + 1 units of noise.
+static void noisy_counter_additions(const fhes_params &p, const char *label) {
+  using namespace fhes::circ;
+  int n_prog = 0;
+  for (int B = 3; B <= 6; B++)
+    for (int k : {0, 3, 9, 14, 16, 30, 60, 120})
+      for (int addend_kind = 0; addend_kind < 3; addend_kind++) {   // 0: constant 1, 1: constant 3, 2: an encrypted boolean
+        const int n_in = B + 1 + 16;
+        try {
+          Builder b(p, n_in);
+          if ((double)(k + 1) > b.noise_cap()) continue;   // an operand beyond the cap cannot even be refreshed: no circuit hands one on
+          Ops o(b);
+          const int M = b.msg_mod();
+          std::vector<Blk> zeros;
+          for (int j = 0; j < 16; j++) zeros.push_back(b.pbs(b.input(B + 1 + j, (uint32_t)M - 1), [](uint64_t) { return 0; }));
+          Radix x;
+          for (int i = 0; i < B; i++) {
+            Blk v = b.input(i, (uint32_t)M - 1);
+            for (int j = 0; j < k; j++) v = b.add(v, zeros[(size_t)((i + j) % 16)]);   // repeated terms scale: noise grows faster, still a zero
+            x.push_back(v);
+          }
+          Radix r;
+          if (addend_kind == 2) {
+            Blk flag = b.input(B, 1);
+            for (int j = 0; j < k; j++) flag = b.add(flag, zeros[(size_t)(j % 16)]);
+            r = o.add(x, o.bool_to_radix(flag, B));
+          } else {
+            r = o.scalar_add(x, addend_kind == 0 ? 1 : 3);
+          }
+          Program pr = b.finish(r, "noisy_add");
+          n_prog++;
+          std::mt19937_64 rng((uint64_t)(B * 1000 + k * 10 + addend_kind));
+          for (int trial = 0; trial < 24; trial++) {
+            std::vector<int64_t> in((size_t)n_in, 0);
+            uint64_t xv = 0, mod = 1;
+            for (int i = 0; i < B; i++) {
+              in[(size_t)i] = (trial == 0) ? M - 1 : (int64_t)(rng() % (uint64_t)M);   // trial 0: all digits M-1, the longest carry chain
+              xv += (uint64_t)in[(size_t)i] * mod;
+              mod *= (uint64_t)M;
+            }
+            in[(size_t)B] = (trial & 1);
+            for (int j = 0; j < 16; j++) in[(size_t)(B + 1 + j)] = (int64_t)(rng() % (uint64_t)M);
+            const uint64_t want = (xv + (addend_kind == 2 ? (uint64_t)in[(size_t)B] : (addend_kind == 0 ? 1u : 3u))) % mod;
+            const auto out = eval_plain(pr, in);
+            uint64_t got = 0, w = 1;
+            for (int i = 0; i < B; i++) { got += (uint64_t)(out[(size_t)i] % M) * w; w *= (uint64_t)M; }
+            EXPECT(got == want, "%s: %d blocks, %d extra noise units, addend kind %d: %llu + addend gave %llu, want %llu", label, B, k,
+                   addend_kind, (unsigned long long)xv, (unsigned long long)got, (unsigned long long)want);
+          }
+        } catch (const std::exception &e) {
+          EXPECT(false, "%s: %d blocks, %d extra noise units, addend kind %d: %s", label, B, k, addend_kind, e.what());
+        }
+      }
+  // operands whose blocks hold carries of their own (degree >= M: a lazy sum of two digits): `clean` (v % M) would drop the carry
+  // -- the one-digit path must hand them to the general addition
+  for (int B = 3; B <= 5; B++) {
+    try {
+      Builder b(p, 2 * B);
+      Ops o(b);
+      const int M = b.msg_mod();
+      Radix x;
+      for (int i = 0; i < B; i++) x.push_back(b.add(b.input(i, (uint32_t)M - 1), b.input(B + i, (uint32_t)M - 1)));
+      Program pr = b.finish(o.scalar_add(x, 1), "carry_add");
+      n_prog++;
+      std::mt19937_64 rng((uint64_t)B);
+      for (int trial = 0; trial < 32; trial++) {
+        std::vector<int64_t> in((size_t)(2 * B));
+        uint64_t xv = 0, mod = 1;
+        for (int i = 0; i < B; i++) {
+          in[(size_t)i] = trial == 0 ? M - 1 : (int64_t)(rng() % (uint64_t)M);
+          in[(size_t)(B + i)] = trial == 0 ? M - 1 : (int64_t)(rng() % (uint64_t)M);
+          xv += (uint64_t)(in[(size_t)i] + in[(size_t)(B + i)]) * mod;
+          mod *= (uint64_t)M;
+        }
+        const auto out = eval_plain(pr, in);
+        uint64_t got = 0, w = 1;
+        for (int i = 0; i < B; i++) { got += (uint64_t)(out[(size_t)i] % M) * w; w *= (uint64_t)M; }
+        EXPECT(got == (xv + 1) % mod, "%s: %d blocks with carries inside: got %llu, want %llu", label, B, (unsigned long long)got, (unsigned long long)((xv + 1) % mod));
+      }
+    } catch (const std::exception &e) {
+      EXPECT(false, "%s: %d blocks with carries inside: %s", label, B, e.what());
+    }
+  }
+  printf("noisy counter additions (%s): %d programs compiled and evaluated\n", label, n_prog);
+}
+
 // every prefix, hostile header bytes, seeded random corruption; `parse` returns true when the blob was accepted
 template <typename Parse>
 static void hammer(const char *what, const std::vector<uint8_t> &good, size_t header_bytes, Parse parse, uint64_t seed) {
@@ -128,6 +238,8 @@ int main() {
   EXPECT(fhes_params_multibit(&mb2, 2) == FHES_OK, "multibit params");
   circuits(def, "classic cap");
   circuits(mb2, "multi-bit cap");
+  noisy_counter_additions(def, "classic cap");
+  noisy_counter_additions(mb2, "multi-bit cap");
 
   // ---- client ----
   fhes_client_key *ck = fhes_client_key_generate(&toy, 255, 0x5EED);
