@@ -239,3 +239,41 @@ def test_keyswitch_on_matrix_cores_equals_valu_keyswitch(w):
         check(w.lib.fhes_arena_free(ctx, h, 3 * n))
     finally:
         check(w.lib.fhes_set_keyswitch_mfma_min(ctx, 1))
+
+
+@pytest.mark.parametrize("which,interleave", [("multibit2", "1"), ("multibit3", "0"), ("toy_multibit3", "0"), ("toy_multibit2", "1")])
+def test_multibit_non_default_key_layouts_in_a_process_of_their_own(which, interleave, libs):
+    """the interleaved (g = 2) and plain (g = 3) layouts of the multi-bit key are different kernel instantiations that
+    only developer probes ran.  FHES_MB_INTERLEAVE is read at key upload, so each case runs in a child process: wide and
+    one-per-CU launches (both builds), every word against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import ctypes as C, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import numpy as np\n"
+        "from fhe_string_amd._lib import check\n"
+        "from tests.helpers import ptr, world\n"
+        f"w = world({which!r})\n"
+        "ctx = w.ctx()\n"
+        "count = 600 if w.N <= 256 else 520\n"       # > 512: the throughput build; the first 8 alone: the one-per-CU build
+        "vals = (np.arange(count) % 16).astype(np.uint8)\n"
+        "cts = w.encrypt(vals)\n"
+        "t, poly = w.lut_poly(lambda x: (3 * x + 1) % 16)\n"
+        "lid = check(w.lib.fhes_lut_register(ctx, ptr(t), 16))\n"
+        "h_in = check(w.lib.fhes_arena_alloc(ctx, count)); h_out = check(w.lib.fhes_arena_alloc(ctx, count))\n"
+        "check(w.lib.fhes_arena_upload(ctx, h_in, count, ptr(cts)))\n"
+        "ref = np.stack([w.oracle_pbs(cts[i], poly) for i in range(3)])\n"
+        "for n in (count, 8):\n"
+        "    tp = np.arange(n + 1, dtype=np.int32); ti = np.arange(h_in, h_in + n, dtype=np.int32)\n"
+        "    check(w.lib.fhes_pbs_batch(ctx, n, ptr(tp), ptr(ti), ptr(np.ones(n, dtype=np.int64)), ptr(np.zeros(n, dtype=np.uint64)),\n"
+        "                               ptr(np.full(n, lid, dtype=np.int32)), ptr(np.arange(h_out, h_out + n, dtype=np.int32))))\n"
+        "    res = np.zeros((n, w.W), dtype=np.uint64)\n"
+        "    check(w.lib.fhes_arena_download(ctx, h_out, n, ptr(res)))\n"
+        "    assert np.array_equal(res[:3], ref), n\n"
+        "    assert list(w.decrypt(res)) == [(3 * int(v) + 1) % 16 for v in vals[:n]], n\n"
+        "print('layout ok')\n")
+    env = dict(os.environ, FHES_MB_INTERLEAVE=interleave)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "layout ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
