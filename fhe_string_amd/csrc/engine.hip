@@ -700,7 +700,7 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   const bool n2048 = ctx->dims.N == 2048;
   if (variant == 2 || (variant == 0 && n2048 && ctx->lat_max > 0 && d.v_count <= ctx->lat_max)) {
     if (!n2048) return fail(FHES_ERR_UNSUPPORTED, "the latency build of the blind rotate is written for N = 2048");
-    return launch_br_lat<23, dev::lat_opt(0, 0, 0, 1)>(ctx, lane, d);
+    return launch_br_lat<23, dev::kLatDefaultOpt>(ctx, lane, d);
   }
   if (variant == 0 || variant == 3 || variant == 7) return n2048 ? launch_br_v5<11, 2>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
 #ifdef FHES_LAB
@@ -711,9 +711,9 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
       case 20: return launch_br_lat<23, lat_opt(0, 0, 0, 0)>(ctx, lane, d);
       case 21: return launch_br_lat<23, lat_opt(0, 1, 0, 0)>(ctx, lane, d);     // half barriers through LDS flags
       case 22: return launch_br_lat<23, lat_opt(0, 2, 0, 0)>(ctx, lane, d);     // WRONG results: no half barriers
-      case 23: return launch_br_lat<23, lat_opt(1, 0, 0, 0)>(ctx, lane, d);     // WRONG results: no LDS exchanges
-      case 24: return launch_br_lat<23, lat_opt(2, 0, 0, 0)>(ctx, lane, d);     // WRONG results: no butterflies
-      case 25: return launch_br_lat<23, lat_opt(0, 0, 1, 1)>(ctx, lane, d);     // half 0 at high priority
+      case 23: return launch_br_lat<23, lat_opt(0, 0, 0, 1, 0, 1) | (1 << 9) | (1 << 10)>(ctx, lane, d);   // + the in-wave part without LDS (layout v2)
+      case 24: return launch_br_lat<23, lat_opt(0, 0, 0, 1, 0, 1) | (1 << 9)>(ctx, lane, d);   // interleaved stores + rotated-read addresses ahead of B6
+      case 25: return launch_br_lat<23, lat_opt(0, 0, 0, 1, 0, 1)>(ctx, lane, d);   // stores pair by pair behind their butterflies
       default: return launch_br_lat<23, lat_opt(0, 0, 0, 0, 1)>(ctx, lane, d);  // phase stamps
     }
   }
@@ -1246,7 +1246,7 @@ int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
     fprintf(stderr, "[fhes lab] bsk_e copy %d at %p\n", v - 100, (void *)ctx->bsk_e);
     return FHES_OK;
   }
-  const bool wrong = v == 9 || v == 10 || v == 13 || v == 14 || (v >= 22 && v <= 24);   // timing-only ablations
+  const bool wrong = v == 9 || v == 10 || v == 13 || v == 14 || v == 22;   // timing-only ablations
   const bool lab = v == 1 || v == 5 || v == 6 || v == 8 || wrong || (v >= 20 && v <= 26);
   if (wrong) {   // a developer has to ask for wrong results by name
     const char *e = getenv("FHES_DEV_ABLATIONS");

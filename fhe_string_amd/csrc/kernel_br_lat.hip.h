@@ -62,6 +62,49 @@ __device__ __forceinline__ void lat_transpose_e1_l4(double2 (&x)[4]) {
   lat_swap16(x[1].x, x[3].x); lat_swap16(x[1].y, x[3].y);
 }
 
+// Register bit <-> lane bit 3 / 2 WITHOUT LDS (layout v2): a row shift by 8 / 4 lanes whose bank mask lets only the lanes take the
+// partner's value that need it (banks = groups of four lanes: lane bit 3 = banks 2, 3; lane bit 2 = banks 1, 3); the other lanes keep
+// `old`.  Same exchange as the permlane swaps: the first register of a pair ends up with the data of the lanes whose bit was 0.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double lat_dpp_upd(double old, double src) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, BANKS, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, BANKS, false);
+  return __hiloint2double(hi, lo);
+}
+template <int SHIFT>   // SHIFT = 8: lane bit 3, SHIFT = 4: lane bit 2
+__device__ __forceinline__ void lat_swap_row(double &a, double &b) {
+  constexpr int SHR = 0x110 + SHIFT, SHL = 0x100 + SHIFT;
+  constexpr int HI = SHIFT == 8 ? 0xC : 0xA, LO = SHIFT == 8 ? 0x3 : 0x5;   // banks whose lanes have the bit set / clear
+  const double a2 = lat_dpp_upd<SHR, HI>(a, b);   // lanes with the bit set: b of the lane SHIFT below
+  const double b2 = lat_dpp_upd<SHL, LO>(b, a);   // lanes with the bit clear: a of the lane SHIFT above
+  a = a2;
+  b = b2;
+}
+__device__ __forceinline__ void lat_transpose_e1_l3(double2 (&x)[4]) {
+  lat_swap_row<8>(x[0].x, x[2].x); lat_swap_row<8>(x[0].y, x[2].y);
+  lat_swap_row<8>(x[1].x, x[3].x); lat_swap_row<8>(x[1].y, x[3].y);
+}
+__device__ __forceinline__ void lat_transpose_e0_l2(double2 (&x)[4]) {
+  lat_swap_row<4>(x[0].x, x[1].x); lat_swap_row<4>(x[0].y, x[1].y);
+  lat_swap_row<4>(x[2].x, x[3].x); lat_swap_row<4>(x[2].y, x[3].y);
+}
+// register bit e0 <-> lane bit 1: quad permute [2, 3, 0, 1] and a per-lane select (`odd2`: lane bit 1 set)
+__device__ __forceinline__ double lat_dpp_xor2(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4E, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4E, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void lat_swap_quad(double &a, double &b, bool odd2) {
+  const double pb = lat_dpp_xor2(b), pa = lat_dpp_xor2(a);
+  const double a2 = odd2 ? pb : a, b2 = odd2 ? b : pa;
+  a = a2;
+  b = b2;
+}
+__device__ __forceinline__ void lat_transpose_e0_l1(double2 (&x)[4], bool odd2) {
+  lat_swap_quad(x[0].x, x[1].x, odd2); lat_swap_quad(x[0].y, x[1].y, odd2);
+  lat_swap_quad(x[2].x, x[3].x, odd2); lat_swap_quad(x[2].y, x[3].y, odd2);
+}
+
 // forward 2-bit pass: the stage of the higher index bit (e1) first; hi = its twiddle (the block does not depend on e), lo0 / lo1
 // the twiddles of the lower stage for e1 = 0 / 1
 __device__ __forceinline__ void lat_fwd_pass(double2 (&x)[4], double2 hi, double2 lo0, double2 lo1) {
@@ -126,7 +169,11 @@ __device__ __forceinline__ void lat_half_barrier(unsigned flags_lane /* byte add
 // OPT packs the lab switches: bits 0-1 LAT_ABL, bits 2-3 SYNC, bits 4-5 PRIO (1: the waves of half 0 at high priority for the
 // whole kernel, 2: those of half 1), bit 6 GPF (the GGSW rows of iteration i + 1 requested right behind the external product of
 // iteration i -- a whole iteration ahead, into the registers that have just died -- instead of at the top of iteration i + 1)
-constexpr int lat_opt(int abl, int sync, int prio, int gpf, int stamp = 0) { return abl | (sync << 2) | (prio << 4) | (gpf << 6) | (stamp << 7); }
+constexpr int lat_opt(int abl, int sync, int prio, int gpf, int stamp = 0, int ils = 0) { return abl | (sync << 2) | (prio << 4) | (gpf << 6) | (stamp << 7) | (ils << 8); }   // + bit 9 RPRE, below
+// what the product launches: GGSW rows a whole iteration ahead, stores pair by pair behind their butterflies (-3 %), the next
+// iteration's rotated-read addresses in front of the closing barrier (-2.5 %): 2.47 -> 2.33 ms per bootstrap in the same run
+// (profiles/r05_probe14_lat_ils_rpre_v2.txt; layout v2 -- no LDS inside a wave -- is 3 % SLOWER: 80 more VALU slots per transform)
+constexpr int kLatDefaultOpt = lat_opt(0, 0, 0, 1, 0, 1) | (1 << 9);
 constexpr int kLatStamps = 32, kLatStampIter = 300;   // bit 7 STAMP: every wave records s_memtime at the marked points of ONE iteration (lab)
 template <int BL, int OPT = 0>
 __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
@@ -136,6 +183,15 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     const double2 *__restrict__ psi, unsigned long long *__restrict__ stamps = nullptr) {
   constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2;
   constexpr int LAT_ABL = OPT & 3, SYNC = (OPT >> 2) & 3, PRIO = (OPT >> 4) & 3, GPF = (OPT >> 6) & 1, STAMP = (OPT >> 7) & 1;
+  // bit 8 ILS: the stores of an exchange go out pair by pair, each behind the last butterfly that produces it, instead of as one
+  // burst behind the pass
+  constexpr bool ILS = ((OPT >> 8) & 1) && LAT_ABL == 0;
+  // bit 9 RPRE: the addresses and sign masks of the NEXT iteration's rotated reads are formed in front of the closing barrier (the
+  // rotation is known since B1), where the wave waits for its image stores anyway -- not behind it, on every wave's critical path
+  constexpr bool RPRE = ((OPT >> 9) & 1) != 0;
+  // bit 10 V2: the in-wave part without LDS -- C <-> D as transposes with lane bits 3 / 2, D <-> E with lane bit 1 (layouts L_D', L_E':
+  // e = (p3, p2) / (p3, p1); l5 = p6, l4 = p7, l3 = p5, l2 = p4, l1 = p1 / p2, l0 = p0; scripts/model/lat_layouts_v2.py)
+  constexpr bool V2 = ((OPT >> 10) & 1) != 0 && LAT_ABL == 0;
   static_assert(BL >= 1 && BL <= 31, "single-level digit must fit the high dword");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t *img_all = reinterpret_cast<uint64_t *>(smem_raw);                       // [2][N]   image of -acc, plain order
@@ -178,14 +234,17 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
   } while (0)
 
   // ---- slots of this thread in every layout (element indices inside a half's buffer) ----
-  const int blk16 = w * 16 + ((l >> 1) & 15);                 // p >> 4 in layouts D / E
+  const int l1 = (l >> 1) & 1, l2 = (l >> 2) & 1, l3 = (l >> 3) & 1;
+  const bool odd2 = l1 != 0;
+  const int blk16 = V2 ? w * 16 + l4 * 8 + l5 * 4 + l3 * 2 + l2 : w * 16 + ((l >> 1) & 15);   // p >> 4 in layouts D / E
+  const int lE = V2 ? l1 : l5;                                 // the lane bit that holds p1 (layout D) / p2 (layout E)
   int sA[4], sB[4], sC[4], sD[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     sA[e] = q + 256 * e;
     sB[e] = w * 256 + e * 64 + l4 * 32 + l5 * 16 + lo4;
     sC[e] = fswz(w * 256 + l4 * 128 + l5 * 64 + e * 16 + lo4);
-    sD[e] = fswz(blk16 * 16 + e * 4 + l5 * 2 + l0);
+    sD[e] = fswz(blk16 * 16 + e * 4 + l5 * 2 + l0);   // (layout v1 only)
   }
 
   // ---- every twiddle of both transforms, once (registers for the whole loop) ----
@@ -195,17 +254,17 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
   const int blkC = w * 4 + l4 * 2 + l5;                       // p >> 6 in layout C
   const double2 fC_hi = psi[16 + blkC], fC_lo0 = psi[32 + 2 * blkC], fC_lo1 = psi[32 + 2 * blkC + 1];
   const double2 fD_hi = psi[64 + blk16], fD_lo0 = psi[128 + 2 * blk16], fD_lo1 = psi[128 + 2 * blk16 + 1];
-  const double2 fE_0 = psi[256 + blk16 * 4 + l5], fE_1 = psi[256 + blk16 * 4 + 2 + l5];   // stage of p1: block = (p >> 2)
+  const double2 fE_0 = psi[256 + blk16 * 4 + lE], fE_1 = psi[256 + blk16 * 4 + 2 + lE];   // stage of p1: block = (p >> 2)
   double2 cd[4];                                              // lane-pair stage: t on even lanes, (-t.x, t.y) on odd lanes
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const double2 t = psi[512 + blk16 * 8 + (e >> 1) * 4 + l5 * 2 + (e & 1)];
+    const double2 t = psi[512 + blk16 * 8 + (e >> 1) * 4 + lE * 2 + (e & 1)];
     cd[e] = l0 ? make_double2(-t.x, t.y) : t;
   }
   // inverse: tw[(index bits below the stage's bit) << (9 - bit)]
   const double sgn = l0 ? -1.0 : 1.0;
   const double2 iE = tw[l0 << 8];
-  const int low2 = l5 * 2 + l0;                               // (p1, p0) in layout D
+  const int low2 = lE * 2 + l0;                               // (p1, p0) in layout D
   const double2 iD_lo = tw[low2 << 7], iD_hi0 = tw[low2 << 6], iD_hi1 = tw[(4 + low2) << 6];
   const double2 iC_lo = tw[lo4 << 5], iC_hi0 = tw[lo4 << 4], iC_hi1 = tw[(16 + lo4) << 4];
   const int low6 = l4 * 32 + l5 * 16 + lo4;                   // p5..p0 in layout B
@@ -219,7 +278,7 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
   // sits at e8 = (p3 p2 p1) = e1 * 4 + l5 * 2 + e0, position (p >> 4) * 2 + p0 = w * 32 + (l & 31) ----
   const __amdgpu_buffer_rsrc_t rs_g =
       __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_small * 4 * M * 16), 0x00020000);
-  const unsigned voff_g = (unsigned)((r * 8 + l5 * 2) * 128 + w * 32 + (l & 31)) * 16u;
+  const unsigned voff_g = V2 ? (unsigned)((r * 8 + l1 * 2) * 128 + blk16 * 2 + l0) * 16u : (unsigned)((r * 8 + l5 * 2) * 128 + w * 32 + (l & 31)) * 16u;
 
   const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
   auto modswitch_of = [&](uint64_t v) __attribute__((always_inline)) {
@@ -262,6 +321,22 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     }
   };
   if (GPF) load_ggsw(0);
+  // rotated reads: word indices into the image and sign masks (-1: negate) of the coefficients p - a and p + M - a
+  unsigned ri0[4], ri1[4];
+  int m0v[4], m1v[4];
+  auto rot_prepare = [&](int a) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned s0 = (unsigned)(q + 256 * e - a) & (unsigned)(2 * N - 1);
+      const unsigned s1 = (s0 + (unsigned)M) & (unsigned)(2 * N - 1);
+      // the image holds -acc: the operand is +acc[s] = -image when the rotation did NOT wrap, -acc[s] = image when it did
+      m0v[e] = (int)((s0 >> LOGN) & 1u) - 1;   // -1: negate
+      m1v[e] = (int)((s1 >> LOGN) & 1u) - 1;
+      ri0[e] = s0 & (unsigned)(N - 1);
+      ri1[e] = s1 & (unsigned)(N - 1);
+    }
+  };
+  if (RPRE) rot_prepare(a_next);
   for (int i = 0; i < n_small; ++i) {
     const int a = a_next;
     it_now = i;
@@ -270,16 +345,11 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     // ---- digits of X^a acc - acc at the own coefficients p (re) and p + M (im) ----
     {
       uint64_t va[4], vb[4];
-      int m0v[4], m1v[4];
+      if (!RPRE) rot_prepare(a);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const unsigned s0 = (unsigned)(q + 256 * e - a) & (unsigned)(2 * N - 1);
-        const unsigned s1 = (s0 + (unsigned)M) & (unsigned)(2 * N - 1);
-        // the image holds -acc: the operand is +acc[s] = -image when the rotation did NOT wrap, -acc[s] = image when it did
-        m0v[e] = (int)((s0 >> LOGN) & 1u) - 1;   // -1: negate
-        m1v[e] = (int)((s1 >> LOGN) & 1u) - 1;
-        va[e] = img[s0 & (unsigned)(N - 1)];
-        vb[e] = img[s1 & (unsigned)(N - 1)];
+        va[e] = img[ri0[e]];
+        vb[e] = img[ri1[e]];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -304,11 +374,21 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     if (!GPF) load_ggsw(i);
     // ---- forward transform ----
     FHES_LAT_STAMP(1);
+    if (ILS) {
+      fwd_butterfly(x[0], x[2], fA_hi);
+      fwd_butterfly(x[1], x[3], fA_hi);
+      fwd_butterfly(x[0], x[1], fA_lo0);
+      x1[sA[0]] = x[0]; x1[sA[1]] = x[1];
+      __builtin_amdgcn_sched_barrier(0);
+      fwd_butterfly(x[2], x[3], fA_lo1);
+      x1[sA[2]] = x[2]; x1[sA[3]] = x[3];
+    } else {
     if (LAT_ABL != 2) lat_fwd_pass(x, fA_hi, fA_lo0, fA_lo1);                  // bits 9, 8
     FHES_LAT_STAMP(2);
     if (LAT_ABL != 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x1[sA[e]] = x[e];
+    }
     }
     a_next = modswitch_of(ks_next);
     asm volatile("" : "+s"(a_next));
@@ -323,11 +403,24 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     if (LAT_ABL != 2) lat_fwd_pass(x, fB_hi, fB_lo0, fB_lo1);                  // bits 7, 6
     lat_transpose_e0_l5(x);
     lat_transpose_e1_l4(x);                                                     // -> L_C
-    if (LAT_ABL != 2) lat_fwd_pass(x, fC_hi, fC_lo0, fC_lo1);                  // bits 5, 4
+    if (ILS && !V2) {
+      fwd_butterfly(x[0], x[2], fC_hi);
+      fwd_butterfly(x[1], x[3], fC_hi);
+      fwd_butterfly(x[0], x[1], fC_lo0);
+      x2[sC[0]] = x[0]; x2[sC[1]] = x[1];
+      __builtin_amdgcn_sched_barrier(0);
+      fwd_butterfly(x[2], x[3], fC_lo1);
+      x2[sC[2]] = x[2]; x2[sC[3]] = x[3];
+    } else if (LAT_ABL != 2) lat_fwd_pass(x, fC_hi, fC_lo0, fC_lo1);                  // bits 5, 4
     FHES_LAT_STAMP(5);
-    if (LAT_ABL != 1) {
+    if (V2) {
+      lat_transpose_e1_l3(x);
+      lat_transpose_e0_l2(x);                                                   // -> L_D' (no LDS)
+    } else if (LAT_ABL != 1) {
+      if (!ILS) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x2[sC[e]] = x[e];
+      }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[e] = x2[sD[e]];
@@ -335,7 +428,25 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     }
     FHES_LAT_STAMP(6);
     if (LAT_ABL != 2) lat_fwd_pass(x, fD_hi, fD_lo0, fD_lo1);                  // bits 3, 2
-    lat_transpose_e0_l5(x);                                                     // -> L_E
+    if (V2) lat_transpose_e0_l1(x, odd2); else lat_transpose_e0_l5(x);          // -> L_E
+    if (ILS) {
+      auto dpp1 = [&](double2 &v, const double2 c) __attribute__((always_inline)) {   // lat_fwd_stage0_dpp on one point
+        const double px = dpp_swap1(v.x), py = dpp_swap1(v.y);
+        double re = __builtin_fma(c.x, px, v.x);
+        re = __builtin_fma(-c.y, py, re);
+        double im = __builtin_fma(c.x, py, v.y);
+        im = __builtin_fma(c.y, px, im);
+        v = make_double2(re, im);
+      };
+      double2 *sw = s_r + (i & 1) * 2 * M + q;
+      fwd_butterfly(x[0], x[1], fE_0);
+      dpp1(x[0], cd[0]); dpp1(x[1], cd[1]);
+      sw[0] = x[0]; sw[256] = x[1];
+      __builtin_amdgcn_sched_barrier(0);
+      fwd_butterfly(x[2], x[3], fE_1);
+      dpp1(x[2], cd[2]); dpp1(x[3], cd[3]);
+      sw[512] = x[2]; sw[768] = x[3];
+    } else {
     if (LAT_ABL != 2) {
       fwd_butterfly(x[0], x[1], fE_0);                                          // bit 1
       fwd_butterfly(x[2], x[3], fE_1);
@@ -345,6 +456,7 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     if (LAT_ABL != 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) s_r[(i & 1) * 2 * M + e * 256 + q] = x[e];
+    }
     }
     FHES_LAT_STAMP(8);
     __syncthreads();  // B3: the one dependence between the halves.  S alternates between two buffers: with the halves free of
@@ -379,12 +491,25 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
       inv_butterfly(x[0], x[1], iE);                                            // bit 1
       inv_butterfly(x[2], x[3], iE);
     }
-    lat_transpose_e0_l5(x);                                                     // -> L_D
-    if (LAT_ABL != 2) lat_inv_pass(x, iD_lo, iD_hi0, iD_hi1);                  // bits 2, 3
+    if (V2) lat_transpose_e0_l1(x, odd2); else lat_transpose_e0_l5(x);          // -> L_D
+    if (ILS && !V2) {
+      inv_butterfly(x[0], x[1], iD_lo);
+      inv_butterfly(x[2], x[3], iD_lo);
+      inv_butterfly(x[0], x[2], iD_hi0);
+      x2[sD[0]] = x[0]; x2[sD[2]] = x[2];
+      __builtin_amdgcn_sched_barrier(0);
+      inv_butterfly(x[1], x[3], iD_hi1);
+      x2[sD[1]] = x[1]; x2[sD[3]] = x[3];
+    } else if (LAT_ABL != 2) lat_inv_pass(x, iD_lo, iD_hi0, iD_hi1);                  // bits 2, 3
     FHES_LAT_STAMP(11);
-    if (LAT_ABL != 1) {
+    if (V2) {
+      lat_transpose_e0_l2(x);
+      lat_transpose_e1_l3(x);                                                   // -> L_C (no LDS)
+    } else if (LAT_ABL != 1) {
+      if (!ILS) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x2[sD[e]] = x[e];
+      }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[e] = x2[sC[e]];
@@ -394,11 +519,21 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
     if (LAT_ABL != 2) lat_inv_pass(x, iC_lo, iC_hi0, iC_hi1);                  // bits 4, 5
     lat_transpose_e0_l5(x);
     lat_transpose_e1_l4(x);                                                     // -> L_B
+    if (ILS) {
+      inv_butterfly(x[0], x[1], iB_lo);
+      inv_butterfly(x[2], x[3], iB_lo);
+      inv_butterfly(x[0], x[2], iB_hi0);
+      x1[sB[0]] = x[0]; x1[sB[2]] = x[2];
+      __builtin_amdgcn_sched_barrier(0);
+      inv_butterfly(x[1], x[3], iB_hi1);
+      x1[sB[1]] = x[1]; x1[sB[3]] = x[3];
+    } else {
     if (LAT_ABL != 2) lat_inv_pass(x, iB_lo, iB_hi0, iB_hi1);                  // bits 6, 7
     FHES_LAT_STAMP(13);
     if (LAT_ABL != 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x1[sB[e]] = x[e];
+    }
     }
     FHES_LAT_STAMP(14);
     FHES_LAT_HALF_BARRIER();  // B5: the half's own
@@ -418,6 +553,11 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
       nhi[e] = add64(torus_from_f64_pair(v.y), nhi[e]);
       img[q + 256 * e] = nlo[e];
       img[q + 256 * e + M] = nhi[e];
+    }
+    if (RPRE) {
+      rot_prepare(a_next);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(ri0[e]), "+v"(ri1[e]), "+v"(m0v[e]), "+v"(m1v[e]));   // materialised HERE
     }
     FHES_LAT_STAMP(17);
     FHES_LAT_HALF_BARRIER();  // B6: the half's own (a half rotates its own polynomial)

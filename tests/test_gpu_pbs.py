@@ -160,7 +160,7 @@ def test_all_blind_rotate_variants_agree(libs):
     # 3 / 7 = the throughput build, 12 = the generic kernel (an independent implementation); a lab build (FHES_LAB=1) adds the
     # retired ones: 1 the simple kernel, 5 / 6 priority policies, 8 three workgroups per CU, 20 / 21 / 25 switches of the latency build
     lab = os.environ.get("FHES_LAB") == "1"
-    variants = (12, 0, 2, 3, 7) + ((1, 5, 6, 8, 20, 21, 25) if lab else ())
+    variants = (12, 0, 2, 3, 7) + ((1, 5, 6, 8, 20, 21, 23, 24, 25) if lab else ())
     try:
         for variant in variants:
             check(w.lib.fhes_set_kernel_variant(ctx, variant))
@@ -176,7 +176,7 @@ def test_all_blind_rotate_variants_agree(libs):
                 assert np.array_equal(res, first), f"variant {variant} differs from the generic kernel"
         # what is not in the build is refused, and so are the timing-only ablations (wrong results by construction) unless a
         # developer asks by name
-        refused = (9, 10, 13, 14, 22, 23, 24) if (lab and os.environ.get("FHES_DEV_ABLATIONS") != "1") else (() if lab else (1, 5, 6, 8, 9, 10, 13, 14, 20, 26))
+        refused = (9, 10, 13, 14, 22) if (lab and os.environ.get("FHES_DEV_ABLATIONS") != "1") else (() if lab else (1, 5, 6, 8, 9, 10, 13, 14, 20, 26))
         for variant in refused + (11, 99, -1):
             assert w.lib.fhes_set_kernel_variant(ctx, variant) != 0, variant
     finally:
