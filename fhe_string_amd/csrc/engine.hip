@@ -515,6 +515,20 @@ static int launch_br_mb(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+// the 512-thread latency build of the multi-bit blind rotate (kernel_br_lat.hip.h); N = 2048
+template <int G, bool ILV, int BL = 23>
+static int launch_br_mb_lat(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_mb_lat<G, ILV, 18>(ctx, lane, d);
+  const int n_deg = (ctx->dims.n / G) * ((1 << G) - 1);
+  const size_t lds = dev::lat_mb_lds_bytes(n_deg);
+  auto kern = dev::blind_rotate_mb_lat_kernel<BL, G, ILV>;
+  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(dev::kLatThreads), lds, lane.stream, d, ctx->arena, ctx->ct_stride, lane.ks_out,
+                     ctx->ks_stride, ctx->dims.n, ctx->bsk_e, ctx->lut_polys, ctx->twist_inv, ctx->tw, ctx->root, ctx->psi);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
 template <int LOGN, int PRIO = 0, int BL = 23>
 static int launch_br_v5(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_v5<LOGN, PRIO, 18>(ctx, lane, d);
@@ -684,6 +698,12 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
     // workgroup per CU: everything in registers, bundle pipeline), throughput with the pipeline
     // (g = 3) and without (g = 2).  br_variant 2 forces the latency build, 3 the throughput build.
     const bool lat = ctx->br_variant == 2 || (ctx->br_variant == 0 && d.v_count <= ctx->n_cus);
+    // the 512-thread latency build: the automatic choice for one-per-CU launches at N = 2048 (variant 2 forces it; variant 4 forces it
+    // even when FHES_MB_LAT512=0 switched the automatic choice off)
+    if (ctx->dims.N == 2048 && (ctx->br_variant == 4 || ((ctx->br_variant == 0 || ctx->br_variant == 2) && ctx->mb_lat512 && (ctx->br_variant == 2 || d.v_count <= ctx->lat_max)))) {
+      if (ctx->dims.g == 3) return ctx->mb_ilv ? launch_br_mb_lat<3, true>(ctx, lane, d) : launch_br_mb_lat<3, false>(ctx, lane, d);
+      return ctx->mb_ilv ? launch_br_mb_lat<2, true>(ctx, lane, d) : launch_br_mb_lat<2, false>(ctx, lane, d);
+    }
     if (ctx->dims.g == 3) {  // measured: the latency build gains nothing for g = 3 (3.21 vs 3.16 ms)
       if (ctx->mb_ilv) return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true, false, 23, true>(ctx, lane, d) : launch_br_mb<8, 3, true, false, 23, true>(ctx, lane, d);
       return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true>(ctx, lane, d) : launch_br_mb<8, 3, true>(ctx, lane, d);
@@ -894,6 +914,10 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   // build for every size, another number moves the switch-over (developer knob, scripts/lat_probe.py)
   ctx->lat_max = ctx->n_cus;
   if (const char *e6 = getenv("FHES_LAT_MAX")) ctx->lat_max = atoi(e6) < 0 ? 0 : atoi(e6);
+  // multi-bit sets at N = 2048: one-per-CU launches take the 512-thread latency build (g = 2: 2.05 against 2.52 ms per bootstrap,
+  // g = 3: 2.24 against 2.34; FHES_MB_LAT512=0 keeps the 256-thread one, which also serves the N = 256 test sets)
+  ctx->mb_lat512 = d.g > 1 && d.N == 2048;
+  if (const char *e7 = getenv("FHES_MB_LAT512")) ctx->mb_lat512 = atoi(e7) != 0;
   if (const char *e5 = getenv("FHES_KS_MFMA_MIN")) ctx->ks_mfma_min = atoi(e5);  // developer knob: 0 = VALU keyswitch only, 1 = always MFMA
   if (const char *e3 = getenv("FHES_KS_TB")) ctx->ks_tb = atoi(e3);  // developer knob: 8 / 16 force the tile height
   if (const char *e2 = getenv("FHES_KS_MIN_CPS")) {
@@ -1238,7 +1262,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  const bool product = v == 0 || v == 2 || v == 3 || v == 7 || v == 12;
+  const bool product = v == 0 || v == 2 || v == 3 || v == 4 || v == 7 || v == 12;
 #ifdef FHES_LAB
   if (v >= 100 && v < 100 + (int)ctx->lab_bsk_e.size()) {   // lab: switch to another copy of the engine-layout key
     (void)hipDeviceSynchronize();

@@ -577,5 +577,304 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_lat_kernel(
   if (tid == 0) out[N] = (uint64_t)0 - img_all[N];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Latency build of the MULTI-BIT blind rotate (round 5; grouping factor G = 2, 3; k = 1, one level, N = 2048): the 512-thread
+// shape of blind_rotate_lat_kernel -- layouts L_A .. L_E, permlane transposes, every twiddle in registers -- around the step of
+// blind_rotate_mb_kernel:
+//     bundle = G_0 + sum_{c >= 1} G_c * W_c        W_c[p] = root[deg_c (1 - 4 b_S)] * root[-4 deg_c b_L]   (monomial factors)
+//     acc   <- bundle (x) acc                       digits of acc itself; the accumulator is REPLACED, and lives in registers
+// No rotation inside the loop, so there is no image of the accumulator and no barrier at the end of a step: the next step's
+// first exchange goes into the slots this thread has just read.  Three workgroup barriers per step (A <-> B of both transforms,
+// the hand-over of the spectra).  A multi-bit bootstrap is n / G steps against n CMUX iterations of the classic one: with the
+// step at the classic latency build's cycles plus the bundle, ONE bootstrap is shorter than a classic one.
+// The bundle of step j + 1 is built while step j runs its inverse transform (b0 / b1 are dead behind the external product):
+// batches of one point x CB monomials are requested in one slot and consumed in the next.  In layout E a thread's four points
+// differ in p3 and p1 while p2 is lane bit 5, so the "uniform" factor of a monomial takes two values per wave: a vector load of
+// two addresses (two lines).
+// LDS: X double2[2][M] (A <-> B and, wave-local, C <-> D) | S double2[2 parities][2][M] | degrees u16[(n / G)(2^G - 1)].
+// ------------------------------------------------------------------------------------------
+constexpr size_t lat_mb_lds_bytes(int n_deg) { return (size_t)2 * 1024 * 16 + (size_t)2 * 2 * 1024 * 16 + (size_t)((n_deg + 7) & ~7) * 2; }
+
+template <int BL, int G, bool ILV>
+__global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_mb_lat_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride, int n_small,
+    const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys, const double2 *__restrict__ twist_inv /* twist / M */,
+    const double2 *__restrict__ tw, const double2 *__restrict__ root /* [2N] */, const double2 *__restrict__ psi) {
+  constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2, NC = 1 << G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double2 *x1_all = reinterpret_cast<double2 *>(smem_raw);            // [2][M]
+  double2 *s_all = x1_all + 2 * M;                                    // [2 parities][2][M]
+  uint16_t *degs = reinterpret_cast<uint16_t *>(s_all + 4 * M);
+
+  const int tid = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int w = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+  const int q = tid & 255;
+  const int l = tid & 63;
+  const int l0 = l & 1, l4 = (l >> 4) & 1, l5 = (l >> 5) & 1, lo4 = l & 15;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+  const int n_groups = n_small / G;
+  double2 *x1 = x1_all + (size_t)r * M;
+  double2 *x2 = x1;
+  double2 *s_r = s_all + (size_t)r * M;
+  const double2 *s_o = s_all + (size_t)(1 - r) * M;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  for (int idx = tid; idx < n_groups * (NC - 1); idx += kLatThreads) {
+    const int j = idx / (NC - 1), c = idx % (NC - 1) + 1;
+    uint64_t sum = 0;
+#pragma unroll
+    for (int t = 0; t < G; ++t)
+      if ((c >> (G - 1 - t)) & 1) sum += ks[j * G + t];
+    degs[idx] = (uint16_t)((((sum >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  }
+
+  const int blk16 = w * 16 + ((l >> 1) & 15);
+  int sA[4], sB[4], sC[4], sD[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sA[e] = q + 256 * e;
+    sB[e] = w * 256 + e * 64 + l4 * 32 + l5 * 16 + lo4;
+    sC[e] = fswz(w * 256 + l4 * 128 + l5 * 64 + e * 16 + lo4);
+    sD[e] = fswz(blk16 * 16 + e * 4 + l5 * 2 + l0);
+  }
+  // every twiddle of both transforms (as in blind_rotate_lat_kernel)
+  const double2 fA_hi = psi[1], fA_lo0 = psi[2], fA_lo1 = psi[3];
+  const double2 fB_hi = psi[4 + w], fB_lo0 = psi[8 + 2 * w], fB_lo1 = psi[8 + 2 * w + 1];
+  const int blkC = w * 4 + l4 * 2 + l5;
+  const double2 fC_hi = psi[16 + blkC], fC_lo0 = psi[32 + 2 * blkC], fC_lo1 = psi[32 + 2 * blkC + 1];
+  const double2 fD_hi = psi[64 + blk16], fD_lo0 = psi[128 + 2 * blk16], fD_lo1 = psi[128 + 2 * blk16 + 1];
+  const double2 fE_0 = psi[256 + blk16 * 4 + l5], fE_1 = psi[256 + blk16 * 4 + 2 + l5];
+  double2 cd[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double2 t = psi[512 + blk16 * 8 + (e >> 1) * 4 + l5 * 2 + (e & 1)];
+    cd[e] = l0 ? make_double2(-t.x, t.y) : t;
+  }
+  const double sgn = l0 ? -1.0 : 1.0;
+  const double2 iE = tw[l0 << 8];
+  const int low2 = l5 * 2 + l0;
+  const double2 iD_lo = tw[low2 << 7], iD_hi0 = tw[low2 << 6], iD_hi1 = tw[(4 + low2) << 6];
+  const double2 iC_lo = tw[lo4 << 5], iC_hi0 = tw[lo4 << 4], iC_hi1 = tw[(16 + lo4) << 4];
+  const int low6 = l4 * 32 + l5 * 16 + lo4;
+  const double2 iB_lo = tw[low6 << 3], iB_hi0 = tw[low6 << 2], iB_hi1 = tw[(64 + low6) << 2];
+  const double2 iA_lo = tw[q << 1], iA_hi0 = tw[q], iA_hi1 = tw[256 + q];
+
+  // Fourier key: point p of layout E sits at e8 = (p3 p2 p1) = e1 * 4 + l5 * 2 + e0, position w * 32 + (l & 31) of a polynomial
+  // (blind_rotate_lat_kernel); GGSW c of group j: plain layout [c][row][col][e8][128], interleaved [row][col][e8][c][128]
+  const __amdgpu_buffer_rsrc_t rs_g =
+      __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_groups * NC * 4 * M * 16), 0x00020000);
+  const unsigned voff_g = ILV ? (unsigned)((r * 8 + l5 * 2) * NC * 128 + w * 32 + (l & 31)) * 16u
+                              : (unsigned)((r * 8 + l5 * 2) * 128 + w * 32 + (l & 31)) * 16u;
+  auto goff = [&](unsigned so, int c, int row, int e) __attribute__((always_inline)) {
+    const int e8 = (e >> 1) * 4 + (e & 1);
+    return ILV ? so + (unsigned)(((row * 16 + e8) * NC + c) * 128 * 16) : so + (unsigned)c * (unsigned)(4 * M * 16) + (unsigned)((row * 16 + e8) * 128 * 16);
+  };
+  // monomial factors: b = bitrev(p); b_S = (p3, p2, p1) << 6 (p2 = lane bit 5 here), b_L = bitrev of the point with those bits cleared
+  const int pz = w * 256 + ((l >> 1) & 15) * 16 + l0;
+  const int lexp = (-4 * (int)(__brev((unsigned)pz) >> (32 - 10))) & (2 * N - 1);
+  auto mono_uniform = [&](int dg, int e) __attribute__((always_inline)) {   // root[deg (1 - 4 b_S)], b_S = ((e1) + 2 l5 + 4 (e0)) << 6
+    const int bs4 = (((e >> 1) & 1) + 2 * l5 + 4 * (e & 1)) << 8;
+    return root[(dg - ((dg * bs4) & (2 * N - 1))) & (2 * N - 1)];
+  };
+
+  // ---- acc = (0, X^{-b~} LUT) in registers: coefficients p and p + M of polynomial r, p = q + 256 e (layout A) ----
+  uint64_t own_lo[4], own_hi[4];
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int bt = (int)((((ks[n_small] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+    const int t = (2 * N - bt) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = q + 256 * e;
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      own_lo[e] = v0;
+      own_hi[e] = v1;
+    }
+  }
+  __syncthreads();   // the degrees are in LDS
+
+  // ---- bundle pipeline: batches of one point x CB monomials, monomial range by monomial range ----
+  constexpr int CB = G == 2 ? NC - 1 : 2, NCB = (NC - 1 + CB - 1) / CB, NBATCH = 4 * NCB;   // (g = 3 with CB = 4 spills 19 registers)
+  double2 b0[4], b1[4], tg0[CB], tg1[CB], rw[CB], su[CB];
+  int deg[NC];
+  auto bundle_degrees = [&](int jn) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 1; c < NC; ++c) deg[c] = __builtin_amdgcn_readfirstlane((int)degs[jn * (NC - 1) + (c - 1)]);
+  };
+  auto bundle_issue = [&](int jn, int k) __attribute__((always_inline)) {
+    const int e = k % 4, cb = 1 + (k / 4) * CB;
+    const unsigned so = (unsigned)jn * (unsigned)(NC * 4 * M * 16);
+    if (e == 0) {
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc)
+        if (cb + cc < NC) rw[cc] = root[(lexp * deg[cb + cc]) & (2 * N - 1)];
+    }
+    if (cb == 1) {
+      b0[e] = buf_load_d2(rs_g, voff_g, goff(so, 0, 0, e));
+      b1[e] = buf_load_d2(rs_g, voff_g, goff(so, 0, 1, e));
+    }
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) {
+      const int c = cb + cc;
+      if (c >= NC) continue;
+      su[cc] = mono_uniform(deg[c], e);
+      tg0[cc] = buf_load_d2(rs_g, voff_g, goff(so, c, 0, e));
+      tg1[cc] = buf_load_d2(rs_g, voff_g, goff(so, c, 1, e));
+    }
+  };
+  auto bundle_consume = [&](int k) __attribute__((always_inline)) {
+    const int e = k % 4, cb = 1 + (k / 4) * CB;
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) {
+      if (cb + cc >= NC) continue;
+      const double2 wv = cmul(su[cc], rw[cc]);
+      b0[e] = cfma(tg0[cc], wv, b0[e]);
+      b1[e] = cfma(tg1[cc], wv, b1[e]);
+    }
+  };
+  auto bundle_advance = [&](int jn, int first, int count) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = first; k < first + count; ++k) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (k > 0) bundle_consume(k - 1);
+      bundle_issue(jn, k);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // the batches of a step are spread over five slots of the inverse transform
+  constexpr int Q1 = NBATCH / 5 > 0 ? NBATCH / 5 : 1, Q2 = (2 * NBATCH) / 5, Q3 = (3 * NBATCH) / 5, Q4 = (4 * NBATCH) / 5;
+  // (Tried and dropped: touching the lines of group j + 2 two steps ahead with one-dword loads -- a lone bootstrap finds its key in the
+  // Infinity Cache at best.  The counter of vector loads retires in order, so every real load of the pipeline then waits for the
+  // touches in front of it: 2.57 against 2.11 ms (g = 2), 3.0 against 2.37 ms (g = 3); profiles/r05_probe17_*.)
+  bundle_degrees(0);
+  bundle_advance(0, 0, NBATCH);
+
+  for (int j = 0; j < n_groups; ++j) {
+    const int jn = j + 1 < n_groups ? j + 1 : j;   // the last step rebuilds its own bundle (unused)
+    double2 x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = make_double2(digit1_f64<BL>(own_lo[e]), digit1_f64<BL>(own_hi[e]));
+    // ---- forward transform ----
+    fwd_butterfly(x[0], x[2], fA_hi);
+    fwd_butterfly(x[1], x[3], fA_hi);
+    fwd_butterfly(x[0], x[1], fA_lo0);
+    x1[sA[0]] = x[0]; x1[sA[1]] = x[1];
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_butterfly(x[2], x[3], fA_lo1);
+    x1[sA[2]] = x[2]; x1[sA[3]] = x[3];
+    __syncthreads();  // B1
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = x1[sB[e]];
+    __builtin_amdgcn_sched_barrier(0);
+    lat_fwd_pass(x, fB_hi, fB_lo0, fB_lo1);
+    lat_transpose_e0_l5(x);
+    lat_transpose_e1_l4(x);
+    fwd_butterfly(x[0], x[2], fC_hi);
+    fwd_butterfly(x[1], x[3], fC_hi);
+    fwd_butterfly(x[0], x[1], fC_lo0);
+    x2[sC[0]] = x[0]; x2[sC[1]] = x[1];
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_butterfly(x[2], x[3], fC_lo1);
+    x2[sC[2]] = x[2]; x2[sC[3]] = x[3];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = x2[sD[e]];
+    __builtin_amdgcn_sched_barrier(0);
+    lat_fwd_pass(x, fD_hi, fD_lo0, fD_lo1);
+    lat_transpose_e0_l5(x);
+    fwd_butterfly(x[0], x[1], fE_0);
+    fwd_butterfly(x[2], x[3], fE_1);
+    lat_fwd_stage0_dpp(x, cd);
+    {
+      double2 *sw = s_r + (j & 1) * 2 * M + q;
+      sw[0] = x[0]; sw[256] = x[1]; sw[512] = x[2]; sw[768] = x[3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bundle_consume(NBATCH - 1);   // last batch of this step's bundle
+    __syncthreads();  // B3: the spectra meet
+    {
+      double2 oth[4];
+      const double2 *so_ = s_o + (j & 1) * 2 * M + q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) oth[e] = so_[e * 256];
+      __builtin_amdgcn_sched_barrier(0);
+      if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = ext_mac(x[e], oth[e], b0[e], b1[e]);
+        asm volatile("; end of form r = 0");
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = ext_mac(oth[e], x[e], b0[e], b1[e]);
+        asm volatile("; end of form r = 1");
+      }
+    }
+    bundle_degrees(jn);
+    bundle_advance(jn, 0, Q1);
+    // ---- inverse transform ----
+    lat_inv_stage0_dpp(x, sgn);
+    inv_butterfly(x[0], x[1], iE);
+    inv_butterfly(x[2], x[3], iE);
+    lat_transpose_e0_l5(x);
+    inv_butterfly(x[0], x[1], iD_lo);
+    inv_butterfly(x[2], x[3], iD_lo);
+    inv_butterfly(x[0], x[2], iD_hi0);
+    x2[sD[0]] = x[0]; x2[sD[2]] = x[2];
+    __builtin_amdgcn_sched_barrier(0);
+    inv_butterfly(x[1], x[3], iD_hi1);
+    x2[sD[1]] = x[1]; x2[sD[3]] = x[3];
+    bundle_advance(jn, Q1, Q2 - Q1);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = x2[sC[e]];
+    __builtin_amdgcn_sched_barrier(0);
+    lat_inv_pass(x, iC_lo, iC_hi0, iC_hi1);
+    bundle_advance(jn, Q2, Q3 - Q2);
+    lat_transpose_e0_l5(x);
+    lat_transpose_e1_l4(x);
+    inv_butterfly(x[0], x[1], iB_lo);
+    inv_butterfly(x[2], x[3], iB_lo);
+    inv_butterfly(x[0], x[2], iB_hi0);
+    x1[sB[0]] = x[0]; x1[sB[2]] = x[2];
+    __builtin_amdgcn_sched_barrier(0);
+    inv_butterfly(x[1], x[3], iB_hi1);
+    x1[sB[1]] = x[1]; x1[sB[3]] = x[3];
+    bundle_advance(jn, Q3, Q4 - Q3);
+    __syncthreads();  // B5
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = x1[sA[e]];
+    __builtin_amdgcn_sched_barrier(0);
+    lat_inv_pass(x, iA_lo, iA_hi0, iA_hi1);
+    bundle_advance(jn, Q4, NBATCH - Q4);
+    // ---- untwist, round to the torus: the new accumulator (the next step writes into the slots this thread has just read) ----
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double2 v = cmul_conj(x[e], twist_inv[q + 256 * e]);
+      own_lo[e] = torus_from_f64_fast(v.x);
+      own_hi[e] = torus_from_f64_fast(v.y);
+    }
+  }
+
+  // ---- sample extract from registers: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int p = q + 256 * e;
+    if (r == 0) {
+      if (p == 0) out[0] = own_lo[e];
+      else out[N - p] = (uint64_t)0 - own_lo[e];
+      out[N - (p + M)] = (uint64_t)0 - own_hi[e];
+    } else if (p == 0) {
+      out[N] = own_lo[e];
+    }
+  }
+}
+
 }  // namespace dev
 }  // namespace fhes
