@@ -701,8 +701,10 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
     // the 512-thread latency build: the automatic choice for one-per-CU launches at N = 2048 (variant 2 forces it; variant 4 forces it
     // even when FHES_MB_LAT512=0 switched the automatic choice off)
     if (ctx->dims.N == 2048 && (ctx->br_variant == 4 || ((ctx->br_variant == 0 || ctx->br_variant == 2) && ctx->mb_lat512 && (ctx->br_variant == 2 || d.v_count <= ctx->lat_max)))) {
-      if (ctx->dims.g == 3) return ctx->mb_ilv ? launch_br_mb_lat<3, true>(ctx, lane, d) : launch_br_mb_lat<3, false>(ctx, lane, d);
-      return ctx->mb_ilv ? launch_br_mb_lat<2, true>(ctx, lane, d) : launch_br_mb_lat<2, false>(ctx, lane, d);
+      // (g = 3 with the PLAIN key layout -- FHES_MB_INTERLEAVE=0, not the default -- stays on the 256-thread build: that
+      // instantiation of the 512-thread kernel spills four registers)
+      if (ctx->dims.g == 3 && ctx->mb_ilv) return launch_br_mb_lat<3, true>(ctx, lane, d);
+      if (ctx->dims.g == 2) return ctx->mb_ilv ? launch_br_mb_lat<2, true>(ctx, lane, d) : launch_br_mb_lat<2, false>(ctx, lane, d);
     }
     if (ctx->dims.g == 3) {  // measured: the latency build gains nothing for g = 3 (3.21 vs 3.16 ms)
       if (ctx->mb_ilv) return ctx->dims.N == 2048 ? launch_br_mb<11, 3, true, false, 23, true>(ctx, lane, d) : launch_br_mb<8, 3, true, false, 23, true>(ctx, lane, d);
