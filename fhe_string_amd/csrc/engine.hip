@@ -529,6 +529,32 @@ static int launch_br_mb_lat(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+// the SPLIT multi-bit blind rotate (kernel_br_lat.hip.h): every bundle of every step on the whole device, then the sequential part
+template <int G, bool ILV, int BL = 23>
+static int launch_br_mb_split(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_mb_split<G, ILV, 18>(ctx, lane, d);
+  constexpr int M = 1024;
+  const int n_groups = ctx->dims.n / G;
+  const size_t need = (size_t)d.v_count * n_groups * 4 * M * 16;
+  if (lane.gen_scratch_bytes < need) {
+    lane.drop(lane.gen_scratch);
+    lane.gen_scratch = nullptr;
+    lane.gen_scratch_bytes = 0;
+    FHES_HIP(hipMalloc(&lane.gen_scratch, need));
+    lane.gen_scratch_bytes = need;
+  }
+  double2 *bundles = reinterpret_cast<double2 *>(lane.gen_scratch);
+  hipLaunchKernelGGL((dev::mb_bundle_kernel<G, ILV>), dim3(n_groups * 4), dim3(256), 0, lane.stream, d.v_count, lane.ks_out, ctx->ks_stride,
+                     ctx->dims.n, ctx->bsk_e, ctx->root, bundles);
+  FHES_HIP(hipGetLastError());
+  auto kern = dev::blind_rotate_mb_seq_kernel<BL>;
+  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), dev::kSeqLdsBytes)) return rc;
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(dev::kLatThreads), dev::kSeqLdsBytes, lane.stream, d, ctx->arena, ctx->ct_stride, lane.ks_out,
+                     ctx->ks_stride, ctx->dims.n, n_groups, bundles, ctx->lut_polys, ctx->twist_inv, ctx->tw, ctx->psi);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
 template <int LOGN, int PRIO = 0, int BL = 23>
 static int launch_br_v5(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_v5<LOGN, PRIO, 18>(ctx, lane, d);
@@ -700,6 +726,11 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
     const bool lat = ctx->br_variant == 2 || (ctx->br_variant == 0 && d.v_count <= ctx->n_cus);
     // the 512-thread latency build: the automatic choice for one-per-CU launches at N = 2048 (variant 2 forces it; variant 4 forces it
     // even when FHES_MB_LAT512=0 switched the automatic choice off)
+    // variant 16 (and, once measured, the automatic choice for a handful of bootstraps): bundles first, then the sequential part
+    if (ctx->dims.N == 2048 && d.v_count <= dev::kSplitMax && (ctx->br_variant == 16 || (ctx->br_variant == 0 && ctx->mb_split_max > 0 && d.v_count <= ctx->mb_split_max))) {
+      if (ctx->dims.g == 3) return ctx->mb_ilv ? launch_br_mb_split<3, true>(ctx, lane, d) : launch_br_mb_split<3, false>(ctx, lane, d);
+      return ctx->mb_ilv ? launch_br_mb_split<2, true>(ctx, lane, d) : launch_br_mb_split<2, false>(ctx, lane, d);
+    }
     if (ctx->dims.N == 2048 && (ctx->br_variant == 4 || ((ctx->br_variant == 0 || ctx->br_variant == 2) && ctx->mb_lat512 && (ctx->br_variant == 2 || d.v_count <= ctx->lat_max)))) {
       // (g = 3 with the PLAIN key layout -- FHES_MB_INTERLEAVE=0, not the default -- stays on the 256-thread build: that
       // instantiation of the 512-thread kernel spills four registers)
@@ -920,6 +951,11 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   // g = 3: 2.24 against 2.34; FHES_MB_LAT512=0 keeps the 256-thread one, which also serves the N = 256 test sets)
   ctx->mb_lat512 = d.g > 1 && d.N == 2048;
   if (const char *e7 = getenv("FHES_MB_LAT512")) ctx->mb_lat512 = atoi(e7) != 0;
+  // ... and launches of up to 128 (g = 2) / 192 (g = 3) bootstraps the SPLIT form: every bundle of every step first, on the whole
+  // device, then the sequential kernel (0.75 ms per g = 3 bootstrap against 2.24 fused; break-even at ~160 / ~256 bootstraps:
+  // profiles/r05_probe20_split_crossover.txt; 16-24 MB of scratch per bootstrap).  FHES_MB_SPLIT_MAX=0 switches it off.
+  ctx->mb_split_max = (d.g > 1 && d.N == 2048) ? (d.g == 3 ? 192 : 128) : 0;
+  if (const char *e8 = getenv("FHES_MB_SPLIT_MAX")) ctx->mb_split_max = atoi(e8) < 0 ? 0 : atoi(e8);
   if (const char *e5 = getenv("FHES_KS_MFMA_MIN")) ctx->ks_mfma_min = atoi(e5);  // developer knob: 0 = VALU keyswitch only, 1 = always MFMA
   if (const char *e3 = getenv("FHES_KS_TB")) ctx->ks_tb = atoi(e3);  // developer knob: 8 / 16 force the tile height
   if (const char *e2 = getenv("FHES_KS_MIN_CPS")) {
@@ -1264,7 +1300,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  const bool product = v == 0 || v == 2 || v == 3 || v == 4 || v == 7 || v == 12;
+  const bool product = v == 0 || v == 2 || v == 3 || v == 4 || v == 7 || v == 12 || v == 16;
 #ifdef FHES_LAB
   if (v >= 100 && v < 100 + (int)ctx->lab_bsk_e.size()) {   // lab: switch to another copy of the engine-layout key
     (void)hipDeviceSynchronize();

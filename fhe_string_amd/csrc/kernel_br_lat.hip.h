@@ -876,5 +876,284 @@ __global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_mb_lat_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// SPLIT multi-bit blind rotate for a handful of bootstraps (round 5): the bundles of ALL steps first, on the whole device, then
+// the sequential part alone.
+//
+// A step of the multi-bit blind rotate is  acc <- bundle_j (x) acc  with  bundle_j = G_0 + sum_c G_c W_c  -- and the bundle depends
+// on the key and on the ciphertext's mask (the monomial degrees), NOT on the accumulator.  One call of the reference's API is a chain of
+// levels of 3-4 bootstraps on 3-4 of 256 CUs; the other CUs can build every bundle of every step at once:
+//   mb_bundle_kernel        grid (n / G groups x 4 quarter-polynomials), 256 threads: a thread holds the 2^G GGSW entries of ONE point in
+//                           all four polynomials (the key is read once per launch, whatever the number of ciphertexts) and loops over the
+//                           ciphertexts: W_c from two table entries (4.8), bundle = G_0 + sum_c cfma(G_c, W_c) in ascending c -- the
+//                           operations of the fused kernels in their order, the same bits -- written in the engine layout of a GGSW;
+//   blind_rotate_mb_seq_kernel   the 512-thread latency shape without any bundle work: a step is a CMUX of the classic latency build
+//                           (digits of the accumulator in registers, no rotation, no image, three barriers) whose "key" is the
+//                           ciphertext's own bundle stream, requested a whole step ahead.
+// The chain shrinks from n CMUX iterations (classic) to n / G steps of about the same cost each: the reason multi-bit bootstrapping
+// exists, and one this engine had left on the table by building the bundle inside the sequential loop.
+// Scratch: n / G x 64 KB per ciphertext (g = 3: 16.3 MB, g = 2: 24.4 MB): launches of up to kSplitMax bootstraps.
+// ------------------------------------------------------------------------------------------
+constexpr int kSplitMax = 256;
+
+template <int G, bool ILV>
+__global__ __launch_bounds__(256) void mb_bundle_kernel(int count, const uint64_t *__restrict__ ks_out, int ks_stride, int n_small,
+                                                        const double2 *__restrict__ bsk_e, const double2 *__restrict__ root /* [2N] */,
+                                                        double2 *__restrict__ bundles /* [count][n / G][4][M] */) {
+  constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2, NC = 1 << G;
+  const int j = blockIdx.x >> 2, chunk = blockIdx.x & 3;
+  const int n_groups = n_small / G;
+  const int i = chunk * 256 + (int)threadIdx.x;          // element of a polynomial in the engine layout: e8 * 128 + q7
+  const int e8 = i >> 7, q7 = i & 127;
+  const int p = ((q7 >> 1) << 4) | (e8 << 1) | (q7 & 1);  // its spectrum slot (bsk_to_engine_layout_kernel)
+  const int b = (int)(__brev((unsigned)p) >> (32 - 10));
+  const int bs = b & (7 << 6), bl = b - bs;
+  // the 2^G GGSW entries of this element in the four polynomials (rc = row * 2 + column)
+  double2 g[NC][4];
+  const double2 *grp = bsk_e + (size_t)j * NC * 4 * M;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int rc = 0; rc < 4; ++rc)
+      g[c][rc] = ILV ? grp[(size_t)((rc * 8 + e8) * NC + c) * 128 + q7] : grp[(size_t)(c * 4 + rc) * M + i];
+  for (int ct = 0; ct < count; ++ct) {
+    const uint64_t *ks = ks_out + (size_t)ct * ks_stride + (size_t)j * G;
+    double2 acc[4];
+#pragma unroll
+    for (int rc = 0; rc < 4; ++rc) acc[rc] = g[0][rc];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) {
+      uint64_t sum = 0;
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        if ((c >> (G - 1 - t)) & 1) sum += ks[t];
+      const int dg = (int)((((sum >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+      const double2 a = root[(dg - ((dg * 4 * bs) & (2 * N - 1))) & (2 * N - 1)];   // root[deg (1 - 4 b_S)]
+      const double2 wl = root[(-4 * dg * bl) & (2 * N - 1)];                        // root[-4 deg b_L]
+      const double2 wv = cmul(a, wl);
+#pragma unroll
+      for (int rc = 0; rc < 4; ++rc) acc[rc] = cfma(g[c][rc], wv, acc[rc]);
+    }
+    double2 *dst = bundles + ((size_t)ct * n_groups + j) * 4 * M + i;
+#pragma unroll
+    for (int rc = 0; rc < 4; ++rc) dst[(size_t)rc * M] = acc[rc];
+  }
+}
+
+constexpr size_t kSeqLdsBytes = (size_t)2 * 1024 * 16 + (size_t)2 * 2 * 1024 * 16;   // X + S (double-buffered)
+
+template <int BL>
+__global__ __launch_bounds__(kLatThreads, 1) void blind_rotate_mb_seq_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride, int n_small, int n_groups,
+    const double2 *__restrict__ bundles, const uint64_t *__restrict__ lut_polys, const double2 *__restrict__ twist_inv /* twist / M */,
+    const double2 *__restrict__ tw, const double2 *__restrict__ psi) {
+  constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double2 *x1_all = reinterpret_cast<double2 *>(smem_raw);            // [2][M]
+  double2 *s_all = x1_all + 2 * M;                                    // [2 parities][2][M]
+
+  const int tid = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int w = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+  const int q = tid & 255;
+  const int l = tid & 63;
+  const int l0 = l & 1, l4 = (l >> 4) & 1, l5 = (l >> 5) & 1, lo4 = l & 15;
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+  double2 *x1 = x1_all + (size_t)r * M;
+  double2 *x2 = x1;
+  double2 *s_r = s_all + (size_t)r * M;
+  const double2 *s_o = s_all + (size_t)(1 - r) * M;
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+
+  const int blk16 = w * 16 + ((l >> 1) & 15);
+  int sA[4], sB[4], sC[4], sD[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sA[e] = q + 256 * e;
+    sB[e] = w * 256 + e * 64 + l4 * 32 + l5 * 16 + lo4;
+    sC[e] = fswz(w * 256 + l4 * 128 + l5 * 64 + e * 16 + lo4);
+    sD[e] = fswz(blk16 * 16 + e * 4 + l5 * 2 + l0);
+  }
+  const double2 fA_hi = psi[1], fA_lo0 = psi[2], fA_lo1 = psi[3];
+  const double2 fB_hi = psi[4 + w], fB_lo0 = psi[8 + 2 * w], fB_lo1 = psi[8 + 2 * w + 1];
+  const int blkC = w * 4 + l4 * 2 + l5;
+  const double2 fC_hi = psi[16 + blkC], fC_lo0 = psi[32 + 2 * blkC], fC_lo1 = psi[32 + 2 * blkC + 1];
+  const double2 fD_hi = psi[64 + blk16], fD_lo0 = psi[128 + 2 * blk16], fD_lo1 = psi[128 + 2 * blk16 + 1];
+  const double2 fE_0 = psi[256 + blk16 * 4 + l5], fE_1 = psi[256 + blk16 * 4 + 2 + l5];
+  double2 cd[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double2 t = psi[512 + blk16 * 8 + (e >> 1) * 4 + l5 * 2 + (e & 1)];
+    cd[e] = l0 ? make_double2(-t.x, t.y) : t;
+  }
+  const double sgn = l0 ? -1.0 : 1.0;
+  const double2 iE = tw[l0 << 8];
+  const int low2 = l5 * 2 + l0;
+  const double2 iD_lo = tw[low2 << 7], iD_hi0 = tw[low2 << 6], iD_hi1 = tw[(4 + low2) << 6];
+  const double2 iC_lo = tw[lo4 << 5], iC_hi0 = tw[lo4 << 4], iC_hi1 = tw[(16 + lo4) << 4];
+  const int low6 = l4 * 32 + l5 * 16 + lo4;
+  const double2 iB_lo = tw[low6 << 3], iB_hi0 = tw[low6 << 2], iB_hi1 = tw[(64 + low6) << 2];
+  const double2 iA_lo = tw[q << 1], iA_hi0 = tw[q], iA_hi1 = tw[256 + q];
+  double2 twi[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) twi[e] = twist_inv[q + 256 * e];
+
+  // this ciphertext's bundle stream: [step][row][col][e8][128] -- the engine layout of a GGSW, addressed as the classic latency build does
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(bundles + (size_t)blockIdx.x * n_groups * 4 * M), 0, (unsigned)((size_t)n_groups * 4 * M * 16), 0x00020000);
+  const unsigned voff_b = (unsigned)((r * 8 + l5 * 2) * 128 + w * 32 + (l & 31)) * 16u;
+  double2 b0[4], b1[4];
+  auto load_bundle = [&](int j) __attribute__((always_inline)) {
+    const unsigned so = (unsigned)j * (unsigned)(4 * M * 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned eo = (unsigned)(((e >> 1) * 4 + (e & 1)) * 128 * 16);
+      b0[e] = buf_load_d2(rs_b, voff_b, so + eo);
+      b1[e] = buf_load_d2(rs_b, voff_b, so + (unsigned)(16 * 128 * 16) + eo);
+    }
+  };
+
+  uint64_t own_lo[4], own_hi[4];
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int bt = (int)((((ks[n_small] >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+    const int t = (2 * N - bt) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = q + 256 * e;
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      own_lo[e] = v0;
+      own_hi[e] = v1;
+    }
+  }
+  load_bundle(0);
+
+  for (int j = 0; j < n_groups; ++j) {
+    double2 x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = make_double2(digit1_f64<BL>(own_lo[e]), digit1_f64<BL>(own_hi[e]));
+    // ---- forward transform ----
+    fwd_butterfly(x[0], x[2], fA_hi);
+    fwd_butterfly(x[1], x[3], fA_hi);
+    fwd_butterfly(x[0], x[1], fA_lo0);
+    x1[sA[0]] = x[0]; x1[sA[1]] = x[1];
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_butterfly(x[2], x[3], fA_lo1);
+    x1[sA[2]] = x[2]; x1[sA[3]] = x[3];
+    __syncthreads();  // B1
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = x1[sB[e]];
+    __builtin_amdgcn_sched_barrier(0);
+    lat_fwd_pass(x, fB_hi, fB_lo0, fB_lo1);
+    lat_transpose_e0_l5(x);
+    lat_transpose_e1_l4(x);
+    fwd_butterfly(x[0], x[2], fC_hi);
+    fwd_butterfly(x[1], x[3], fC_hi);
+    fwd_butterfly(x[0], x[1], fC_lo0);
+    x2[sC[0]] = x[0]; x2[sC[1]] = x[1];
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_butterfly(x[2], x[3], fC_lo1);
+    x2[sC[2]] = x[2]; x2[sC[3]] = x[3];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = x2[sD[e]];
+    __builtin_amdgcn_sched_barrier(0);
+    lat_fwd_pass(x, fD_hi, fD_lo0, fD_lo1);
+    lat_transpose_e0_l5(x);
+    {
+      auto dpp1 = [&](double2 &v, const double2 c) __attribute__((always_inline)) {
+        const double px = dpp_swap1(v.x), py = dpp_swap1(v.y);
+        double re = __builtin_fma(c.x, px, v.x);
+        re = __builtin_fma(-c.y, py, re);
+        double im = __builtin_fma(c.x, py, v.y);
+        im = __builtin_fma(c.y, px, im);
+        v = make_double2(re, im);
+      };
+      double2 *sw = s_r + (j & 1) * 2 * M + q;
+      fwd_butterfly(x[0], x[1], fE_0);
+      dpp1(x[0], cd[0]); dpp1(x[1], cd[1]);
+      sw[0] = x[0]; sw[256] = x[1];
+      __builtin_amdgcn_sched_barrier(0);
+      fwd_butterfly(x[2], x[3], fE_1);
+      dpp1(x[2], cd[2]); dpp1(x[3], cd[3]);
+      sw[512] = x[2]; sw[768] = x[3];
+    }
+    __syncthreads();  // B3: the spectra meet
+    {
+      double2 oth[4];
+      const double2 *so_ = s_o + (j & 1) * 2 * M + q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) oth[e] = so_[e * 256];
+      __builtin_amdgcn_sched_barrier(0);
+      if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = ext_mac(x[e], oth[e], b0[e], b1[e]);
+        asm volatile("; end of form r = 0");
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = ext_mac(oth[e], x[e], b0[e], b1[e]);
+        asm volatile("; end of form r = 1");
+      }
+    }
+    load_bundle(j + 1 < n_groups ? j + 1 : j);   // a whole step ahead (the last request is a repeat: in range, unused)
+    // ---- inverse transform ----
+    lat_inv_stage0_dpp(x, sgn);
+    inv_butterfly(x[0], x[1], iE);
+    inv_butterfly(x[2], x[3], iE);
+    lat_transpose_e0_l5(x);
+    inv_butterfly(x[0], x[1], iD_lo);
+    inv_butterfly(x[2], x[3], iD_lo);
+    inv_butterfly(x[0], x[2], iD_hi0);
+    x2[sD[0]] = x[0]; x2[sD[2]] = x[2];
+    __builtin_amdgcn_sched_barrier(0);
+    inv_butterfly(x[1], x[3], iD_hi1);
+    x2[sD[1]] = x[1]; x2[sD[3]] = x[3];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = x2[sC[e]];
+    __builtin_amdgcn_sched_barrier(0);
+    lat_inv_pass(x, iC_lo, iC_hi0, iC_hi1);
+    lat_transpose_e0_l5(x);
+    lat_transpose_e1_l4(x);
+    inv_butterfly(x[0], x[1], iB_lo);
+    inv_butterfly(x[2], x[3], iB_lo);
+    inv_butterfly(x[0], x[2], iB_hi0);
+    x1[sB[0]] = x[0]; x1[sB[2]] = x[2];
+    __builtin_amdgcn_sched_barrier(0);
+    inv_butterfly(x[1], x[3], iB_hi1);
+    x1[sB[1]] = x[1]; x1[sB[3]] = x[3];
+    __syncthreads();  // B5
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = x1[sA[e]];
+    __builtin_amdgcn_sched_barrier(0);
+    lat_inv_pass(x, iA_lo, iA_hi0, iA_hi1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double2 v = cmul_conj(x[e], twi[e]);
+      own_lo[e] = torus_from_f64_fast(v.x);
+      own_hi[e] = torus_from_f64_fast(v.y);
+    }
+  }
+
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int p = q + 256 * e;
+    if (r == 0) {
+      if (p == 0) out[0] = own_lo[e];
+      else out[N - p] = (uint64_t)0 - own_lo[e];
+      out[N - (p + M)] = (uint64_t)0 - own_hi[e];
+    } else if (p == 0) {
+      out[N] = own_lo[e];
+    }
+  }
+}
+
 }  // namespace dev
 }  // namespace fhes

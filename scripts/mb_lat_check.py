@@ -20,7 +20,7 @@ for which in sys.argv[1:] or ["multibit2", "multibit3"]:
     check(w.lib.fhes_arena_upload(ctx, h_in, count, ptr(cts)))
     ref = np.stack([w.oracle_pbs(cts[i], poly) for i in range(3)])
     res = {}
-    for variant in (3, 0, 4):
+    for variant in (3, 0, 4, 16):
         check(w.lib.fhes_set_kernel_variant(ctx, variant))
         tp = np.arange(count + 1, dtype=np.int32)
         ti = np.arange(h_in, h_in + count, dtype=np.int32)

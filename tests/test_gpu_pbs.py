@@ -241,11 +241,14 @@ def test_keyswitch_on_matrix_cores_equals_valu_keyswitch(w):
         check(w.lib.fhes_set_keyswitch_mfma_min(ctx, 1))
 
 
-@pytest.mark.parametrize("which,interleave", [("multibit2", "1"), ("multibit3", "0"), ("toy_multibit3", "0"), ("toy_multibit2", "1")])
-def test_multibit_non_default_key_layouts_in_a_process_of_their_own(which, interleave, libs):
+@pytest.mark.parametrize("which,interleave", [("multibit2", "1"), ("multibit2", "0"), ("multibit3", "0"), ("multibit3", "1"), ("toy_multibit3", "0"),
+                                              ("toy_multibit2", "1")])
+def test_multibit_builds_and_key_layouts_in_a_process_of_their_own(which, interleave, libs):
     """the interleaved (g = 2) and plain (g = 3) layouts of the multi-bit key are different kernel instantiations that
-    only developer probes ran.  FHES_MB_INTERLEAVE is read at key upload, so each case runs in a child process: wide and
-    one-per-CU launches (both builds), every word against the oracle."""
+    only developer probes ran.  FHES_MB_INTERLEAVE is read at key upload, so each case runs in a child process: every build of the
+    multi-bit blind rotate -- throughput (wide launch and variant 3), the 256-thread latency build (N = 256 sets), the 512-thread one
+    (variant 4), the split form (variant 16: bundles first, then the sequential kernel) and the automatic choice -- on both layouts,
+    every word against the oracle."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -265,14 +268,15 @@ def test_multibit_non_default_key_layouts_in_a_process_of_their_own(which, inter
         "h_in = check(w.lib.fhes_arena_alloc(ctx, count)); h_out = check(w.lib.fhes_arena_alloc(ctx, count))\n"
         "check(w.lib.fhes_arena_upload(ctx, h_in, count, ptr(cts)))\n"
         "ref = np.stack([w.oracle_pbs(cts[i], poly) for i in range(3)])\n"
-        "for n in (count, 8):\n"
+        "for n, variant in ((count, 0), (8, 0), (8, 2), (8, 3)) + (((8, 4), (8, 16), (40, 16)) if w.N == 2048 else ()):\n"
+        "    check(w.lib.fhes_set_kernel_variant(ctx, variant))\n"
         "    tp = np.arange(n + 1, dtype=np.int32); ti = np.arange(h_in, h_in + n, dtype=np.int32)\n"
         "    check(w.lib.fhes_pbs_batch(ctx, n, ptr(tp), ptr(ti), ptr(np.ones(n, dtype=np.int64)), ptr(np.zeros(n, dtype=np.uint64)),\n"
         "                               ptr(np.full(n, lid, dtype=np.int32)), ptr(np.arange(h_out, h_out + n, dtype=np.int32))))\n"
         "    res = np.zeros((n, w.W), dtype=np.uint64)\n"
         "    check(w.lib.fhes_arena_download(ctx, h_out, n, ptr(res)))\n"
-        "    assert np.array_equal(res[:3], ref), n\n"
-        "    assert list(w.decrypt(res)) == [(3 * int(v) + 1) % 16 for v in vals[:n]], n\n"
+        "    assert np.array_equal(res[:3], ref), (n, variant)\n"
+        "    assert list(w.decrypt(res)) == [(3 * int(v) + 1) % 16 for v in vals[:n]], (n, variant)\n"
         "print('layout ok')\n")
     env = dict(os.environ, FHES_MB_INTERLEAVE=interleave)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
