@@ -13,6 +13,7 @@
 
 #include "kernels.hip.h"
 #include "kernel_br_lat.hip.h"
+#include "kernel_br_wpp.hip.h"
 
 namespace fhes {
 
@@ -590,6 +591,19 @@ static int launch_br_lat(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
   return FHES_OK;
 }
 
+// the wave-per-polynomial build of the classic blind rotate (kernel_br_wpp.hip.h): a bootstrap on 128 threads, four per CU
+template <int BL = 23>
+static int launch_br_wpp(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
+  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_wpp<18>(ctx, lane, d);
+  auto kern = dev::blind_rotate_wpp_kernel<BL>;
+  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), dev::kWppLdsBytes)) return rc;
+  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(dev::kWppThreads), dev::kWppLdsBytes, lane.stream, d, ctx->arena,
+                     ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e, ctx->lut_polys, ctx->twist_inv64,
+                     ctx->tw, ctx->psi);
+  FHES_HIP(hipGetLastError());
+  return FHES_OK;
+}
+
 #ifdef FHES_LAB
 // variant 8: three workgroups per CU (48 KB of LDS, <= 168 registers); N = 2048 only
 template <int BL = 23, int ABL = 0>
@@ -754,6 +768,10 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   if (variant == 2 || (variant == 0 && n2048 && ctx->lat_max > 0 && d.v_count <= ctx->lat_max)) {
     if (!n2048) return fail(FHES_ERR_UNSUPPORTED, "the latency build of the blind rotate is written for N = 2048");
     return launch_br_lat<23, dev::kLatDefaultOpt>(ctx, lane, d);
+  }
+  if (variant == 17) {
+    if (!n2048) return fail(FHES_ERR_UNSUPPORTED, "the wave-per-polynomial build of the blind rotate is written for N = 2048");
+    return launch_br_wpp<>(ctx, lane, d);
   }
   if (variant == 0 || variant == 3 || variant == 7) return n2048 ? launch_br_v5<11, 2>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
 #ifdef FHES_LAB
@@ -1300,7 +1318,7 @@ int fhes_set_timing(fhes_ctx *ctx, int32_t enabled) {
 
 int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
   if (!ctx) return fail(FHES_ERR_INVALID, "null ctx");
-  const bool product = v == 0 || v == 2 || v == 3 || v == 4 || v == 7 || v == 12 || v == 16;
+  const bool product = v == 0 || v == 2 || v == 3 || v == 4 || v == 7 || v == 12 || v == 16 || v == 17;
 #ifdef FHES_LAB
   if (v >= 100 && v < 100 + (int)ctx->lab_bsk_e.size()) {   // lab: switch to another copy of the engine-layout key
     (void)hipDeviceSynchronize();

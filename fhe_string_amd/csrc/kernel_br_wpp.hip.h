@@ -1,0 +1,354 @@
+// kernel_br_wpp.hip.h -- the WAVE-PER-POLYNOMIAL build of the classic blind rotate (round 5, VERDICT r4 item 7: a different
+// decomposition of the throughput kernel, chosen by arithmetic; k = 1, one level, N = 2048).
+//
+// The throughput kernel (blind_rotate_v5_kernel) spreads a polynomial over two waves: 8 points per lane, register passes of
+// 3 | 3 | 3 index bits and one stage across lane pairs, four workgroup barriers per CMUX because two of a transform's exchanges
+// cross waves.  Its rate is what two resident workgroups overlap of their LDS and VALU phases BETWEEN those barriers
+// (1.37 x max(VALU, LDS); profiles/EXPERIMENTS.md, round 4).  Here ONE wave owns a polynomial:
+//
+//   * 16 points per lane, register passes of 4 | 4 | 2 index bits: ten stages in three passes, NO lane-pair stage (the last
+//     forward stage and the first inverse stage are register butterflies: 24 f64 operations instead of 2 x 32 + 64 DPP moves);
+//   * both exchanges of a transform are local to the wave: the LDS operations of one wave execute in order, so an exchange
+//     needs no barrier at all -- a wave runs from its digits to its spectrum, and from the external product to its image,
+//     without waiting for anybody;
+//   * two barriers per CMUX, between TWO waves: the spectra meet in the external product (hand-over written / hand-over read);
+//   * the accumulator's image, both exchanges and the hand-over share ONE 17 KB buffer per wave (the own accumulator words live
+//     in registers, so the image is dead while the transforms run): 34 KB per bootstrap, FOUR bootstraps per CU -- eight waves
+//     that are free of each other except in pairs.
+//   * twiddles: pass 1 of the forward transform has uniform twiddles (scalar registers); the 8 + 6 + 8 + 8 per-lane twiddles
+//     of the other passes and the 16 untwist factors do not fit next to 64 + 64 registers of points and accumulator words:
+//     they are requested from the tables (L1 / L2) one pass ahead, like the GGSW rows.
+//
+// The synthetic twin (scripts/micro/lds_valu_gate.hip, GATE_WAVE_PER_POLY=1; profiles/r05_gate_wave_per_poly.jsonl) prices this
+// structure at 5.6 k cycles per CMUX and CU by wall-clock against 6.6 k for the shipped structure's twin (-14 %).
+//
+// Arithmetic: DESIGN.md section 4 -- the butterflies of blind_rotate_v5_kernel on the same operands in the same stage order, the
+// same bits.  Index model of the layouts, the padded slots and every twiddle formula (with the quarter-turn derivations):
+// scripts/model/wpp_layouts.py.
+//
+// Layouts (p = point index p9..p0; e = register e3..e0; l = lane):
+//   L1  e = (p9 p8 p7 p6)   l = p5..p0                          digits, forward pass 1, inverse pass 1', untwist, image
+//   L2  e = (p5 p4 p3 p2)   l5..l2 = p9..p6, l1 l0 = p1 p0      forward pass 2, inverse pass 2'
+//   L3  e = (p3 p2 p1 p0)   l = p9..p4                          forward pass 3, external product, inverse pass 3'
+// Slots (16 bytes): exchange L1 <-> L2 at slot1(p) = p + 4 (p >> 6); exchange L2 <-> L3 and the hand-over at slot2(p) = p + (p >> 4):
+// conflict-free ds_read / ds_write_b128 in both layouts of each exchange, and every address is base(lane) + constant(e).
+#pragma once
+#include "kernels.hip.h"
+
+namespace fhes {
+namespace dev {
+
+constexpr int kWppThreads = 128;
+constexpr int kWppSlots = 1088;                                  // padded slots per wave
+constexpr size_t kWppLdsBytes = (size_t)2 * kWppSlots * 16;      // 34 KB: four workgroups per CU
+
+// forward pass over the four register bits (highest first).  t3: the stage of e3; t2: its successor's twiddle for the EVEN block
+// (the odd block's is -i times that); t1[2], t0[4]: the even blocks of the last two stages.
+__device__ __forceinline__ void wpp_fwd_pass4(double2 (&x)[16], double2 t3, double2 t2, const double2 (&t1)[2], const double2 (&t0)[4]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) fwd_butterfly(x[e], x[e + 8], t3);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    if (e & 4) continue;
+    fwd_butterfly(x[e], x[e + 4], (e >> 3) ? mul_neg_i(t2) : t2);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    if (e & 2) continue;
+    const int blk = e >> 2;
+    fwd_butterfly(x[e], x[e + 2], (blk & 1) ? mul_neg_i(t1[blk >> 1]) : t1[blk >> 1]);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; e += 2) {
+    const int blk = e >> 1;
+    fwd_butterfly(x[e], x[e + 1], (blk & 1) ? mul_neg_i(t0[blk >> 1]) : t0[blk >> 1]);
+  }
+}
+// inverse pass over the four register bits (lowest first).  a: the stage of e0 (depends on the bits below only); b: the next
+// stage for e0 = 0 (e0 = 1: a quarter turn further, -i times); c[e & 1], dd[e & 3] likewise.
+__device__ __forceinline__ void wpp_inv_pass4(double2 (&x)[16], double2 a, double2 b, const double2 (&c)[2], const double2 (&dd)[4]) {
+#pragma unroll
+  for (int e = 0; e < 16; e += 2) inv_butterfly(x[e], x[e + 1], a);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    if (e & 2) continue;
+    inv_butterfly(x[e], x[e + 2], (e & 1) ? mul_neg_i(b) : b);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    if (e & 4) continue;
+    inv_butterfly(x[e], x[e + 4], (e & 2) ? mul_neg_i(c[e & 1]) : c[e & 1]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) inv_butterfly(x[e], x[e + 8], (e & 4) ? mul_neg_i(dd[e & 3]) : dd[e & 3]);
+}
+
+template <int BL>
+__global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
+    NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride, int n_small,
+    const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
+    const double2 *__restrict__ twist_inv /* twist / (M * 2^64): torus_from_f64_pair */, const double2 *__restrict__ tw,
+    const double2 *__restrict__ psi) {
+  constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2;
+  static_assert(BL >= 1 && BL <= 31, "single-level digit must fit the high dword");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave = output polynomial
+  const int l = tid & 63;
+  unsigned char *mine = smem_raw + (size_t)r * kWppSlots * 16;
+  uint64_t *img = reinterpret_cast<uint64_t *>(mine);            // [N] image of -acc, plain order (while no transform runs)
+  double2 *xb = reinterpret_cast<double2 *>(mine);               // [kWppSlots] exchanges and the hand-over
+  const int vidx = d.v0 + blockIdx.x;
+  const int inst = vidx / d.count, node = d.first + vidx % d.count;
+
+  // lane bases of the slots (scripts/model/wpp_layouts.py prints the constants)
+  const int h4 = l >> 2, q2 = l & 3;
+  double2 *s1 = xb + l;                      // L1 / slot1: + 68 e
+  double2 *s2 = xb + h4 * 68 + q2;           // L2 / slot1: + 4 e;   L2 / slot2: + 4 e + (e >> 2)
+  double2 *s3 = xb + l * 17;                 // L3 / slot2: + e
+  // the hand-over as the external product reads it: BOTH spectra from LDS (the own one from the slots this wave has just
+  // written), so the product is the same instruction sequence for both waves and the points' registers are free while it runs
+  const double2 *d0s = reinterpret_cast<const double2 *>(smem_raw) + l * 17;
+  const double2 *d1s = reinterpret_cast<const double2 *>(smem_raw + (size_t)kWppSlots * 16) + l * 17;
+
+  // uniform twiddles of forward pass 1 and of the inverse stage of index bit 1
+  const double2 u3 = psi[1], u2 = psi[2];
+  const double2 u1[2] = {psi[4], psi[6]};
+  const double2 u0[4] = {psi[8], psi[10], psi[12], psi[14]};
+  const double2 iw0 = tw[0], iw1 = tw[M / 4];
+
+  const __amdgpu_buffer_rsrc_t rs_g =
+      __builtin_amdgcn_make_buffer_rsrc((void *)bsk_e, 0, (unsigned)((size_t)n_small * 4 * M * 16), 0x00020000);
+  // Fourier key in the engine layout [i][row][col][e8][128]: point p of L3 sits at e8 = e >> 1, position 2 l + (e & 1)
+  const unsigned voff_g = (unsigned)(r * 8 * 128 + l * 2) * 16u;
+  // the tables through buffer descriptors: one lane offset per request group, the rest immediates (a 64-bit address per request
+  // would cost two registers each)
+  const __amdgpu_buffer_rsrc_t rs_psi = __builtin_amdgcn_make_buffer_rsrc((void *)psi, 0, (unsigned)(M * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc((void *)tw, 0, (unsigned)(M / 2 * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_twi = __builtin_amdgcn_make_buffer_rsrc((void *)twist_inv, 0, (unsigned)(M * 16), 0x00020000);
+  const unsigned h4b = (unsigned)h4 * 16u, q2b = (unsigned)q2 * 16u, lb = (unsigned)l * 16u;
+
+  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  auto modswitch_of = [&](uint64_t v) __attribute__((always_inline)) {
+    return (int)((((v >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
+  };
+
+  // ---- accumulator: acc = (0, X^{-b~} LUT); registers and image hold -acc ----
+  uint64_t nlo[16], nhi[16];
+  {
+    const uint64_t *lut = lut_polys + (size_t)d.lut_ids[node] * N;
+    const int t = (2 * N - modswitch_of(ks[n_small])) & (2 * N - 1);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int p = l + 64 * e;
+      uint64_t v0 = 0, v1 = 0;
+      if (r == 1) {
+        v0 = (t == 0) ? lut[p] : rot_read<N>(lut, t, p);
+        v1 = (t == 0) ? lut[p + M] : rot_read<N>(lut, t, p + M);
+      }
+      nlo[e] = (uint64_t)0 - v0;
+      nhi[e] = (uint64_t)0 - v1;
+      img[p] = nlo[e];
+      img[p + M] = nhi[e];
+    }
+  }
+  // (no barrier: a wave rotates its own polynomial, and its own LDS operations execute in order)
+
+  constexpr uint64_t ROUND = (uint64_t)1 << (63 - BL);
+  int a_next = modswitch_of(ks[0]);
+  for (int i = 0; i < n_small; ++i) {
+    const int a = a_next;
+    // an opaque zero per iteration: the table requests below depend on it, so they stay inside the loop (hoisted, the 46
+    // per-lane constants would need 184 registers)
+    unsigned z = 0;
+    asm volatile("" : "+s"(z));
+    double2 x[16];
+    // ---- digits of X^a acc - acc at the own coefficients p (re) and p + M (im), two halves of eight points ----
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint64_t va[8], vb[8];
+      int m0v[8], m1v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = half * 8 + k;
+        const unsigned s0 = (unsigned)(l + 64 * e - a) & (unsigned)(2 * N - 1);
+        const unsigned s1r = (s0 + (unsigned)M) & (unsigned)(2 * N - 1);
+        // the image holds -acc: the operand is +acc[s] = -image when the rotation did NOT wrap, -acc[s] = image when it did
+        m0v[k] = (int)((s0 >> LOGN) & 1u) - 1;   // -1: negate
+        m1v[k] = (int)((s1r >> LOGN) & 1u) - 1;
+        va[k] = img[s0 & (unsigned)(N - 1)];
+        vb[k] = img[s1r & (unsigned)(N - 1)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = half * 8 + k;
+        uint64_t dd[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int m32 = hh == 0 ? m0v[k] : m1v[k];
+          const uint64_t v = hh == 0 ? va[k] : vb[k];
+          const uint64_t mm = ((uint64_t)(uint32_t)m32 << 32) | (uint64_t)(uint32_t)m32;
+          const uint64_t kk = ROUND | (uint64_t)(uint32_t)(m32 & 1);
+          dd[hh] = add64(add64(v ^ mm, hh == 0 ? nlo[e] : nhi[e]), kk);
+        }
+        const double d0 = (double)((int)(uint32_t)(dd[0] >> 32) >> (32 - BL));
+        const double d1 = (double)((int)(uint32_t)(dd[1] >> 32) >> (32 - BL));
+        x[e] = make_double2(d0, d1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t ks_next = ks[i + 1];
+    // twiddles of forward pass 2, a pass ahead
+    const double2 f3 = buf_load_d2(rs_psi, h4b, z + 16 * 16), f2 = buf_load_d2(rs_psi, h4b * 2, z + 32 * 16);
+    const double2 f1[2] = {buf_load_d2(rs_psi, h4b * 4, z + 64 * 16), buf_load_d2(rs_psi, h4b * 4, z + 66 * 16)};
+    const double2 f0[4] = {buf_load_d2(rs_psi, h4b * 8, z + 128 * 16), buf_load_d2(rs_psi, h4b * 8, z + 130 * 16),
+                           buf_load_d2(rs_psi, h4b * 8, z + 132 * 16), buf_load_d2(rs_psi, h4b * 8, z + 134 * 16)};
+    // ---- forward transform ----
+    wpp_fwd_pass4(x, u3, u2, u1, u0);                                   // bits 9 8 7 6 (uniform twiddles)
+    // every rotated read of the image has returned (the digits are computed): the buffer is the exchange buffer from here on
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s1[68 * e] = x[e];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = s2[4 * e];
+    a_next = modswitch_of(ks_next);
+    asm volatile("" : "+s"(a_next));
+    // twiddles of forward pass 3
+    const double2 g1t[2] = {buf_load_d2(rs_psi, lb * 4, z + 256 * 16), buf_load_d2(rs_psi, lb * 4, z + 258 * 16)};
+    const double2 g0t[4] = {buf_load_d2(rs_psi, lb * 8, z + 512 * 16), buf_load_d2(rs_psi, lb * 8, z + 514 * 16),
+                            buf_load_d2(rs_psi, lb * 8, z + 516 * 16), buf_load_d2(rs_psi, lb * 8, z + 518 * 16)};
+    __builtin_amdgcn_sched_barrier(0);
+    wpp_fwd_pass4(x, f3, f2, f1, f0);                                   // bits 5 4 3 2
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s2[4 * e + (e >> 2)] = x[e];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = s3[e];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {                                      // bit 1
+      if (e & 2) continue;
+      const int blk = e >> 2;
+      fwd_butterfly(x[e], x[e + 2], (blk & 1) ? mul_neg_i(g1t[blk >> 1]) : g1t[blk >> 1]);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {                                   // bit 0: the internal form of DESIGN.md 4.3
+      const int blk = e >> 1;
+      fwd_butterfly_last(x[e], x[e + 1], (blk & 1) ? mul_neg_i(g0t[blk >> 1]) : g0t[blk >> 1]);
+    }
+    // hand-over: the spectrum where the other wave finds it (the slots this wave has just read)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s3[e] = x[e];
+    // ---- external product: D0 G[0][r] + D1 G[1][r], four points at a time, the rows of the next four requested ahead ----
+    {
+      const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
+      double2 g0[2][4], g1[2][4];
+      auto load_rows = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * c + k;
+          const unsigned eo = (unsigned)(((e >> 1) * 128 + (e & 1)) * 16);
+          g0[c & 1][k] = buf_load_d2(rs_g, voff_g, so + (unsigned)(0 * 16 * 128 * 16) + eo);
+          g1[c & 1][k] = buf_load_d2(rs_g, voff_g, so + (unsigned)(1 * 16 * 128 * 16) + eo);
+        }
+      };
+      load_rows(0);
+      __syncthreads();  // B1: both spectra are written
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double2 da[4], db[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          da[k] = d0s[4 * c + k];
+          db[k] = d1s[4 * c + k];
+        }
+        if (c < 3) load_rows(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[4 * c + k] = ext_mac(da[k], db[k], g0[c & 1][k], g1[c & 1][k]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // twiddles of inverse pass 2'
+    const double2 ia = buf_load_d2(rs_tw, q2b << 7, z), ib = buf_load_d2(rs_tw, q2b << 6, z);
+    const double2 ic[2] = {buf_load_d2(rs_tw, q2b << 5, z), buf_load_d2(rs_tw, q2b << 5, z + (4u << 5) * 16)};
+    const double2 id[4] = {buf_load_d2(rs_tw, q2b << 4, z), buf_load_d2(rs_tw, q2b << 4, z + (4u << 4) * 16),
+                           buf_load_d2(rs_tw, q2b << 4, z + (8u << 4) * 16), buf_load_d2(rs_tw, q2b << 4, z + (12u << 4) * 16)};
+    // ---- inverse transform ----
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {                                   // bit 0: twiddle exactly 1
+      const double2 u = x[e], v = x[e + 1];
+      x[e] = make_double2(u.x + v.x, u.y + v.y);
+      x[e + 1] = make_double2(u.x - v.x, u.y - v.y);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {                                      // bit 1: tw[p0 << 8]
+      if (e & 2) continue;
+      inv_butterfly(x[e], x[e + 2], (e & 1) ? iw1 : iw0);
+    }
+    __syncthreads();  // B2: both waves have read the other's spectrum: the buffers are their owners' again
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s3[e] = x[e];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = s2[4 * e + (e >> 2)];
+    // twiddles of inverse pass 1'
+    const double2 ja = buf_load_d2(rs_tw, lb << 3, z), jb = buf_load_d2(rs_tw, lb << 2, z);
+    const double2 jc[2] = {buf_load_d2(rs_tw, lb << 1, z), buf_load_d2(rs_tw, lb << 1, z + (64u << 1) * 16)};
+    const double2 jd[4] = {buf_load_d2(rs_tw, lb, z), buf_load_d2(rs_tw, lb, z + 64 * 16), buf_load_d2(rs_tw, lb, z + 128 * 16),
+                           buf_load_d2(rs_tw, lb, z + 192 * 16)};
+    __builtin_amdgcn_sched_barrier(0);
+    wpp_inv_pass4(x, ia, ib, ic, id);                                   // bits 2 3 4 5
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s2[4 * e] = x[e];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = s1[68 * e];
+    __builtin_amdgcn_sched_barrier(0);
+    wpp_inv_pass4(x, ja, jb, jc, jd);                                   // bits 6 7 8 9
+    // every exchange read has returned: the buffer is the image again
+    asm volatile("" ::: "memory");
+    // ---- untwist (negated factors: -y), round, nacc += rint(-y); the image goes back ----
+    {
+      double2 tf[2][4];
+      auto load_tf = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tf[c & 1][k] = buf_load_d2(rs_twi, lb, z + (unsigned)(64 * (4 * c + k) * 16));
+      };
+      load_tf(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < 3) load_tf(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * c + k;
+          const double2 v = cmul_conj(x[e], make_double2(-tf[c & 1][k].x, -tf[c & 1][k].y));
+          nlo[e] = add64(torus_from_f64_pair(v.x), nlo[e]);
+          nhi[e] = add64(torus_from_f64_pair(v.y), nhi[e]);
+          img[l + 64 * e] = nlo[e];
+          img[l + 64 * e + M] = nhi[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+  __syncthreads();
+
+  // ---- sample extract from the images of -acc: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
+  uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
+  const uint64_t *img0 = reinterpret_cast<const uint64_t *>(smem_raw);
+  const uint64_t *img1 = reinterpret_cast<const uint64_t *>(smem_raw + (size_t)kWppSlots * 16);
+  for (int j = tid; j < N; j += kWppThreads) {
+    const int jj = (j == 0) ? 0 : N - j;
+    const uint64_t v = img0[jj];
+    out[j] = (j == 0) ? (uint64_t)0 - v : v;
+  }
+  if (tid == 0) out[N] = (uint64_t)0 - img1[0];
+}
+
+}  // namespace dev
+}  // namespace fhes

@@ -1,4 +1,6 @@
-"""Lab: the 512-thread multi-bit latency build (variant 4) against the oracle word for word, and against the other builds."""
+"""Lab: builds of the blind rotate against the oracle word for word, and against each other.
+   python scripts/mb_lat_check.py multibit2 multibit3     the multi-bit builds (3, 0, 4, 16)
+   python scripts/mb_lat_check.py default                 the classic builds (3, 0, 2, 17)"""
 import sys
 
 import numpy as np
@@ -20,7 +22,7 @@ for which in sys.argv[1:] or ["multibit2", "multibit3"]:
     check(w.lib.fhes_arena_upload(ctx, h_in, count, ptr(cts)))
     ref = np.stack([w.oracle_pbs(cts[i], poly) for i in range(3)])
     res = {}
-    for variant in (3, 0, 4, 16):
+    for variant in ((3, 0, 2, 17) if w.p.grouping_factor <= 1 else (3, 0, 4, 16)):
         check(w.lib.fhes_set_kernel_variant(ctx, variant))
         tp = np.arange(count + 1, dtype=np.int32)
         ti = np.arange(h_in, h_in + count, dtype=np.int32)

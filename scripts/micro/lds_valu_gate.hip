@@ -111,7 +111,7 @@ template <int N> __device__ __forceinline__ void swap_blocks(unsigned (&y)[8]) {
   if constexpr (N > 0) { SWAP8; swap_blocks<N - 1>(y); }
 }
 template <int VARIANT>
-__global__ __launch_bounds__(VARIANT == 9 ? 512 : 256) void kk(unsigned long long *stamps, double *sink, int iters, double a, double b) {
+__global__ __launch_bounds__(VARIANT == 9 ? 512 : (VARIANT >= 10 ? 128 : 256)) void kk(unsigned long long *stamps, double *sink, int iters, double a, double b) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   double x[8];
   unsigned y[8];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(VARIANT == 9 ? 512 : 256) void kk(unsigned long lon
   const unsigned addr = (threadIdx.x & 255) * 16u;
   u32x4 wv = {threadIdx.x, 1u, 2u, 3u};
   u32x4 r[4] = {};
-  constexpr bool LDS = VARIANT != 2, ALU = VARIANT != 3, FUSED = VARIANT == 1;
+  constexpr bool LDS = VARIANT != 2 && VARIANT != 12, ALU = VARIANT != 3 && VARIANT != 13, FUSED = VARIANT == 1;
   // VARIANT 4: the same totals in four IDENTICAL phases (one load burst, one store burst each); 5: as shipped with a workgroup barrier at the
   // two wave-local exchanges as well (six phases); 6: four identical phases with the loads and stores split into two round trips each
 #define K_RD(n) do { if constexpr (LDS) { emit_rd<0, n>(r, addr); } } while (0)
@@ -134,7 +134,30 @@ __global__ __launch_bounds__(VARIANT == 9 ? 512 : 256) void kk(unsigned long lon
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
   for (int it = 0; it < iters; it++) {
-    if constexpr (VARIANT == 9) {
+    if constexpr (VARIANT >= 10) {
+      // round 5, VERDICT r4 item 7: ONE WAVE PER POLYNOMIAL -- a bootstrap on 128 threads, 16 complex points per lane, passes of 4 | 4 | 2 index
+      // bits, every transform exchange local to its wave (s_waitcnt, no barrier), no lane-pair stage; two 2-wave barriers per CMUX (spectrum
+      // share, image).  Per wave and CMUX: 1232 f64 (2 x 656 - the lane-pair stage's 2 x 16 duplicated products - rounding of the blocks),
+      // 408 other VALU (2 x 221 without the DPP moves; addresses of the 16-byte rotated reads as in the shipped kernel), 96 stores, 147 loads
+      // (40 rotated / own, 5 x 16 exchange, 15 + 12 table twiddles of passes 2 and 3; those of pass 1 are wave-uniform).
+      // 10: bursts as the shipped kernel issues them; 11: the stores of an exchange behind the last blocks of its pass and the loads of the
+      // next pass in two halves (hand-scheduled, optimistic); 12: 10 without LDS operations; 13: 10 without arithmetic
+      if constexpr (VARIANT != 11) {
+        K_RD(10); K_RD(10); K_RD(10); K_RD(10); K_WAIT; K_I(39); K_F(4); K_F(24); K_WR(16); K_WAIT;
+        K_RD(16); K_RD(15); K_WAIT; K_F(24); K_WR(16); K_WAIT;
+        K_RD(16); K_RD(12); K_WAIT; K_F(12); K_WR(16); K_WAIT; __builtin_amdgcn_s_barrier();
+        K_RD(16); K_WAIT; K_F(16); K_F(12); K_WR(16); K_WAIT;
+        K_RD(16); K_WAIT; K_F(24); K_WR(16); K_WAIT;
+        K_RD(16); K_WAIT; K_F(24); K_F(14); K_I(12); K_WR(16); K_WAIT; __builtin_amdgcn_s_barrier();
+      } else {
+        K_RD(10); K_RD(10); K_WAIT; K_I(20); K_RD(10); K_RD(10); K_F(2); K_F(12); K_WAIT; K_I(19); K_F(2); K_F(4); K_F(4); K_WR(8); K_F(4); K_WR(8); K_RD(15); K_WAIT;
+        K_RD(8); K_WAIT; K_RD(8); K_F(12); K_WAIT; K_F(4); K_F(4); K_WR(8); K_F(4); K_WR(8); K_RD(12); K_WAIT;
+        K_RD(8); K_WAIT; K_RD(8); K_F(6); K_WAIT; K_F(3); K_WR(8); K_F(3); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+        K_RD(8); K_WAIT; K_RD(8); K_F(8); K_WAIT; K_F(8); K_F(6); K_WR(8); K_F(6); K_WR(8); K_WAIT;
+        K_RD(8); K_WAIT; K_RD(8); K_F(12); K_WAIT; K_F(4); K_F(4); K_WR(8); K_F(4); K_WR(8); K_WAIT;
+        K_RD(8); K_WAIT; K_RD(8); K_F(12); K_WAIT; K_F(12); K_F(7); K_I(6); K_WR(8); K_F(7); K_I(6); K_WR(8); K_WAIT; __builtin_amdgcn_s_barrier();
+      }
+    } else if constexpr (VARIANT == 9) {
       // what a LATENCY build could be worth: ONE bootstrap on 512 threads -- every wave does half of a shipped wave's work in the same four
       // phases (two waves per SIMD overlap their LDS and VALU phases); optimistic: a 4-point-per-thread transform needs more exchanges
       K_RD(10); K_WAIT; K_F(6); K_I(10); K_WR(4); K_WAIT; __builtin_amdgcn_s_barrier();
@@ -220,6 +243,40 @@ static void run_k(unsigned long long *d_st, double *d_sink, int n_cu, int wg_per
   fflush(stdout);
 }
 
+// one wave per polynomial: 128-thread workgroups (one bootstrap each), `per_cu` of them resident by their LDS allocation
+template <int VARIANT>
+static void run_w(unsigned long long *d_st, double *d_sink, int n_cu, int per_cu) {
+  const int iters = 5000;
+  auto kern = kk<VARIANT>;
+  const int lds_bytes = per_cu <= 2 ? 65536 : (per_cu == 3 ? 53248 : (per_cu == 4 ? 40960 : 20480));   // timing only: reads past the allocation are dropped
+  hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float ms = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(n_cu * per_cu), dim3(128), lds_bytes, 0, d_st, d_sink, iters, 1.0000001, 1e-9);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  std::vector<unsigned long long> st((size_t)n_cu * per_cu * 2);
+  hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> cyc;
+  for (size_t i = 0; i < st.size(); i++) cyc.push_back((double)st[i] / iters);
+  std::sort(cyc.begin(), cyc.end());
+  int resident = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void *>(kern), 128, lds_bytes);
+  static const char *names[] = {"bursts", "stores behind the last blocks of a pass, loads in halves", "no LDS operations", "no arithmetic"};
+  printf("{\"structure\": \"W\", \"variant\": \"one wave per polynomial, %s\", \"bootstraps_per_cu\": %d, \"cycles_per_iteration_median_wave\": %.1f, "
+         "\"cycles_per_iteration_slowest_wave\": %.1f, \"wall_us_per_iteration\": %.4f, \"cycles_per_cmux_per_cu\": %.0f, "
+         "\"cycles_per_cmux_per_cu_by_wall_clock_at_2p4ghz\": %.0f, \"resident_workgroups_per_cu_by_occupancy_api\": %d}\n",
+         names[VARIANT - 10], per_cu, cyc[cyc.size() / 2], cyc.back(), ms * 1e3 / iters, cyc[cyc.size() / 2] / per_cu,
+         ms * 1e3 / iters * 2400.0 / per_cu, resident);
+  fflush(stdout);
+}
+
 template <int STRUCT, int NW, int NR, int NF, int TAIL, int THREADS>
 static void run(unsigned long long *d_st, double *d_sink, int n_cu) {
   const int iters = 20000;
@@ -255,8 +312,22 @@ int main() {
   if (hipGetDeviceProperties(&prop, 0) == hipSuccess) n_cu = prop.multiProcessorCount;
   unsigned long long *d_st;
   double *d_sink;
-  hipMalloc(&d_st, (size_t)(n_cu + 1) * 16 * 8);       // up to four 256-thread workgroups per CU (16 waves)
+  hipMalloc(&d_st, (size_t)(n_cu + 1) * 32 * 8);       // up to four 256-thread workgroups per CU (16 waves)
   hipMalloc(&d_sink, (size_t)(n_cu + 1) * 1024 * 8);
+  if (getenv("GATE_WAVE_PER_POLY")) {
+    run_k<0>(d_st, d_sink, n_cu, 2);
+    for (int per_cu = 2; per_cu <= 4; per_cu++) {
+      run_w<10>(d_st, d_sink, n_cu, per_cu);
+      run_w<11>(d_st, d_sink, n_cu, per_cu);
+    }
+    run_w<12>(d_st, d_sink, n_cu, 2);
+    run_w<13>(d_st, d_sink, n_cu, 2);
+    run_w<12>(d_st, d_sink, n_cu, 4);
+    run_w<13>(d_st, d_sink, n_cu, 4);
+    run_w<10>(d_st, d_sink, n_cu, 8);
+    run_w<11>(d_st, d_sink, n_cu, 8);
+    return 0;
+  }
   // VALU only / LDS only references
   run<S_B, 0, 0, 20, 0, 512>(d_st, d_sink, n_cu);
   run<S_B, 0, 0, 20, 0, 256>(d_st, d_sink, n_cu);
