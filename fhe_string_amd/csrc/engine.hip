@@ -592,14 +592,18 @@ static int launch_br_lat(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
 }
 
 // the wave-per-polynomial build of the classic blind rotate (kernel_br_wpp.hip.h): a bootstrap on 128 threads, four per CU
-template <int BL = 23>
+template <int BL = 23, bool STAMP = false, int ABL = 0>
 static int launch_br_wpp(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
-  if (BL == 23 && ctx->dims.pbs_base_log == 18) return launch_br_wpp<18>(ctx, lane, d);
-  auto kern = dev::blind_rotate_wpp_kernel<BL>;
+  if (BL == 23 && !STAMP && ABL == 0 && ctx->dims.pbs_base_log == 18) return launch_br_wpp<18>(ctx, lane, d);
+  auto kern = dev::blind_rotate_wpp_kernel<BL, STAMP, ABL>;
   if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), dev::kWppLdsBytes)) return rc;
+  if (STAMP && !ctx->lat_stamps) {   // lab: stamps of the first 1024 workgroups, written to $FHES_LAT_STAMPS when the context goes away
+    FHES_HIP(hipMalloc(&ctx->lat_stamps, (size_t)256 * 8 * dev::kLatStamps * 8));
+    FHES_HIP(hipMemset(ctx->lat_stamps, 0, (size_t)256 * 8 * dev::kLatStamps * 8));
+  }
   hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(dev::kWppThreads), dev::kWppLdsBytes, lane.stream, d, ctx->arena,
                      ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e, ctx->lut_polys, ctx->twist_inv64,
-                     ctx->tw, ctx->psi);
+                     ctx->tw, ctx->psi, STAMP ? ctx->lat_stamps : nullptr);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
@@ -775,6 +779,12 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   }
   if (variant == 0 || variant == 3 || variant == 7) return n2048 ? launch_br_v5<11, 2>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
 #ifdef FHES_LAB
+  if (variant >= 27 && variant <= 29) {   // wave-per-polynomial build: phase stamps; timing-only ablations (WRONG results)
+    if (!n2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the lab builds exist for the default set only");
+    if (variant == 28) return launch_br_wpp<23, false, 1>(ctx, lane, d);   // without the per-lane table requests
+    if (variant == 29) return launch_br_wpp<23, false, 2>(ctx, lane, d);   // without any global load inside the loop
+    return launch_br_wpp<23, true>(ctx, lane, d);
+  }
   if (variant >= 20 && variant <= 26) {   // switches of the latency build (scripts/r05_probe*.sh)
     if (!n2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the lab builds exist for the default set only");
     using dev::lat_opt;
@@ -1326,8 +1336,8 @@ int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
     fprintf(stderr, "[fhes lab] bsk_e copy %d at %p\n", v - 100, (void *)ctx->bsk_e);
     return FHES_OK;
   }
-  const bool wrong = v == 9 || v == 10 || v == 13 || v == 14 || v == 22;   // timing-only ablations
-  const bool lab = v == 1 || v == 5 || v == 6 || v == 8 || wrong || (v >= 20 && v <= 26);
+  const bool wrong = v == 9 || v == 10 || v == 13 || v == 14 || v == 22 || v == 28 || v == 29;   // timing-only ablations
+  const bool lab = v == 1 || v == 5 || v == 6 || v == 8 || wrong || (v >= 20 && v <= 29);
   if (wrong) {   // a developer has to ask for wrong results by name
     const char *e = getenv("FHES_DEV_ABLATIONS");
     if (!e || std::string(e) != "1")

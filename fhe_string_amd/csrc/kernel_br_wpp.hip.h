@@ -33,7 +33,7 @@
 // Slots (16 bytes): exchange L1 <-> L2 at slot1(p) = p + 4 (p >> 6); exchange L2 <-> L3 and the hand-over at slot2(p) = p + (p >> 4):
 // conflict-free ds_read / ds_write_b128 in both layouts of each exchange, and every address is base(lane) + constant(e).
 #pragma once
-#include "kernels.hip.h"
+#include "kernel_br_lat.hip.h"
 
 namespace fhes {
 namespace dev {
@@ -83,16 +83,26 @@ __device__ __forceinline__ void wpp_inv_pass4(double2 (&x)[16], double2 a, doubl
   for (int e = 0; e < 8; ++e) inv_butterfly(x[e], x[e + 8], (e & 4) ? mul_neg_i(dd[e & 3]) : dd[e & 3]);
 }
 
-template <int BL>
+constexpr int kWppStampIter = 300;   // STAMP (lab): every wave records s_memtime at the marked points of ONE iteration
+// ABL (lab, timing only, WRONG results): 1 = the per-lane table requests replaced by a register constant; 2 = the GGSW rows as well
+template <int BL, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride, int n_small,
     const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
     const double2 *__restrict__ twist_inv /* twist / (M * 2^64): torus_from_f64_pair */, const double2 *__restrict__ tw,
-    const double2 *__restrict__ psi) {
+    const double2 *__restrict__ psi, unsigned long long *__restrict__ stamps = nullptr) {
   constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2;
   static_assert(BL >= 1 && BL <= 31, "single-level digit must fit the high dword");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
+  int it_now = -1;
+#define FHES_WPP_STAMP(k)                                                                                  \
+  do {                                                                                                     \
+    if (STAMP && it_now == kWppStampIter && blockIdx.x < 1024) {                                           \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
+      if ((tid & 63) == 0) stamps[((size_t)blockIdx.x * 2 + (size_t)(tid >> 6)) * kLatStamps + (k)] = t_;   \
+    }                                                                                                      \
+  } while (0)
   const int r = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave = output polynomial
   const int l = tid & 63;
   unsigned char *mine = smem_raw + (size_t)r * kWppSlots * 16;
@@ -127,6 +137,16 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
   const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc((void *)tw, 0, (unsigned)(M / 2 * 16), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_twi = __builtin_amdgcn_make_buffer_rsrc((void *)twist_inv, 0, (unsigned)(M * 16), 0x00020000);
   const unsigned h4b = (unsigned)h4 * 16u, q2b = (unsigned)q2 * 16u, lb = (unsigned)l * 16u;
+  double abl_c = 0.70710678;
+  asm volatile("" : "+v"(abl_c));
+  auto tab = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) __attribute__((always_inline)) {
+    if (ABL >= 1) return make_double2(abl_c, -abl_c);
+    return buf_load_d2(rs, voff, soff);
+  };
+  auto row = [&](unsigned soff) __attribute__((always_inline)) {
+    if (ABL >= 2) return make_double2(abl_c, abl_c);
+    return buf_load_d2(rs_g, voff_g, soff);
+  };
 
   const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
   auto modswitch_of = [&](uint64_t v) __attribute__((always_inline)) {
@@ -154,10 +174,17 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
   }
   // (no barrier: a wave rotates its own polynomial, and its own LDS operations execute in order)
 
+  // the per-lane twiddles of forward pass 3 stay in registers for the whole loop (6 entries: their requests are the scattered ones --
+  // psi[512 + 8 l + ..] is 64 cache lines per request; more do not fit: a spilled constant is reloaded where it is used, latency and
+  // all -- 102 k PBS/s with 14 entries held and 10 of them spilled); the others are requested per iteration, a pass ahead
+  const double2 g1t[2] = {tab(rs_psi, lb * 4, 256 * 16), tab(rs_psi, lb * 4, 258 * 16)};
+  const double2 g0t[4] = {tab(rs_psi, lb * 8, 512 * 16), tab(rs_psi, lb * 8, 514 * 16), tab(rs_psi, lb * 8, 516 * 16), tab(rs_psi, lb * 8, 518 * 16)};
   constexpr uint64_t ROUND = (uint64_t)1 << (63 - BL);
   int a_next = modswitch_of(ks[0]);
   for (int i = 0; i < n_small; ++i) {
     const int a = a_next;
+    it_now = i;
+    FHES_WPP_STAMP(0);
     // an opaque zero per iteration: the table requests below depend on it, so they stay inside the loop (hoisted, the 46
     // per-lane constants would need 184 registers)
     unsigned z = 0;
@@ -200,12 +227,14 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     __builtin_amdgcn_sched_barrier(0);
     const uint64_t ks_next = ks[i + 1];
     // twiddles of forward pass 2, a pass ahead
-    const double2 f3 = buf_load_d2(rs_psi, h4b, z + 16 * 16), f2 = buf_load_d2(rs_psi, h4b * 2, z + 32 * 16);
-    const double2 f1[2] = {buf_load_d2(rs_psi, h4b * 4, z + 64 * 16), buf_load_d2(rs_psi, h4b * 4, z + 66 * 16)};
-    const double2 f0[4] = {buf_load_d2(rs_psi, h4b * 8, z + 128 * 16), buf_load_d2(rs_psi, h4b * 8, z + 130 * 16),
-                           buf_load_d2(rs_psi, h4b * 8, z + 132 * 16), buf_load_d2(rs_psi, h4b * 8, z + 134 * 16)};
+    const double2 f3 = tab(rs_psi, h4b, z + 16 * 16), f2 = tab(rs_psi, h4b * 2, z + 32 * 16);
+    const double2 f1[2] = {tab(rs_psi, h4b * 4, z + 64 * 16), tab(rs_psi, h4b * 4, z + 66 * 16)};
+    const double2 f0[4] = {tab(rs_psi, h4b * 8, z + 128 * 16), tab(rs_psi, h4b * 8, z + 130 * 16),
+                           tab(rs_psi, h4b * 8, z + 132 * 16), tab(rs_psi, h4b * 8, z + 134 * 16)};
+    FHES_WPP_STAMP(1);
     // ---- forward transform ----
     wpp_fwd_pass4(x, u3, u2, u1, u0);                                   // bits 9 8 7 6 (uniform twiddles)
+    FHES_WPP_STAMP(2);
     // every rotated read of the image has returned (the digits are computed): the buffer is the exchange buffer from here on
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -213,20 +242,33 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = s2[4 * e];
+    FHES_WPP_STAMP(3);
     a_next = modswitch_of(ks_next);
     asm volatile("" : "+s"(a_next));
-    // twiddles of forward pass 3
-    const double2 g1t[2] = {buf_load_d2(rs_psi, lb * 4, z + 256 * 16), buf_load_d2(rs_psi, lb * 4, z + 258 * 16)};
-    const double2 g0t[4] = {buf_load_d2(rs_psi, lb * 8, z + 512 * 16), buf_load_d2(rs_psi, lb * 8, z + 514 * 16),
-                            buf_load_d2(rs_psi, lb * 8, z + 516 * 16), buf_load_d2(rs_psi, lb * 8, z + 518 * 16)};
     __builtin_amdgcn_sched_barrier(0);
     wpp_fwd_pass4(x, f3, f2, f1, f0);                                   // bits 5 4 3 2
+    FHES_WPP_STAMP(4);
 #pragma unroll
     for (int e = 0; e < 16; ++e) s2[4 * e + (e >> 2)] = x[e];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = s3[e];
+    // GGSW rows of the whole external product in flight before it starts (the rows come through L2: a request placed where it is
+    // consumed waits a thousand cycles): the first half here, the second behind the hand-over, when the points' registers are free
+    const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
+    double2 g0[2][4], g1[2][4];
+    auto load_rows = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = 4 * c + k;
+        const unsigned eo = (unsigned)(((e >> 1) * 128 + (e & 1)) * 16);
+        g0[c & 1][k] = row(so + (unsigned)(0 * 16 * 128 * 16) + eo);
+        g1[c & 1][k] = row(so + (unsigned)(1 * 16 * 128 * 16) + eo);
+      }
+    };
+    load_rows(0);
     __builtin_amdgcn_sched_barrier(0);
+    FHES_WPP_STAMP(5);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {                                      // bit 1
       if (e & 2) continue;
@@ -241,42 +283,39 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     // hand-over: the spectrum where the other wave finds it (the slots this wave has just read)
 #pragma unroll
     for (int e = 0; e < 16; ++e) s3[e] = x[e];
-    // ---- external product: D0 G[0][r] + D1 G[1][r], four points at a time, the rows of the next four requested ahead ----
-    {
-      const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
-      double2 g0[2][4], g1[2][4];
-      auto load_rows = [&](int c) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(1);
+    FHES_WPP_STAMP(6);
+    __syncthreads();  // B1: both spectra are written
+    FHES_WPP_STAMP(7);
+    // ---- external product: D0 G[0][r] + D1 G[1][r], four points at a time; both spectra from LDS ----
+    double2 ia, ib, ic[2], id[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int e = 4 * c + k;
-          const unsigned eo = (unsigned)(((e >> 1) * 128 + (e & 1)) * 16);
-          g0[c & 1][k] = buf_load_d2(rs_g, voff_g, so + (unsigned)(0 * 16 * 128 * 16) + eo);
-          g1[c & 1][k] = buf_load_d2(rs_g, voff_g, so + (unsigned)(1 * 16 * 128 * 16) + eo);
-        }
-      };
-      load_rows(0);
-      __syncthreads();  // B1: both spectra are written
+    for (int c = 0; c < 4; ++c) {
+      double2 da[4], db[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        double2 da[4], db[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          da[k] = d0s[4 * c + k];
-          db[k] = d1s[4 * c + k];
-        }
-        if (c < 3) load_rows(c + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) x[4 * c + k] = ext_mac(da[k], db[k], g0[c & 1][k], g1[c & 1][k]);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int k = 0; k < 4; ++k) {
+        da[k] = d0s[4 * c + k];
+        db[k] = d1s[4 * c + k];
       }
+      if (c == 3) {   // twiddles of inverse pass 2', into the registers of the rows just consumed
+        ia = tab(rs_tw, q2b << 7, z);
+        ib = tab(rs_tw, q2b << 6, z);
+        ic[0] = tab(rs_tw, q2b << 5, z);
+        ic[1] = tab(rs_tw, q2b << 5, z + (4u << 5) * 16);
+        id[0] = tab(rs_tw, q2b << 4, z);
+        id[1] = tab(rs_tw, q2b << 4, z + (4u << 4) * 16);
+        id[2] = tab(rs_tw, q2b << 4, z + (8u << 4) * 16);
+        id[3] = tab(rs_tw, q2b << 4, z + (12u << 4) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[4 * c + k] = ext_mac(da[k], db[k], g0[c & 1][k], g1[c & 1][k]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c < 2) load_rows(c + 2);
     }
-    // twiddles of inverse pass 2'
-    const double2 ia = buf_load_d2(rs_tw, q2b << 7, z), ib = buf_load_d2(rs_tw, q2b << 6, z);
-    const double2 ic[2] = {buf_load_d2(rs_tw, q2b << 5, z), buf_load_d2(rs_tw, q2b << 5, z + (4u << 5) * 16)};
-    const double2 id[4] = {buf_load_d2(rs_tw, q2b << 4, z), buf_load_d2(rs_tw, q2b << 4, z + (4u << 4) * 16),
-                           buf_load_d2(rs_tw, q2b << 4, z + (8u << 4) * 16), buf_load_d2(rs_tw, q2b << 4, z + (12u << 4) * 16)};
     // ---- inverse transform ----
+    FHES_WPP_STAMP(8);
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {                                   // bit 0: twiddle exactly 1
       const double2 u = x[e], v = x[e + 1];
@@ -288,39 +327,45 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
       if (e & 2) continue;
       inv_butterfly(x[e], x[e + 2], (e & 1) ? iw1 : iw0);
     }
+    FHES_WPP_STAMP(9);
     __syncthreads();  // B2: both waves have read the other's spectrum: the buffers are their owners' again
+    FHES_WPP_STAMP(10);
 #pragma unroll
     for (int e = 0; e < 16; ++e) s3[e] = x[e];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = s2[4 * e + (e >> 2)];
+    FHES_WPP_STAMP(11);
     // twiddles of inverse pass 1'
-    const double2 ja = buf_load_d2(rs_tw, lb << 3, z), jb = buf_load_d2(rs_tw, lb << 2, z);
-    const double2 jc[2] = {buf_load_d2(rs_tw, lb << 1, z), buf_load_d2(rs_tw, lb << 1, z + (64u << 1) * 16)};
-    const double2 jd[4] = {buf_load_d2(rs_tw, lb, z), buf_load_d2(rs_tw, lb, z + 64 * 16), buf_load_d2(rs_tw, lb, z + 128 * 16),
-                           buf_load_d2(rs_tw, lb, z + 192 * 16)};
+    const double2 ja = tab(rs_tw, lb << 3, z), jb = tab(rs_tw, lb << 2, z);
+    const double2 jc[2] = {tab(rs_tw, lb << 1, z), tab(rs_tw, lb << 1, z + (64u << 1) * 16)};
+    const double2 jd[4] = {tab(rs_tw, lb, z), tab(rs_tw, lb, z + 64 * 16), tab(rs_tw, lb, z + 128 * 16),
+                           tab(rs_tw, lb, z + 192 * 16)};
     __builtin_amdgcn_sched_barrier(0);
     wpp_inv_pass4(x, ia, ib, ic, id);                                   // bits 2 3 4 5
+    FHES_WPP_STAMP(12);
 #pragma unroll
     for (int e = 0; e < 16; ++e) s2[4 * e] = x[e];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = s1[68 * e];
+    FHES_WPP_STAMP(13);
+    double2 tf[2][4];
+    auto load_tf = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tf[c & 1][k] = tab(rs_twi, lb, z + (unsigned)(64 * (4 * c + k) * 16));
+    };
+    load_tf(0);
+    load_tf(1);
     __builtin_amdgcn_sched_barrier(0);
     wpp_inv_pass4(x, ja, jb, jc, jd);                                   // bits 6 7 8 9
+    FHES_WPP_STAMP(14);
     // every exchange read has returned: the buffer is the image again
     asm volatile("" ::: "memory");
     // ---- untwist (negated factors: -y), round, nacc += rint(-y); the image goes back ----
     {
-      double2 tf[2][4];
-      auto load_tf = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) tf[c & 1][k] = buf_load_d2(rs_twi, lb, z + (unsigned)(64 * (4 * c + k) * 16));
-      };
-      load_tf(0);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        if (c < 3) load_tf(c + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -332,10 +377,13 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
           img[l + 64 * e + M] = nhi[e];
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (c < 2) load_tf(c + 2);
       }
     }
     asm volatile("" ::: "memory");
+    FHES_WPP_STAMP(15);
   }
+#undef FHES_WPP_STAMP
   __syncthreads();
 
   // ---- sample extract from the images of -acc: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
