@@ -40,7 +40,10 @@ namespace dev {
 
 constexpr int kWppThreads = 128;
 constexpr int kWppSlots = 1088;                                  // padded slots per wave
-constexpr size_t kWppLdsBytes = (size_t)2 * kWppSlots * 16;      // 34 KB: four workgroups per CU
+// two buffers (34 KB) | F: the twiddles of forward pass 2, [8][16 blocks] | I: those of inverse pass 2', [8][4] | J: three of inverse
+// pass 1', [3][64 lanes]  = 40 448 bytes: four workgroups per CU (160 KB)
+constexpr int kWppTabF = 2 * kWppSlots, kWppTabI = kWppTabF + 8 * 16, kWppTabJ = kWppTabI + 8 * 4, kWppTabEnd = kWppTabJ + 3 * 64;   // in slots of 16 bytes
+constexpr size_t kWppLdsBytes = (size_t)kWppTabEnd * 16;
 
 // forward pass over the four register bits (highest first).  t3: the stage of e3; t2: its successor's twiddle for the EVEN block
 // (the odd block's is -i times that); t1[2], t0[4]: the even blocks of the last two stages.
@@ -172,13 +175,39 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
       img[p + M] = nhi[e];
     }
   }
-  // (no barrier: a wave rotates its own polynomial, and its own LDS operations execute in order)
+  // (no barrier for the image: a wave rotates its own polynomial, and its own LDS operations execute in order)
+  // ---- twiddle tables of the workgroup (both waves read them): per-lane requests to L2 cost 0.3 % of the rate EACH
+  // (profiles/r05_probe28_wpp_ablations.txt), an LDS read next to the exchange's sixteen costs nothing measurable ----
+  {
+    double2 *tabs = reinterpret_cast<double2 *>(smem_raw);
+    if (tid < 128) {   // F[k][h]: psi[16 + h], psi[32 + 2 h], psi[64 + 4 h], psi[66 + 4 h], psi[128 + 8 h + 2 j]
+      const int k = tid >> 4, h = tid & 15;
+      const int idx = k == 0 ? 16 + h : (k == 1 ? 32 + 2 * h : (k < 4 ? 64 + 4 * h + 2 * (k - 2) : 128 + 8 * h + 2 * (k - 4)));
+      tabs[kWppTabF + tid] = psi[idx];
+    }
+    if (tid < 32) {    // I[k][q]: tw[q << 7], tw[q << 6], tw[q << 5], tw[(4 + q) << 5], tw[(4 j + q) << 4]
+      const int k = tid >> 2, q = tid & 3;
+      const int idx = k == 0 ? q << 7 : (k == 1 ? q << 6 : (k < 4 ? (4 * (k - 2) + q) << 5 : (4 * (k - 4) + q) << 4));
+      tabs[kWppTabI + tid] = tw[idx];
+    }
+    for (int t = tid; t < 192; t += kWppThreads) {   // J[k][l]: tw[l << 3], tw[l << 2], tw[l << 1]
+      const int k = t >> 6, ll = t & 63;
+      tabs[kWppTabJ + t] = tw[ll << (3 - k)];
+    }
+  }
+  __syncthreads();
+  const double2 *tabF = reinterpret_cast<const double2 *>(smem_raw) + kWppTabF + h4;    // + 16 k
+  const double2 *tabI = reinterpret_cast<const double2 *>(smem_raw) + kWppTabI + q2;    // + 4 k
+  const double2 *tabJ = reinterpret_cast<const double2 *>(smem_raw) + kWppTabJ + l;     // + 64 k
 
   // the per-lane twiddles of forward pass 3 stay in registers for the whole loop (6 entries: their requests are the scattered ones --
   // psi[512 + 8 l + ..] is 64 cache lines per request; more do not fit: a spilled constant is reloaded where it is used, latency and
   // all -- 102 k PBS/s with 14 entries held and 10 of them spilled); the others are requested per iteration, a pass ahead
   const double2 g1t[2] = {tab(rs_psi, lb * 4, 256 * 16), tab(rs_psi, lb * 4, 258 * 16)};
   const double2 g0t[4] = {tab(rs_psi, lb * 8, 512 * 16), tab(rs_psi, lb * 8, 514 * 16), tab(rs_psi, lb * 8, 516 * 16), tab(rs_psi, lb * 8, 518 * 16)};
+  // ... and so do five of inverse pass 1' (the registers that are left)
+  const double2 jc1 = tab(rs_tw, lb << 1, (64u << 1) * 16);
+  const double2 jd[4] = {tab(rs_tw, lb, 0), tab(rs_tw, lb, 64 * 16), tab(rs_tw, lb, 128 * 16), tab(rs_tw, lb, 192 * 16)};
   constexpr uint64_t ROUND = (uint64_t)1 << (63 - BL);
   int a_next = modswitch_of(ks[0]);
   for (int i = 0; i < n_small; ++i) {
@@ -226,11 +255,10 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
     const uint64_t ks_next = ks[i + 1];
-    // twiddles of forward pass 2, a pass ahead
-    const double2 f3 = tab(rs_psi, h4b, z + 16 * 16), f2 = tab(rs_psi, h4b * 2, z + 32 * 16);
-    const double2 f1[2] = {tab(rs_psi, h4b * 4, z + 64 * 16), tab(rs_psi, h4b * 4, z + 66 * 16)};
-    const double2 f0[4] = {tab(rs_psi, h4b * 8, z + 128 * 16), tab(rs_psi, h4b * 8, z + 130 * 16),
-                           tab(rs_psi, h4b * 8, z + 132 * 16), tab(rs_psi, h4b * 8, z + 134 * 16)};
+    // twiddles of forward pass 2 (LDS table), a pass ahead
+    const double2 f3 = tabF[0], f2 = tabF[16];
+    const double2 f1[2] = {tabF[32], tabF[48]};
+    const double2 f0[4] = {tabF[64], tabF[80], tabF[96], tabF[112]};
     FHES_WPP_STAMP(1);
     // ---- forward transform ----
     wpp_fwd_pass4(x, u3, u2, u1, u0);                                   // bits 9 8 7 6 (uniform twiddles)
@@ -289,7 +317,6 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     __syncthreads();  // B1: both spectra are written
     FHES_WPP_STAMP(7);
     // ---- external product: D0 G[0][r] + D1 G[1][r], four points at a time; both spectra from LDS ----
-    double2 ia, ib, ic[2], id[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       double2 da[4], db[4];
@@ -298,22 +325,16 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
         da[k] = d0s[4 * c + k];
         db[k] = d1s[4 * c + k];
       }
-      if (c == 3) {   // twiddles of inverse pass 2', into the registers of the rows just consumed
-        ia = tab(rs_tw, q2b << 7, z);
-        ib = tab(rs_tw, q2b << 6, z);
-        ic[0] = tab(rs_tw, q2b << 5, z);
-        ic[1] = tab(rs_tw, q2b << 5, z + (4u << 5) * 16);
-        id[0] = tab(rs_tw, q2b << 4, z);
-        id[1] = tab(rs_tw, q2b << 4, z + (4u << 4) * 16);
-        id[2] = tab(rs_tw, q2b << 4, z + (8u << 4) * 16);
-        id[3] = tab(rs_tw, q2b << 4, z + (12u << 4) * 16);
-      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[4 * c + k] = ext_mac(da[k], db[k], g0[c & 1][k], g1[c & 1][k]);
       __builtin_amdgcn_sched_barrier(0);
       if (c < 2) load_rows(c + 2);
     }
+    // twiddles of inverse pass 2' (LDS table), a pass ahead
+    const double2 ia = tabI[0], ib = tabI[4];
+    const double2 ic[2] = {tabI[8], tabI[12]};
+    const double2 id[4] = {tabI[16], tabI[20], tabI[24], tabI[28]};
     // ---- inverse transform ----
     FHES_WPP_STAMP(8);
 #pragma unroll
@@ -337,10 +358,8 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     for (int e = 0; e < 16; ++e) x[e] = s2[4 * e + (e >> 2)];
     FHES_WPP_STAMP(11);
     // twiddles of inverse pass 1'
-    const double2 ja = tab(rs_tw, lb << 3, z), jb = tab(rs_tw, lb << 2, z);
-    const double2 jc[2] = {tab(rs_tw, lb << 1, z), tab(rs_tw, lb << 1, z + (64u << 1) * 16)};
-    const double2 jd[4] = {tab(rs_tw, lb, z), tab(rs_tw, lb, z + 64 * 16), tab(rs_tw, lb, z + 128 * 16),
-                           tab(rs_tw, lb, z + 192 * 16)};
+    const double2 ja = tabJ[0], jb = tabJ[64];
+    const double2 jc[2] = {tabJ[128], jc1};
     __builtin_amdgcn_sched_barrier(0);
     wpp_inv_pass4(x, ia, ib, ic, id);                                   // bits 2 3 4 5
     FHES_WPP_STAMP(12);
