@@ -46,8 +46,11 @@ constexpr int kWppTabF = 2 * kWppSlots, kWppTabI = kWppTabF + 8 * 16, kWppTabJ =
 constexpr size_t kWppLdsBytes = (size_t)kWppTabEnd * 16;
 
 // forward pass over the four register bits (highest first).  t3: the stage of e3; t2: its successor's twiddle for the EVEN block
-// (the odd block's is -i times that); t1[2], t0[4]: the even blocks of the last two stages.
-__device__ __forceinline__ void wpp_fwd_pass4(double2 (&x)[16], double2 t3, double2 t2, const double2 (&t1)[2], const double2 (&t0)[4]) {
+// (the odd block's is -i times that); t1[2], t0[4]: the even blocks of the last two stages.  `out(e)` is called
+// for both points of a last-stage butterfly right behind it: the exchange's stores leave while the next butterflies compute
+// (two ds_write_b128 = 26 cycles of the LDS store path, one butterfly = 6 x 4 cycles of the SIMD).
+template <class Out>
+__device__ __forceinline__ void wpp_fwd_pass4(double2 (&x)[16], double2 t3, double2 t2, const double2 (&t1)[2], const double2 (&t0)[4], Out out) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) fwd_butterfly(x[e], x[e + 8], t3);
 #pragma unroll
@@ -65,11 +68,15 @@ __device__ __forceinline__ void wpp_fwd_pass4(double2 (&x)[16], double2 t3, doub
   for (int e = 0; e < 16; e += 2) {
     const int blk = e >> 1;
     fwd_butterfly(x[e], x[e + 1], (blk & 1) ? mul_neg_i(t0[blk >> 1]) : t0[blk >> 1]);
+    out(e);
+    out(e + 1);
+    if ((e & 2) != 0) __builtin_amdgcn_sched_barrier(0);
   }
 }
 // inverse pass over the four register bits (lowest first).  a: the stage of e0 (depends on the bits below only); b: the next
 // stage for e0 = 0 (e0 = 1: a quarter turn further, -i times); c[e & 1], dd[e & 3] likewise.
-__device__ __forceinline__ void wpp_inv_pass4(double2 (&x)[16], double2 a, double2 b, const double2 (&c)[2], const double2 (&dd)[4]) {
+template <class Out>
+__device__ __forceinline__ void wpp_inv_pass4(double2 (&x)[16], double2 a, double2 b, const double2 (&c)[2], const double2 (&dd)[4], Out out) {
 #pragma unroll
   for (int e = 0; e < 16; e += 2) inv_butterfly(x[e], x[e + 1], a);
 #pragma unroll
@@ -83,7 +90,12 @@ __device__ __forceinline__ void wpp_inv_pass4(double2 (&x)[16], double2 a, doubl
     inv_butterfly(x[e], x[e + 4], (e & 2) ? mul_neg_i(c[e & 1]) : c[e & 1]);
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) inv_butterfly(x[e], x[e + 8], (e & 4) ? mul_neg_i(dd[e & 3]) : dd[e & 3]);
+  for (int e = 0; e < 8; ++e) {
+    inv_butterfly(x[e], x[e + 8], (e & 4) ? mul_neg_i(dd[e & 3]) : dd[e & 3]);
+    out(e);
+    out(e + 8);
+    if ((e & 1) != 0) __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 constexpr int kWppStampIter = 300;   // STAMP (lab): every wave records s_memtime at the marked points of ONE iteration
@@ -261,12 +273,10 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     const double2 f0[4] = {tabF[64], tabF[80], tabF[96], tabF[112]};
     FHES_WPP_STAMP(1);
     // ---- forward transform ----
-    wpp_fwd_pass4(x, u3, u2, u1, u0);                                   // bits 9 8 7 6 (uniform twiddles)
-    FHES_WPP_STAMP(2);
     // every rotated read of the image has returned (the digits are computed): the buffer is the exchange buffer from here on
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s1[68 * e] = x[e];
+    wpp_fwd_pass4(x, u3, u2, u1, u0, [&](int e) __attribute__((always_inline)) { s1[68 * e] = x[e]; });   // bits 9 8 7 6 (uniform twiddles)
+    FHES_WPP_STAMP(2);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = s2[4 * e];
@@ -274,10 +284,8 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     a_next = modswitch_of(ks_next);
     asm volatile("" : "+s"(a_next));
     __builtin_amdgcn_sched_barrier(0);
-    wpp_fwd_pass4(x, f3, f2, f1, f0);                                   // bits 5 4 3 2
+    wpp_fwd_pass4(x, f3, f2, f1, f0, [&](int e) __attribute__((always_inline)) { s2[4 * e + (e >> 2)] = x[e]; });   // bits 5 4 3 2
     FHES_WPP_STAMP(4);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s2[4 * e + (e >> 2)] = x[e];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = s3[e];
@@ -307,10 +315,11 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     for (int e = 0; e < 16; e += 2) {                                   // bit 0: the internal form of DESIGN.md 4.3
       const int blk = e >> 1;
       fwd_butterfly_last(x[e], x[e + 1], (blk & 1) ? mul_neg_i(g0t[blk >> 1]) : g0t[blk >> 1]);
+      // hand-over: the spectrum where the other wave finds it (the slots this wave has just read), behind each butterfly
+      s3[e] = x[e];
+      s3[e + 1] = x[e + 1];
+      if ((e & 2) != 0) __builtin_amdgcn_sched_barrier(0);
     }
-    // hand-over: the spectrum where the other wave finds it (the slots this wave has just read)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s3[e] = x[e];
     __builtin_amdgcn_sched_barrier(0);
     load_rows(1);
     FHES_WPP_STAMP(6);
@@ -343,16 +352,18 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
       x[e] = make_double2(u.x + v.x, u.y + v.y);
       x[e + 1] = make_double2(u.x - v.x, u.y - v.y);
     }
+    FHES_WPP_STAMP(9);
+    __syncthreads();  // B2: both waves have read both spectra: the buffers are their owners' again (in front of the stage whose
+                      // results go back into them, so that its stores can leave butterfly by butterfly)
+    FHES_WPP_STAMP(10);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {                                      // bit 1: tw[p0 << 8]
       if (e & 2) continue;
       inv_butterfly(x[e], x[e + 2], (e & 1) ? iw1 : iw0);
+      s3[e] = x[e];
+      s3[e + 2] = x[e + 2];
+      if ((e & 1) != 0) __builtin_amdgcn_sched_barrier(0);
     }
-    FHES_WPP_STAMP(9);
-    __syncthreads();  // B2: both waves have read the other's spectrum: the buffers are their owners' again
-    FHES_WPP_STAMP(10);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s3[e] = x[e];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = s2[4 * e + (e >> 2)];
@@ -361,10 +372,8 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     const double2 ja = tabJ[0], jb = tabJ[64];
     const double2 jc[2] = {tabJ[128], jc1};
     __builtin_amdgcn_sched_barrier(0);
-    wpp_inv_pass4(x, ia, ib, ic, id);                                   // bits 2 3 4 5
+    wpp_inv_pass4(x, ia, ib, ic, id, [&](int e) __attribute__((always_inline)) { s2[4 * e] = x[e]; });   // bits 2 3 4 5
     FHES_WPP_STAMP(12);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s2[4 * e] = x[e];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = s1[68 * e];
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     load_tf(0);
     load_tf(1);
     __builtin_amdgcn_sched_barrier(0);
-    wpp_inv_pass4(x, ja, jb, jc, jd);                                   // bits 6 7 8 9
+    wpp_inv_pass4(x, ja, jb, jc, jd, [](int) {});                       // bits 6 7 8 9
     FHES_WPP_STAMP(14);
     // every exchange read has returned: the buffer is the image again
     asm volatile("" ::: "memory");
