@@ -650,13 +650,15 @@ def main():
                 try:
                     valu, f64 = cr["valu_per_wave_iter"], cr["f64_per_wave_iter"]
                     cmux = cr["cmux_iterations_per_pbs"]
-                    spec_peak = N_CU * SPEC_CLOCK_HZ / (cmux * (f64 * 4.0 + (valu - f64) * 2.0))
+                    wpp = cr.get("waves_per_pbs", 4)     # 4: throughput build; 2: wave-per-polynomial build (a PBS occupies two of a CU's four SIMDs)
+                    spec_peak = N_CU * SPEC_CLOCK_HZ / (cmux * (f64 * 4.0 + (valu - f64) * 2.0) * wpp / 4.0)
                     roof["valu_issue_at_guide_rates"] = {
                         "peak_pbs_per_s": round(spec_peak, 1), "frac": round(br_rate / spec_peak, 4),
                         "valu_per_wave_cmux": round(valu, 1), "f64_per_wave_cmux": round(f64, 1), "non_f64_valu_share": round((valu - f64) / valu, 4),
                         "f64_min_per_wave_cmux_canonical": cr.get("f64_min_per_wave_iter"),
-                        "formula": "peak = 256 CUs x 2.4 GHz / (cmux_per_pbs x (f64 x 4 + (valu - f64) x 2) cycles): the guide's issue rates, one PBS = 4 waves on "
-                                   "the 4 SIMDs of a CU; instruction counts from SQ_INSTS_VALU* of the bench command"}
+                        "waves_per_pbs": wpp,
+                        "formula": "peak = 256 CUs x 2.4 GHz / (cmux_per_pbs x (f64 x 4 + (valu - f64) x 2) cycles x waves_per_pbs / 4): the guide's issue rates, one "
+                                   "PBS = waves_per_pbs waves on as many of the 4 SIMDs of a CU; instruction counts from SQ_INSTS_VALU* of the bench command"}
                     if cr.get("bound_pbs_per_s"):
                         lp = cr.get("lds_pipe")
                         roof["valu_issue_at_measured_slot_costs"] = {

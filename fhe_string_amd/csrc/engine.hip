@@ -732,6 +732,8 @@ static int launch_br_gen(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
 //   0   auto: the latency build for launches of at most one workgroup per CU (ctx->lat_max), the throughput build above
 //   2   the latency build (kernel_br_lat.hip.h: one bootstrap on 512 threads; N = 2048)
 //   3   the throughput build at every launch size (blind_rotate_v5_kernel, no priority hints; 7 = its number of rounds 2-4)
+//   17  the wave-per-polynomial build (kernel_br_wpp.hip.h: one wave per polynomial, four bootstraps per CU; N = 2048): the rate of
+//       the throughput build within 1 % at launches of whole rounds, 8 % above it at 513-1024 bootstraps, below it under 512
 //   12  the generic kernel on a 2_2 set (the second implementation the tests compare with)
 // A lab build (-DFHES_LAB: FHES_LAB=1 python -m fhe_string_amd.build, scripts/) also carries the simple reference kernel (1),
 // the two wave-priority policies of the throughput kernel (5, 6), variant 8 (three workgroups per CU, 28 % slower) and the
@@ -777,6 +779,13 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
     if (!n2048) return fail(FHES_ERR_UNSUPPORTED, "the wave-per-polynomial build of the blind rotate is written for N = 2048");
     return launch_br_wpp<>(ctx, lane, d);
   }
+  // auto: the wave-per-polynomial build holds 1024 bootstraps per round (four per CU) against 512 for the throughput build, at the
+  // same rate when its rounds are full: it takes the launches whose LAST round of 1024 is full or nearly so -- 1024: 125.5 k against
+  // 115.7 k PBS/s, 2048: 126.0 k against 121.0 k; 768: the same; 512 or 1536: the throughput build by 20 % (profiles/r05_probe29_wpp_rates.txt)
+  if (variant == 0 && n2048 && ctx->wpp_auto) {
+    const int tail = d.v_count % 1024;
+    if (d.v_count >= 896 && (tail == 0 || tail > 896)) return launch_br_wpp<>(ctx, lane, d);
+  }
   if (variant == 0 || variant == 3 || variant == 7) return n2048 ? launch_br_v5<11, 2>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
 #ifdef FHES_LAB
   if (variant >= 27 && variant <= 29) {   // wave-per-polynomial build: phase stamps; timing-only ablations (WRONG results)
@@ -814,7 +823,7 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   if (variant == 6) return n2048 ? launch_br_v5<11, 1>(ctx, lane, d) : launch_br_v5<8, 1>(ctx, lane, d);
   if ((variant == 9 || variant == 10) && n2048) return variant == 9 ? launch_br_v5<11, 4>(ctx, lane, d) : launch_br_v5<11, 5>(ctx, lane, d);
 #endif
-  return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d is not in this build (0, 2, 3, 7, 12; a lab build has the others)", variant);
+  return fail(FHES_ERR_UNSUPPORTED, "blind-rotate variant %d is not in this build (0, 2, 3, 7, 12, 17; a lab build has the others)", variant);
 }
 
 static int take_event(fhes_ctx *ctx, hipEvent_t *e) {
@@ -984,6 +993,7 @@ fhes_ctx *fhes_ctx_create(const fhes_params *p, int32_t device) {
   // profiles/r05_probe20_split_crossover.txt; 16-24 MB of scratch per bootstrap).  FHES_MB_SPLIT_MAX=0 switches it off.
   ctx->mb_split_max = (d.g > 1 && d.N == 2048) ? (d.g == 3 ? 192 : 128) : 0;
   if (const char *e8 = getenv("FHES_MB_SPLIT_MAX")) ctx->mb_split_max = atoi(e8) < 0 ? 0 : atoi(e8);
+  if (const char *e9 = getenv("FHES_WPP_AUTO")) ctx->wpp_auto = atoi(e9) != 0;
   if (const char *e5 = getenv("FHES_KS_MFMA_MIN")) ctx->ks_mfma_min = atoi(e5);  // developer knob: 0 = VALU keyswitch only, 1 = always MFMA
   if (const char *e3 = getenv("FHES_KS_TB")) ctx->ks_tb = atoi(e3);  // developer knob: 8 / 16 force the tile height
   if (const char *e2 = getenv("FHES_KS_MIN_CPS")) {
@@ -1348,7 +1358,7 @@ int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
 #endif
   if (!product && !lab)
     return fail(v < 0 || v > 26 ? FHES_ERR_INVALID : FHES_ERR_UNSUPPORTED,
-                "blind-rotate variant %d is not in this build (0 = auto, 2 = latency build, 3 / 7 = throughput build, 12 = generic kernel)", v);
+                "blind-rotate variant %d is not in this build (0 = auto, 2 = latency build, 3 / 7 = throughput build, 17 = wave-per-polynomial build, 12 = generic kernel)", v);
   ctx->br_variant = v;
   return FHES_OK;
 }

@@ -279,7 +279,10 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     FHES_WPP_STAMP(2);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = s2[4 * e];
+    for (int k = 0; k < 16; ++k) {   // in the order the first stage pairs them: (e, e + 8)
+      const int e = (k >> 1) + 8 * (k & 1);
+      x[e] = s2[4 * e];
+    }
     FHES_WPP_STAMP(3);
     a_next = modswitch_of(ks_next);
     asm volatile("" : "+s"(a_next));
@@ -288,9 +291,12 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     FHES_WPP_STAMP(4);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = s3[e];
-    // GGSW rows of the whole external product in flight before it starts (the rows come through L2: a request placed where it is
-    // consumed waits a thousand cycles): the first half here, the second behind the hand-over, when the points' registers are free
+    for (int k = 0; k < 16; ++k) {   // in the order the stage of bit 1 pairs them: (e, e + 2)
+      const int e = (k & 1) * 2 + ((k >> 1) & 1) + (k >> 2) * 4;
+      x[e] = s3[e];
+    }
+    // GGSW rows: four points' worth requested here, the next four behind the hand-over, then one group ahead of the products
+    // (all sixteen in flight at once measured the same rate and takes 64 registers more)
     const unsigned so = (unsigned)i * (unsigned)(4 * M * 16);
     double2 g0[2][4], g1[2][4];
     auto load_rows = [&](int c) __attribute__((always_inline)) {

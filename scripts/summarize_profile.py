@@ -179,8 +179,9 @@ if br and br[0] in sq:
     c = sq[br[0]]
     # CMUX iterations (classic 2_2 set) / group steps (multi-bit: n / g = 764 / 2, 765 / 3) per PBS
     n_iter = 742 if "multibit" not in extra else (382 if extra.split()[-1] == "multibit2" else 255)
-    wgs = c.get("sqa_workgroups", 0)                      # one workgroup = one PBS, 4 waves
-    wave_iters = wgs * 4 * (n_iter or 1)
+    wgs = c.get("sqa_workgroups", 0)                      # one workgroup = one PBS: 4 waves (throughput build), 2 (wave-per-polynomial build), 8 (latency builds)
+    wpw = 2 if "_wpp_" in br[0] else (8 if ("_lat_" in br[0] or "_seq_" in br[0]) else 4)
+    wave_iters = wgs * wpw * (n_iter or 1)
     f64 = sum(c.get(x, 0) for x in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
     wgs_b = c.get("sqb_workgroups", wgs) or wgs
     dur_a, dur_b = c.get("sqa_duration_ns", 0) * 1e-9, c.get("sqb_duration_ns", 0) * 1e-9
@@ -197,8 +198,9 @@ if br and br[0] in sq:
         "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc passes sqa / sqb of the bench command), profiles/{tag}_issue_rates.jsonl",
         "kernel": br[0], "pbs_profiled": wgs, "cmux_iterations_per_pbs": n_iter,
         "valu_per_wave_iter": c.get("SQ_INSTS_VALU", 0) / wave_iters if wave_iters else None,
-        "f64_per_wave_iter": f64 / (wgs_b * 4 * (n_iter or 1)) if wgs_b else None,
-        "lds_instr_per_wave_iter": c.get("SQ_INSTS_LDS", 0) / (wgs_b * 4 * (n_iter or 1)) if wgs_b else None,
+        "waves_per_pbs": wpw,
+        "f64_per_wave_iter": f64 / (wgs_b * wpw * (n_iter or 1)) if wgs_b else None,
+        "lds_instr_per_wave_iter": c.get("SQ_INSTS_LDS", 0) / (wgs_b * wpw * (n_iter or 1)) if wgs_b else None,
         "clock_ghz_under_load": clock / 1e9 if clock else None,
         "issue_cycles_f64_2waves": c_f64, "issue_cycles_other_next_to_f64": c_other,
         "valu_busy_frac": c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (c.get("GRBM_GUI_ACTIVE", 0) / 8 * 256 * 4) if c.get("GRBM_GUI_ACTIVE") else None,
@@ -209,7 +211,7 @@ if br and br[0] in sq:
                             "wait_inst_any": c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
                             "wait_inst_lds": c.get("SQ_WAIT_INST_LDS", 0) / c["SQ_WAVE_CYCLES"] * (dur_a / dur_b if dur_b else 1) if c.get("SQ_WAVE_CYCLES") else None},
         "raw": {k2: v2 for k2, v2 in c.items()},
-        "note": "SQ_* ACTIVE / WAIT / WAVE counters are quad-cycles; SQ_INSTS_* are wave-instructions; one workgroup = one PBS = 4 waves x cmux_iterations",
+        "note": "SQ_* ACTIVE / WAIT / WAVE counters are quad-cycles; SQ_INSTS_* are wave-instructions; one workgroup = one PBS = waves_per_pbs waves x cmux_iterations",
     }
     if "multibit" not in extra:
         # Minimum number of f64 FMA / ADD / MUL instructions that produce the canonical arithmetic's bits, counted per
@@ -223,13 +225,14 @@ if br and br[0] in sq:
         M_pts = 1024
         fwd = 9 * (M_pts // 2) * 6 + (M_pts // 2) * 8
         inv = (M_pts // 2) * 4 + 9 * (M_pts // 2) * 6 - 2 * (M_pts - 2)
-        comp["f64_min_per_wave_iter"] = (2 * fwd + 2 * M_pts * 8 + 2 * inv + 2 * (M_pts * 4 - 4) + 2 * 2 * M_pts * 6) / 256
+        comp["f64_min_per_wave_iter"] = (2 * fwd + 2 * M_pts * 8 + 2 * inv + 2 * (M_pts * 4 - 4) + 2 * 2 * M_pts * 6) / (64 * wpw)
         comp["f64_min_note"] = ("minimum f64 FMA / ADD / MUL instructions per lane and CMUX that reproduce DESIGN.md section 4 bit for bit "
                                 "(derivation in scripts/summarize_profile.py); measured f64_per_wave_iter equals it: the arithmetic is at its floor, "
                                 "what is left to remove are the non-f64 VALU slots")
     if comp["valu_per_wave_iter"] and c_f64 and c_other and clock and n_iter:
         other = comp["valu_per_wave_iter"] - comp["f64_per_wave_iter"]
         cyc = comp["f64_per_wave_iter"] * c_f64 + other * c_other
+        cyc = cyc * wpw / 4      # a CMUX occupies waves_per_pbs of the CU's four SIMDs for `cyc` cycles
         comp["issue_cycles_per_pbs_iteration_per_cu"] = cyc
         comp["bound_pbs_per_s"] = 256 * clock / (n_iter * cyc)
     # second pipe (round 3): the LDS.  Static instruction mix of the kernel's loop body (llvm-objdump of the
@@ -240,15 +243,17 @@ if br and br[0] in sq:
     # 1021 cycles against 1088 predicted) and that a barrier-separated phase pays VALU + LDS, not max.
     if "multibit" not in extra and clock and wave_iters:
         mix = {"ds_write_b128": 48, "ds_read_b128": 58, "ds_read_b64": 16}   # 40 exchange + 18 twiddle reads (73 before the quarter-turn twiddles were derived, round 3)
+        if wpw == 2:   # wave-per-polynomial build: 80 exchange / hand-over stores + 16 ds_write2st64_b64 of the image (priced as b128); 64 exchange + 32 product + 19 table loads; 32 rotated reads
+            mix = {"ds_write_b128": 96, "ds_read_b128": 115, "ds_read_b64": 32}
         conflicts = c.get("SQ_LDS_BANK_CONFLICT", 0) / wave_iters
         lds_cyc = mix["ds_write_b128"] * 13 + mix["ds_read_b128"] * 4 + mix["ds_read_b64"] * 2 + conflicts
         comp["lds_pipe"] = {"instr_per_wave_iter_static": mix, "instr_per_wave_iter_measured": comp["lds_instr_per_wave_iter"],
                             "bank_conflict_cycles_per_wave_iter": conflicts,
                             "lds_pipe_cycles_per_wave_iter": lds_cyc,
-                            "lds_pipe_cycles_per_pbs_iteration_per_cu": 4 * lds_cyc,
-                            "bound_pbs_per_s": 256 * clock / (n_iter * 4 * lds_cyc)}
+                            "lds_pipe_cycles_per_pbs_iteration_per_cu": wpw * lds_cyc,
+                            "bound_pbs_per_s": 256 * clock / (n_iter * wpw * lds_cyc)}
         if comp.get("issue_cycles_per_pbs_iteration_per_cu"):
-            comp["serial_sum_pbs_per_s"] = 256 * clock / (n_iter * (comp["issue_cycles_per_pbs_iteration_per_cu"] + 4 * lds_cyc))
+            comp["serial_sum_pbs_per_s"] = 256 * clock / (n_iter * (comp["issue_cycles_per_pbs_iteration_per_cu"] + wpw * lds_cyc))
     json.dump(comp, open(os.path.join(dst, "compute_roofline.json" if "multibit" not in extra else f"compute_roofline_{extra.split()[-1]}.json"), "w"), indent=1)
     out["compute_roofline"] = comp
     json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)

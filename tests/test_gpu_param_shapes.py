@@ -76,13 +76,13 @@ def test_generic_kernel_equals_the_throughput_and_latency_builds_on_the_default_
     args = (ctx, n, ptr(np.arange(n + 1, dtype=np.int32)), ptr(np.arange(h, h + n, dtype=np.int32)), ptr(np.ones(n, dtype=np.int64)),
             ptr(np.zeros(n, dtype=np.uint64)), ptr(np.full(n, lid, dtype=np.int32)), ptr(np.arange(ho, ho + n, dtype=np.int32)))
     outs = {}
-    for variant in (3, 2, 12):
+    for variant in (3, 2, 17, 12):
         check(w.lib.fhes_set_kernel_variant(ctx, variant))
         check(w.lib.fhes_pbs_batch(*args))
         outs[variant] = np.zeros((n, w.W), dtype=np.uint64)
         check(w.lib.fhes_arena_download(ctx, ho, n, ptr(outs[variant])))
     check(w.lib.fhes_set_kernel_variant(ctx, 0))
-    assert np.array_equal(outs[3], outs[12]) and np.array_equal(outs[2], outs[12])
+    assert np.array_equal(outs[3], outs[12]) and np.array_equal(outs[2], outs[12]) and np.array_equal(outs[17], outs[12])
     assert list(w.decrypt(outs[12])) == [(int(v) ** 2 + 1) % 16 for v in vals]
     check(w.lib.fhes_arena_free(ctx, h, n))
     check(w.lib.fhes_arena_free(ctx, ho, n))

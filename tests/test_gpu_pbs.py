@@ -157,10 +157,11 @@ def test_all_blind_rotate_variants_agree(libs):
     outs = np.arange(h_out, h_out + count, dtype=np.int32)
     ref = np.stack([w.oracle_pbs(cts[i], poly) for i in range(4)])
     # the product library: 0 = auto (the latency build at this launch size), 2 = the latency build (one bootstrap on 512 threads),
-    # 3 / 7 = the throughput build, 12 = the generic kernel (an independent implementation); a lab build (FHES_LAB=1) adds the
+    # 3 / 7 = the throughput build, 17 = the wave-per-polynomial build (one wave per polynomial, 16 points per lane), 12 = the generic
+    # kernel (an independent implementation); a lab build (FHES_LAB=1) adds the
     # retired ones: 1 the simple kernel, 5 / 6 priority policies, 8 three workgroups per CU, 20 / 21 / 25 switches of the latency build
     lab = os.environ.get("FHES_LAB") == "1"
-    variants = (12, 0, 2, 3, 7) + ((1, 5, 6, 8, 20, 21, 23, 24, 25) if lab else ())
+    variants = (12, 0, 2, 3, 7, 17) + ((1, 5, 6, 8, 20, 21, 23, 24, 25, 27) if lab else ())
     try:
         for variant in variants:
             check(w.lib.fhes_set_kernel_variant(ctx, variant))
@@ -176,11 +177,78 @@ def test_all_blind_rotate_variants_agree(libs):
                 assert np.array_equal(res, first), f"variant {variant} differs from the generic kernel"
         # what is not in the build is refused, and so are the timing-only ablations (wrong results by construction) unless a
         # developer asks by name
-        refused = (9, 10, 13, 14, 22) if (lab and os.environ.get("FHES_DEV_ABLATIONS") != "1") else (() if lab else (1, 5, 6, 8, 9, 10, 13, 14, 20, 26))
+        refused = (9, 10, 13, 14, 22, 28, 29) if (lab and os.environ.get("FHES_DEV_ABLATIONS") != "1") else (() if lab else (1, 5, 6, 8, 9, 10, 13, 14, 20, 26, 27, 28))
         for variant in refused + (11, 99, -1):
             assert w.lib.fhes_set_kernel_variant(ctx, variant) != 0, variant
     finally:
         check(w.lib.fhes_set_kernel_variant(ctx, 0))
+    check(w.lib.fhes_arena_free(ctx, h_in, count))
+    check(w.lib.fhes_arena_free(ctx, h_out, count))
+
+
+def test_automatic_choice_at_a_full_round_of_1024_equals_the_throughput_build(libs):
+    """variant 0 hands launches whose last round of 1024 is full to the wave-per-polynomial build (engine.hip, launch_blind_rotate):
+    1024 bootstraps under 0, 3 and 17 are the same words, the first ones the oracle's, and all decrypt"""
+    w = world("default")
+    ctx = w.ctx()
+    count = 1024
+    rng = np.random.default_rng(11)
+    vals = rng.integers(0, 16, size=count).astype(np.uint8)
+    cts = w.encrypt(vals)
+    t, poly = w.lut_poly(lambda x: (3 * x + 1) % 16)
+    lid = check(w.lib.fhes_lut_register(ctx, ptr(t), 16))
+    h_in = check(w.lib.fhes_arena_alloc(ctx, count))
+    h_out = check(w.lib.fhes_arena_alloc(ctx, count))
+    check(w.lib.fhes_arena_upload(ctx, h_in, count, ptr(cts)))
+    args = (ctx, count, ptr(np.arange(count + 1, dtype=np.int32)), ptr(np.arange(h_in, h_in + count, dtype=np.int32)),
+            ptr(np.ones(count, dtype=np.int64)), ptr(np.zeros(count, dtype=np.uint64)), ptr(np.full(count, lid, dtype=np.int32)),
+            ptr(np.arange(h_out, h_out + count, dtype=np.int32)))
+    outs = {}
+    try:
+        for variant in (0, 3, 17):
+            check(w.lib.fhes_set_kernel_variant(ctx, variant))
+            check(w.lib.fhes_pbs_batch(*args))
+            outs[variant] = np.zeros((count, w.W), dtype=np.uint64)
+            check(w.lib.fhes_arena_download(ctx, h_out, count, ptr(outs[variant])))
+    finally:
+        check(w.lib.fhes_set_kernel_variant(ctx, 0))
+    assert np.array_equal(outs[0], outs[3]) and np.array_equal(outs[17], outs[3])
+    for i in (0, 1023):
+        assert np.array_equal(outs[0][i], w.oracle_pbs(cts[i], poly))
+    assert list(w.decrypt(outs[0])) == [(3 * int(v) + 1) % 16 for v in vals]
+    check(w.lib.fhes_arena_free(ctx, h_in, count))
+    check(w.lib.fhes_arena_free(ctx, h_out, count))
+
+
+def test_wave_per_polynomial_build_with_the_base_2_18_decomposition(libs):
+    """variant 17 is instantiated for pbs_base_log 18 as well (Level 0 with a caller's keys): the oracle's bits,
+    on launches of one and of several workgroups per CU's worth of LDS"""
+    w = world("default_b18")
+    ctx = w.ctx()
+    count = 9
+    vals = (np.arange(count) * 7 % 16).astype(np.uint8)
+    cts = w.encrypt(vals)
+    t, poly = w.lut_poly(lambda x: (x + 9) % 16)
+    lid = check(w.lib.fhes_lut_register(ctx, ptr(t), 16))
+    h_in = check(w.lib.fhes_arena_alloc(ctx, count))
+    h_out = check(w.lib.fhes_arena_alloc(ctx, count))
+    check(w.lib.fhes_arena_upload(ctx, h_in, count, ptr(cts)))
+    args = (ctx, count, ptr(np.arange(count + 1, dtype=np.int32)), ptr(np.arange(h_in, h_in + count, dtype=np.int32)),
+            ptr(np.ones(count, dtype=np.int64)), ptr(np.zeros(count, dtype=np.uint64)), ptr(np.full(count, lid, dtype=np.int32)),
+            ptr(np.arange(h_out, h_out + count, dtype=np.int32)))
+    ref = np.stack([w.oracle_pbs(cts[i], poly) for i in range(2)])
+    outs = {}
+    try:
+        for variant in (3, 17):
+            check(w.lib.fhes_set_kernel_variant(ctx, variant))
+            check(w.lib.fhes_pbs_batch(*args))
+            outs[variant] = np.zeros((count, w.W), dtype=np.uint64)
+            check(w.lib.fhes_arena_download(ctx, h_out, count, ptr(outs[variant])))
+    finally:
+        check(w.lib.fhes_set_kernel_variant(ctx, 0))
+    assert np.array_equal(outs[17][:2], ref)
+    assert np.array_equal(outs[17], outs[3])
+    assert list(w.decrypt(outs[17])) == [(int(v) + 9) % 16 for v in vals]
     check(w.lib.fhes_arena_free(ctx, h_in, count))
     check(w.lib.fhes_arena_free(ctx, h_out, count))
 
