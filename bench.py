@@ -6,7 +6,8 @@
 
 One "step" = one pass of `find` over one batch of B independent (input, pattern) pairs that are
 already resident in HBM (default B = 256: every one of the 68 dependent levels then fills the 256
-CUs several times over; with the round's first throughput kernel 91.1 / 93.8 / 94.1 / 94.4 k PBS/s at B = 170 / 256 / 512 / 1024; `--batch 1` times a single find).  The single-find wall-clock is measured too (untimed region)
+CUs several times over -- 13 levels of 3 bootstraps and 48 of 4 become launches of 768 and 1024, the seven wide levels launches of
+3 840 to 131 072; with the round's first throughput kernel 91.1 / 93.8 / 94.1 / 94.4 k PBS/s at B = 170 / 256 / 512 / 1024; `--batch 1` times a single find).  The single-find wall-clock is measured too (untimed region)
 and reported as `find_wall_ms_single`.  With N > 1 (launched by torch.distributed.run, one process
 per GPU) every rank runs the same workload on its own B strings: independent strings shard with no
 data-path collective, so scaling is "weak" and `value` is the PBS all ranks executed per second.
@@ -180,7 +181,7 @@ def main():
     ap.add_argument("--params", choices=["classic", "multibit2", "multibit3"], default="classic",
                     help="parameter set: PARAM_MESSAGE_2_CARRY_2_KS_PBS (the headline, BASELINE config 2) or the "
                          "multi-bit 2_2 sets of config 5")
-    ap.add_argument("--batch", type=int, default=256, help="independent (input, pattern) pairs per step and rank (levels of 5-7 bootstraps become launches of 1280-1792: whole multiples of the 256 CUs)")
+    ap.add_argument("--batch", type=int, default=256, help="independent (input, pattern) pairs per step and rank (the levels of 3-4 bootstraps become launches of 768-1024: whole multiples of the 256 CUs)")
     args = ap.parse_args()
 
     # ---- `--gpus N` is a promise about the world size ----
