@@ -782,9 +782,12 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   // auto: the wave-per-polynomial build holds 1024 bootstraps per round (four per CU) against 512 for the throughput build, at the
   // same rate when its rounds are full: it takes the launches whose LAST round of 1024 is full or nearly so -- 1024: 125.5 k against
   // 115.7 k PBS/s, 2048: 126.0 k against 121.0 k; 768: the same; 512 or 1536: the throughput build by 20 % (profiles/r05_probe29_wpp_rates.txt)
+  // Up to four rounds only: from 4096 bootstraps on the two builds run at the same rate, and in long launches the free-running waves
+  // of this build drift apart along the key -- 42 % of its GGSW reads then miss L2 (20 MB of fabric reads per bootstrap, 2.9 TB/s from the
+  // Infinity Cache; the throughput build's workgroups stay together: 0.2 MB per bootstrap; profiles/EXPERIMENTS.md)
   if (variant == 0 && n2048 && ctx->wpp_auto) {
     const int tail = d.v_count % 1024;
-    if (d.v_count >= 896 && (tail == 0 || tail > 896)) return launch_br_wpp<>(ctx, lane, d);
+    if (d.v_count >= 896 && d.v_count <= 4096 && (tail == 0 || tail > 896)) return launch_br_wpp<>(ctx, lane, d);
   }
   if (variant == 0 || variant == 3 || variant == 7) return n2048 ? launch_br_v5<11, 2>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
 #ifdef FHES_LAB

@@ -142,8 +142,19 @@ if bench_line and "roofline" in bench_line:
 # dispatches of the batched steps only (>= 512 workgroups, as bench.py's timed launches are)
 try:
     trace = newest(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+    # the dispatch sizes of a batched step: every level of one find x the strings of a step, cut into chunks of 16 384 (engine.hip);
+    # the untimed sections of the command (one find in its log-depth form, the concurrent callers) launch other sizes
+    sizes = None
+    if bench_line and "config" in bench_line and bench_line["config"].get("pbs_per_level_of_one_find"):
+        sizes = set()
+        for lv in bench_line["config"]["pbs_per_level_of_one_find"]:
+            c = lv * bench_line["config"]["strings_per_step_per_rank"]
+            while c > 0:
+                sizes.add(min(c, 16384))
+                c -= min(c, 16384)
     durs = [(float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6 for r in csv.DictReader(open(trace))
-            if "blind_rotate" in r["Kernel_Name"] and int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1) >= 512]
+            if "blind_rotate" in r["Kernel_Name"] and int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1) >= 512
+            and (sizes is None or int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1) in sizes)]
     if check is not None and durs and bench_line:
         check["rocprof_avg_ms_of_batched_launches"] = round(sum(durs) / len(durs), 4)
         check["rocprof_batched_launches"] = len(durs)
