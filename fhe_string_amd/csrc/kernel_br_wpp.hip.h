@@ -13,14 +13,24 @@
 //     without waiting for anybody;
 //   * two barriers per CMUX, between TWO waves: the spectra meet in the external product (hand-over written / hand-over read);
 //   * the accumulator's image, both exchanges and the hand-over share ONE 17 KB buffer per wave (the own accumulator words live
-//     in registers, so the image is dead while the transforms run): 34 KB per bootstrap, FOUR bootstraps per CU -- eight waves
-//     that are free of each other except in pairs.
-//   * twiddles: pass 1 of the forward transform has uniform twiddles (scalar registers); the 8 + 6 + 8 + 8 per-lane twiddles
-//     of the other passes and the 16 untwist factors do not fit next to 64 + 64 registers of points and accumulator words:
-//     they are requested from the tables (L1 / L2) one pass ahead, like the GGSW rows.
+//     in registers, so the image is dead while the transforms run): 34 KB per bootstrap + 5.5 KB of twiddle tables, FOUR
+//     bootstraps per CU -- eight waves that are free of each other except in pairs;
+//   * the external product reads BOTH spectra from LDS (the own one from the slots the wave has just written): one instruction
+//     sequence for both waves -- a branch on the wave's role got folded into register moves and 96 spilled registers -- and the
+//     points' 64 registers are free while it runs;
+//   * twiddles: pass 1 of the forward transform has uniform twiddles (scalar registers).  The 8 + 6 + 8 + 8 per-lane twiddles of
+//     the other passes and the 16 untwist factors do not fit next to 64 + 64 registers of points and accumulator words, and a
+//     per-lane request to L2 costs 0.3 % of the rate EACH (timing-only ablation: 140 k PBS/s without any, 122 k with all 46):
+//     forward pass 3 (6) and five of inverse pass 1' stay in registers for the whole loop, forward pass 2 (8), inverse pass 2'
+//     (8) and three of pass 1' come from per-workgroup LDS tables read a pass AHEAD (read where they are used they cost 2 %),
+//     the untwist factors are the only table requests left in the loop.  A constant the compiler has to spill is reloaded
+//     where it is used, latency and all (102 k PBS/s with ten of them spilled): 252 registers, none spilled.
 //
-// The synthetic twin (scripts/micro/lds_valu_gate.hip, GATE_WAVE_PER_POLY=1; profiles/r05_gate_wave_per_poly.jsonl) prices this
-// structure at 5.6 k cycles per CMUX and CU by wall-clock against 6.6 k for the shipped structure's twin (-14 %).
+// The synthetic twin (scripts/micro/lds_valu_gate.hip, GATE_WAVE_PER_POLY=1; profiles/r05_gate_wave_per_poly.jsonl) priced this
+// structure at 5.6 k cycles per CMUX and CU by wall-clock against 6.6 k for the shipped structure's twin (-14 %).  Measured: the
+// throughput build's rate from 4096 bootstraps on, 4-8.5 % above it at one or two full rounds of 1024, behind it when the last round
+// is partial (profiles/r05_probe29_wpp_rates.txt; DESIGN.md section 7 has the reading).  launch_blind_rotate (engine.hip) hands
+// it the launches of one to four rounds whose last round is full.
 //
 // Arithmetic: DESIGN.md section 4 -- the butterflies of blind_rotate_v5_kernel on the same operands in the same stage order, the
 // same bits.  Index model of the layouts, the padded slots and every twiddle formula (with the quarter-turn derivations):
