@@ -592,18 +592,19 @@ static int launch_br_lat(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
 }
 
 // the wave-per-polynomial build of the classic blind rotate (kernel_br_wpp.hip.h): a bootstrap on 128 threads, four per CU
-template <int BL = 23, bool STAMP = false, int ABL = 0>
+template <int BL = 23, bool STAMP = false, int ABL = 0, int BOOTS = 1>
 static int launch_br_wpp(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
-  if (BL == 23 && !STAMP && ABL == 0 && ctx->dims.pbs_base_log == 18) return launch_br_wpp<18>(ctx, lane, d);
-  auto kern = dev::blind_rotate_wpp_kernel<BL, STAMP, ABL>;
-  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), dev::kWppLdsBytes)) return rc;
+  if (BL == 23 && !STAMP && ABL == 0 && BOOTS == 1 && ctx->dims.pbs_base_log == 18) return launch_br_wpp<18>(ctx, lane, d);
+  auto kern = dev::blind_rotate_wpp_kernel<BL, STAMP, ABL, BOOTS>;
+  constexpr size_t lds = dev::wpp_lds_bytes(BOOTS);
+  if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
   if (STAMP && !ctx->lat_stamps) {   // lab: stamps of the first 1024 workgroups, written to $FHES_LAT_STAMPS when the context goes away
     FHES_HIP(hipMalloc(&ctx->lat_stamps, (size_t)256 * 8 * dev::kLatStamps * 8));
     FHES_HIP(hipMemset(ctx->lat_stamps, 0, (size_t)256 * 8 * dev::kLatStamps * 8));
   }
-  hipLaunchKernelGGL(kern, dim3(d.v_count), dim3(dev::kWppThreads), dev::kWppLdsBytes, lane.stream, d, ctx->arena,
+  hipLaunchKernelGGL(kern, dim3((d.v_count + BOOTS - 1) / BOOTS), dim3(dev::kWppThreads * BOOTS), lds, lane.stream, d, ctx->arena,
                      ctx->ct_stride, lane.ks_out, ctx->ks_stride, ctx->dims.n, ctx->bsk_e, ctx->lut_polys, ctx->twist_inv64,
-                     ctx->tw, ctx->psi, STAMP ? ctx->lat_stamps : nullptr);
+                     ctx->tw, ctx->psi, STAMP ? ctx->lat_stamps : nullptr, (int)d.v_count);
   FHES_HIP(hipGetLastError());
   return FHES_OK;
 }
@@ -791,8 +792,9 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   }
   if (variant == 0 || variant == 3 || variant == 7) return n2048 ? launch_br_v5<11, 2>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
 #ifdef FHES_LAB
-  if (variant >= 27 && variant <= 29) {   // wave-per-polynomial build: phase stamps; timing-only ablations (WRONG results)
+  if (variant >= 27 && variant <= 30) {   // wave-per-polynomial build: phase stamps; timing-only ablations (WRONG results); two bootstraps per workgroup
     if (!n2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the lab builds exist for the default set only");
+    if (variant == 30) return launch_br_wpp<23, false, 0, 2>(ctx, lane, d);
     if (variant == 28) return launch_br_wpp<23, false, 1>(ctx, lane, d);   // without the per-lane table requests
     if (variant == 29) return launch_br_wpp<23, false, 2>(ctx, lane, d);   // without any global load inside the loop
     return launch_br_wpp<23, true>(ctx, lane, d);
@@ -1350,7 +1352,7 @@ int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
     return FHES_OK;
   }
   const bool wrong = v == 9 || v == 10 || v == 13 || v == 14 || v == 22 || v == 28 || v == 29;   // timing-only ablations
-  const bool lab = v == 1 || v == 5 || v == 6 || v == 8 || wrong || (v >= 20 && v <= 29);
+  const bool lab = v == 1 || v == 5 || v == 6 || v == 8 || wrong || (v >= 20 && v <= 30);
   if (wrong) {   // a developer has to ask for wrong results by name
     const char *e = getenv("FHES_DEV_ABLATIONS");
     if (!e || std::string(e) != "1")

@@ -52,8 +52,9 @@ constexpr int kWppThreads = 128;
 constexpr int kWppSlots = 1088;                                  // padded slots per wave
 // two buffers (34 KB) | F: the twiddles of forward pass 2, [8][16 blocks] | I: those of inverse pass 2', [8][4] | J: three of inverse
 // pass 1', [3][64 lanes]  = 40 448 bytes: four workgroups per CU (160 KB)
-constexpr int kWppTabF = 2 * kWppSlots, kWppTabI = kWppTabF + 8 * 16, kWppTabJ = kWppTabI + 8 * 4, kWppTabEnd = kWppTabJ + 3 * 64;   // in slots of 16 bytes
-constexpr size_t kWppLdsBytes = (size_t)kWppTabEnd * 16;
+constexpr int kWppTabI = 8 * 16, kWppTabJ = kWppTabI + 8 * 4, kWppTabEnd = kWppTabJ + 3 * 64;   // in slots of 16 bytes, behind the buffers
+constexpr size_t wpp_lds_bytes(int boots) { return (size_t)(boots * 2 * kWppSlots + kWppTabEnd) * 16; }
+constexpr size_t kWppLdsBytes = wpp_lds_bytes(1);
 
 // forward pass over the four register bits (highest first).  t3: the stage of e3; t2: its successor's twiddle for the EVEN block
 // (the odd block's is -i times that); t1[2], t0[4]: the even blocks of the last two stages.  `out(e)` is called
@@ -110,12 +111,15 @@ __device__ __forceinline__ void wpp_inv_pass4(double2 (&x)[16], double2 a, doubl
 
 constexpr int kWppStampIter = 300;   // STAMP (lab): every wave records s_memtime at the marked points of ONE iteration
 // ABL (lab, timing only, WRONG results): 1 = the per-lane table requests replaced by a register constant; 2 = the GGSW rows as well
-template <int BL, bool STAMP = false, int ABL = 0>
-__global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
+// BOOTS (lab): bootstraps per workgroup -- 1: 128 threads, four workgroups per CU; 2: 256 threads, two workgroups per CU whose
+// four waves meet at both barriers (the throughput build's occupancy shape: do two workgroups in anti-phase overlap better than
+// eight free-running waves?)
+template <int BL, bool STAMP = false, int ABL = 0, int BOOTS = 1>
+__global__ __launch_bounds__(kWppThreads * BOOTS, 2) void blind_rotate_wpp_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride, int n_small,
     const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
     const double2 *__restrict__ twist_inv /* twist / (M * 2^64): torus_from_f64_pair */, const double2 *__restrict__ tw,
-    const double2 *__restrict__ psi, unsigned long long *__restrict__ stamps = nullptr) {
+    const double2 *__restrict__ psi, unsigned long long *__restrict__ stamps = nullptr, int v_count = 0) {
   constexpr int LOGN = 11, N = 1 << LOGN, M = N / 2;
   static_assert(BL >= 1 && BL <= 31, "single-level digit must fit the high dword");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -123,17 +127,21 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
   int it_now = -1;
 #define FHES_WPP_STAMP(k)                                                                                  \
   do {                                                                                                     \
-    if (STAMP && it_now == kWppStampIter && blockIdx.x < 1024) {                                           \
+    if (STAMP && it_now == kWppStampIter && blockIdx.x * BOOTS < 1024) {                                        \
       const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
-      if ((tid & 63) == 0) stamps[((size_t)blockIdx.x * 2 + (size_t)(tid >> 6)) * kLatStamps + (k)] = t_;   \
+      if ((tid & 63) == 0) stamps[((size_t)blockIdx.x * 2 * BOOTS + (size_t)(tid >> 6)) * kLatStamps + (k)] = t_; \
     }                                                                                                      \
   } while (0)
-  const int r = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave = output polynomial
+  const int r = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);  // wave = output polynomial
+  const int boot = __builtin_amdgcn_readfirstlane(tid >> 7);     // bootstrap inside the workgroup (BOOTS = 2)
   const int l = tid & 63;
-  unsigned char *mine = smem_raw + (size_t)r * kWppSlots * 16;
+  unsigned char *boot_base = smem_raw + (size_t)boot * 2 * kWppSlots * 16;
+  unsigned char *mine = boot_base + (size_t)r * kWppSlots * 16;
   uint64_t *img = reinterpret_cast<uint64_t *>(mine);            // [N] image of -acc, plain order (while no transform runs)
   double2 *xb = reinterpret_cast<double2 *>(mine);               // [kWppSlots] exchanges and the hand-over
-  const int vidx = d.v0 + blockIdx.x;
+  // BOOTS = 2 and an odd launch: the last workgroup's second half repeats the last bootstrap (same inputs, same words written twice)
+  const int slot_in_launch = BOOTS == 1 ? (int)blockIdx.x : min((int)blockIdx.x * BOOTS + boot, v_count - 1);
+  const int vidx = d.v0 + slot_in_launch;
   const int inst = vidx / d.count, node = d.first + vidx % d.count;
 
   // lane bases of the slots (scripts/model/wpp_layouts.py prints the constants)
@@ -143,8 +151,8 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
   double2 *s3 = xb + l * 17;                 // L3 / slot2: + e
   // the hand-over as the external product reads it: BOTH spectra from LDS (the own one from the slots this wave has just
   // written), so the product is the same instruction sequence for both waves and the points' registers are free while it runs
-  const double2 *d0s = reinterpret_cast<const double2 *>(smem_raw) + l * 17;
-  const double2 *d1s = reinterpret_cast<const double2 *>(smem_raw + (size_t)kWppSlots * 16) + l * 17;
+  const double2 *d0s = reinterpret_cast<const double2 *>(boot_base) + l * 17;
+  const double2 *d1s = reinterpret_cast<const double2 *>(boot_base + (size_t)kWppSlots * 16) + l * 17;
 
   // uniform twiddles of forward pass 1 and of the inverse stage of index bit 1
   const double2 u3 = psi[1], u2 = psi[2];
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
     return buf_load_d2(rs_g, voff_g, soff);
   };
 
-  const uint64_t *ks = ks_out + (size_t)blockIdx.x * ks_stride;
+  const uint64_t *ks = ks_out + (size_t)slot_in_launch * ks_stride;
   auto modswitch_of = [&](uint64_t v) __attribute__((always_inline)) {
     return (int)((((v >> (64 - LOGN - 2)) + 1) >> 1) & (uint64_t)(2 * N - 1));
   };
@@ -201,26 +209,27 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
   // ---- twiddle tables of the workgroup (both waves read them): per-lane requests to L2 cost 0.3 % of the rate EACH
   // (profiles/r05_probe28_wpp_ablations.txt), an LDS read next to the exchange's sixteen costs nothing measurable ----
   {
-    double2 *tabs = reinterpret_cast<double2 *>(smem_raw);
+    double2 *tabs = reinterpret_cast<double2 *>(smem_raw) + BOOTS * 2 * kWppSlots;
     if (tid < 128) {   // F[k][h]: psi[16 + h], psi[32 + 2 h], psi[64 + 4 h], psi[66 + 4 h], psi[128 + 8 h + 2 j]
       const int k = tid >> 4, h = tid & 15;
       const int idx = k == 0 ? 16 + h : (k == 1 ? 32 + 2 * h : (k < 4 ? 64 + 4 * h + 2 * (k - 2) : 128 + 8 * h + 2 * (k - 4)));
-      tabs[kWppTabF + tid] = psi[idx];
+      tabs[tid] = psi[idx];
     }
     if (tid < 32) {    // I[k][q]: tw[q << 7], tw[q << 6], tw[q << 5], tw[(4 + q) << 5], tw[(4 j + q) << 4]
       const int k = tid >> 2, q = tid & 3;
       const int idx = k == 0 ? q << 7 : (k == 1 ? q << 6 : (k < 4 ? (4 * (k - 2) + q) << 5 : (4 * (k - 4) + q) << 4));
       tabs[kWppTabI + tid] = tw[idx];
     }
-    for (int t = tid; t < 192; t += kWppThreads) {   // J[k][l]: tw[l << 3], tw[l << 2], tw[l << 1]
+    for (int t = tid; t < 192; t += kWppThreads * BOOTS) {   // J[k][l]: tw[l << 3], tw[l << 2], tw[l << 1]
       const int k = t >> 6, ll = t & 63;
       tabs[kWppTabJ + t] = tw[ll << (3 - k)];
     }
   }
   __syncthreads();
-  const double2 *tabF = reinterpret_cast<const double2 *>(smem_raw) + kWppTabF + h4;    // + 16 k
-  const double2 *tabI = reinterpret_cast<const double2 *>(smem_raw) + kWppTabI + q2;    // + 4 k
-  const double2 *tabJ = reinterpret_cast<const double2 *>(smem_raw) + kWppTabJ + l;     // + 64 k
+  const double2 *tab0 = reinterpret_cast<const double2 *>(smem_raw) + BOOTS * 2 * kWppSlots;
+  const double2 *tabF = tab0 + h4;               // + 16 k
+  const double2 *tabI = tab0 + kWppTabI + q2;    // + 4 k
+  const double2 *tabJ = tab0 + kWppTabJ + l;     // + 64 k
 
   // the per-lane twiddles of forward pass 3 stay in registers for the whole loop (6 entries: their requests are the scattered ones --
   // psi[512 + 8 l + ..] is 64 cache lines per request; more do not fit: a spilled constant is reloaded where it is used, latency and
@@ -432,14 +441,14 @@ __global__ __launch_bounds__(kWppThreads, 2) void blind_rotate_wpp_kernel(
 
   // ---- sample extract from the images of -acc: a'_0 = a_0, a'_j = -a_{N-j}, b' = b_0 ----
   uint64_t *out = arena + (size_t)resolve(d, inst, d.out_idx[node]) * ct_stride;
-  const uint64_t *img0 = reinterpret_cast<const uint64_t *>(smem_raw);
-  const uint64_t *img1 = reinterpret_cast<const uint64_t *>(smem_raw + (size_t)kWppSlots * 16);
-  for (int j = tid; j < N; j += kWppThreads) {
+  const uint64_t *img0 = reinterpret_cast<const uint64_t *>(boot_base);
+  const uint64_t *img1 = reinterpret_cast<const uint64_t *>(boot_base + (size_t)kWppSlots * 16);
+  for (int j = tid & 127; j < N; j += kWppThreads) {
     const int jj = (j == 0) ? 0 : N - j;
     const uint64_t v = img0[jj];
     out[j] = (j == 0) ? (uint64_t)0 - v : v;
   }
-  if (tid == 0) out[N] = (uint64_t)0 - img1[0];
+  if ((tid & 127) == 0) out[N] = (uint64_t)0 - img1[0];
 }
 
 }  // namespace dev
