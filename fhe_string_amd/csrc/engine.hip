@@ -594,7 +594,7 @@ static int launch_br_lat(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
 // the wave-per-polynomial build of the classic blind rotate (kernel_br_wpp.hip.h): a bootstrap on 128 threads, four per CU
 template <int BL = 23, bool STAMP = false, int ABL = 0, int BOOTS = 1>
 static int launch_br_wpp(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
-  if (BL == 23 && !STAMP && ABL == 0 && BOOTS == 1 && ctx->dims.pbs_base_log == 18) return launch_br_wpp<18>(ctx, lane, d);
+  if (BL == 23 && !STAMP && ABL == 0 && ctx->dims.pbs_base_log == 18) return launch_br_wpp<18, false, 0, BOOTS>(ctx, lane, d);
   auto kern = dev::blind_rotate_wpp_kernel<BL, STAMP, ABL, BOOTS>;
   constexpr size_t lds = dev::wpp_lds_bytes(BOOTS);
   if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
@@ -733,8 +733,8 @@ static int launch_br_gen(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
 //   0   auto: the latency build for launches of at most one workgroup per CU (ctx->lat_max), the throughput build above
 //   2   the latency build (kernel_br_lat.hip.h: one bootstrap on 512 threads; N = 2048)
 //   3   the throughput build at every launch size (blind_rotate_v5_kernel, no priority hints; 7 = its number of rounds 2-4)
-//   17  the wave-per-polynomial build (kernel_br_wpp.hip.h: one wave per polynomial, four bootstraps per CU; N = 2048): the rate of
-//       the throughput build within 1 % at launches of whole rounds, 8 % above it at 513-1024 bootstraps, below it under 512
+//   17  the wave-per-polynomial build (kernel_br_wpp.hip.h: one wave per polynomial, two bootstraps per workgroup, two workgroups per CU;
+//       N = 2048): 8-10 % above the throughput build per full round of 1024, behind it where its last round is a small remainder
 //   12  the generic kernel on a 2_2 set (the second implementation the tests compare with)
 // A lab build (-DFHES_LAB: FHES_LAB=1 python -m fhe_string_amd.build, scripts/) also carries the simple reference kernel (1),
 // the two wave-priority policies of the throughput kernel (5, 6), variant 8 (three workgroups per CU, 28 % slower) and the
@@ -778,23 +778,24 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   }
   if (variant == 17) {
     if (!n2048) return fail(FHES_ERR_UNSUPPORTED, "the wave-per-polynomial build of the blind rotate is written for N = 2048");
-    return launch_br_wpp<>(ctx, lane, d);
+    return launch_br_wpp<23, false, 0, 2>(ctx, lane, d);
   }
-  // auto: the wave-per-polynomial build holds 1024 bootstraps per round (four per CU) against 512 for the throughput build, at the
-  // same rate when its rounds are full: it takes the launches whose LAST round of 1024 is full or nearly so -- 1024: 125.5 k against
-  // 115.7 k PBS/s, 2048: 126.0 k against 121.0 k; 768: the same; 512 or 1536: the throughput build by 20 % (profiles/r05_probe29_wpp_rates.txt)
-  // Up to four rounds only: from 4096 bootstraps on the two builds run at the same rate, and in long launches the free-running waves
-  // of this build drift apart along the key -- 42 % of its GGSW reads then miss L2 (20 MB of fabric reads per bootstrap, 2.9 TB/s from the
-  // Infinity Cache; the throughput build's workgroups stay together: 0.2 MB per bootstrap; profiles/EXPERIMENTS.md)
+  // auto: the wave-per-polynomial build (two bootstraps per workgroup, two workgroups per CU: rounds of 1024) is 8-10 % faster per full
+  // round than the throughput build (rounds of 512), but a partial last round costs it more.  Both are step functions of the launch
+  // size; the choice compares them (ms on the box of profiles/r05_probe33_wpp2_sizes.txt -- only the ORDER matters, and it held on every
+  // box measured): 896-1024, 1536, 2048 and everything from 2560 on go to the wave-per-polynomial build, 257-768, 1152-1280 and 1792 stay
   if (variant == 0 && n2048 && ctx->wpp_auto) {
-    const int tail = d.v_count % 1024;
-    if (d.v_count >= 896 && d.v_count <= 4096 && (tail == 0 || tail > 896)) return launch_br_wpp<>(ctx, lane, d);
+    const int v = d.v_count;
+    const int r5 = v % 512, r10 = v % 1024;
+    const double t_v5 = 0.45 + 4.22 * (v / 512) + (r5 == 0 ? 0.0 : (r5 <= 256 ? 2.45 : 4.3));
+    const double t_wpp = 0.6 + 7.6 * (v / 1024) + (r10 == 0 ? 0.0 : (r10 <= 512 ? 4.0 : 7.9));
+    if (t_wpp < t_v5) return launch_br_wpp<23, false, 0, 2>(ctx, lane, d);
   }
   if (variant == 0 || variant == 3 || variant == 7) return n2048 ? launch_br_v5<11, 2>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
 #ifdef FHES_LAB
-  if (variant >= 27 && variant <= 30) {   // wave-per-polynomial build: phase stamps; timing-only ablations (WRONG results); two bootstraps per workgroup
+  if (variant >= 27 && variant <= 30) {   // wave-per-polynomial build: phase stamps and timing-only ablations (WRONG results) of its one-bootstrap-per-workgroup form; 30: that form itself
     if (!n2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the lab builds exist for the default set only");
-    if (variant == 30) return launch_br_wpp<23, false, 0, 2>(ctx, lane, d);
+    if (variant == 30) return launch_br_wpp<23, false, 0, 1>(ctx, lane, d);   // ONE bootstrap per workgroup, four workgroups per CU (the first form: 126 k against 136 k)
     if (variant == 28) return launch_br_wpp<23, false, 1>(ctx, lane, d);   // without the per-lane table requests
     if (variant == 29) return launch_br_wpp<23, false, 2>(ctx, lane, d);   // without any global load inside the loop
     return launch_br_wpp<23, true>(ctx, lane, d);

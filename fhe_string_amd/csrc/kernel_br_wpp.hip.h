@@ -11,10 +11,15 @@
 //   * both exchanges of a transform are local to the wave: the LDS operations of one wave execute in order, so an exchange
 //     needs no barrier at all -- a wave runs from its digits to its spectrum, and from the external product to its image,
 //     without waiting for anybody;
-//   * two barriers per CMUX, between TWO waves: the spectra meet in the external product (hand-over written / hand-over read);
+//   * two barriers per CMUX: the spectra meet in the external product (hand-over written / hand-over read).  TWO bootstraps share
+//     a workgroup (BOOTS = 2: 256 threads, two workgroups per CU), so four waves meet at each barrier although only pairs
+//     depend on each other -- on purpose: the first form (BOOTS = 1: 128 threads, four workgroups per CU, eight waves free of
+//     each other except in pairs) ran at the throughput build's rate, 126 k PBS/s, because free-running waves collide in the
+//     LDS store path at random, while two barrier-synchronised workgroups fall into anti-phase -- one computes while the other
+//     exchanges: 136 k in the same run (profiles/r05_probe32_wpp_two_per_workgroup.txt);
 //   * the accumulator's image, both exchanges and the hand-over share ONE 17 KB buffer per wave (the own accumulator words live
-//     in registers, so the image is dead while the transforms run): 34 KB per bootstrap + 5.5 KB of twiddle tables, FOUR
-//     bootstraps per CU -- eight waves that are free of each other except in pairs;
+//     in registers, so the image is dead while the transforms run): 34 KB per bootstrap + 5.5 KB of twiddle tables per
+//     workgroup, FOUR bootstraps per CU;
 //   * the external product reads BOTH spectra from LDS (the own one from the slots the wave has just written): one instruction
 //     sequence for both waves -- a branch on the wave's role got folded into register moves and 96 spilled registers -- and the
 //     points' 64 registers are free while it runs;
@@ -27,10 +32,10 @@
 //     where it is used, latency and all (102 k PBS/s with ten of them spilled): 252 registers, none spilled.
 //
 // The synthetic twin (scripts/micro/lds_valu_gate.hip, GATE_WAVE_PER_POLY=1; profiles/r05_gate_wave_per_poly.jsonl) priced this
-// structure at 5.6 k cycles per CMUX and CU by wall-clock against 6.6 k for the shipped structure's twin (-14 %).  Measured: the
-// throughput build's rate from 4096 bootstraps on, 4-8.5 % above it at one or two full rounds of 1024, behind it when the last round
-// is partial (profiles/r05_probe29_wpp_rates.txt; DESIGN.md section 7 has the reading).  launch_blind_rotate (engine.hip) hands
-// it the launches of one to four rounds whose last round is full.
+// structure at 5.6 k cycles per CMUX and CU by wall-clock against 6.6 k for the shipped structure's twin (-14 %).  Measured with two
+// bootstraps per workgroup: 8-10 % above the throughput build per full round of 1024 bootstraps (136 k against 123 k PBS/s at
+// 16 384 in the same run), behind it where the last round is a small remainder (profiles/r05_probe33_wpp2_sizes.txt; DESIGN.md
+// section 7 has the reading).  launch_blind_rotate (engine.hip) compares the two step functions of the launch size.
 //
 // Arithmetic: DESIGN.md section 4 -- the butterflies of blind_rotate_v5_kernel on the same operands in the same stage order, the
 // same bits.  Index model of the layouts, the padded slots and every twiddle formula (with the quarter-turn derivations):

@@ -25,6 +25,13 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
+def boots_of(name):
+    """bootstraps per workgroup: 2 for blind_rotate_wpp_kernel<BL, STAMP, ABL, 2> (two bootstraps share a workgroup), else 1"""
+    import re
+    m = re.search(r"blind_rotate_wpp_kernel<[^>]*,\s*(\d+)>", name)
+    return int(m.group(1)) if m else 1
+
+
 def short(name):
     n = name.split("(")[0].replace("void ", "")
     return n
@@ -152,9 +159,13 @@ try:
             while c > 0:
                 sizes.add(min(c, 16384))
                 c -= min(c, 16384)
+    def pbs_of(r):   # bootstraps of a dispatch: workgroups x bootstraps per workgroup (an odd launch rounds up: accept both)
+        wg = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
+        b = boots_of(r["Kernel_Name"])
+        return [wg * b - k for k in range(b)]
     durs = [(float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6 for r in csv.DictReader(open(trace))
-            if "blind_rotate" in r["Kernel_Name"] and int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1) >= 512
-            and (sizes is None or int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1) in sizes)]
+            if "blind_rotate" in r["Kernel_Name"] and max(pbs_of(r)) >= 512
+            and (sizes is None or any(c in sizes for c in pbs_of(r)))]
     if check is not None and durs and bench_line:
         check["rocprof_avg_ms_of_batched_launches"] = round(sum(durs) / len(durs), 4)
         check["rocprof_batched_launches"] = len(durs)
@@ -192,9 +203,11 @@ if br and br[0] in sq:
     n_iter = 742 if "multibit" not in extra else (382 if extra.split()[-1] == "multibit2" else 255)
     wgs = c.get("sqa_workgroups", 0)                      # one workgroup = one PBS: 4 waves (throughput build), 2 (wave-per-polynomial build), 8 (latency builds)
     wpw = 2 if "_wpp_" in br[0] else (8 if ("_lat_" in br[0] or "_seq_" in br[0]) else 4)
+    boots = boots_of(br[0])
+    wgs = wgs * boots                                     # from here on: bootstraps, not workgroups
     wave_iters = wgs * wpw * (n_iter or 1)
     f64 = sum(c.get(x, 0) for x in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
-    wgs_b = c.get("sqb_workgroups", wgs) or wgs
+    wgs_b = (c.get("sqb_workgroups", 0) * boots) or wgs
     dur_a, dur_b = c.get("sqa_duration_ns", 0) * 1e-9, c.get("sqb_duration_ns", 0) * 1e-9
     clock = c.get("GRBM_GUI_ACTIVE", 0) / 8 / dur_a if dur_a else None     # MI355X_MICROARCH.md, DVFS give-back
     def rate(instr, wps=2):

@@ -157,11 +157,11 @@ def test_all_blind_rotate_variants_agree(libs):
     outs = np.arange(h_out, h_out + count, dtype=np.int32)
     ref = np.stack([w.oracle_pbs(cts[i], poly) for i in range(4)])
     # the product library: 0 = auto (the latency build at this launch size), 2 = the latency build (one bootstrap on 512 threads),
-    # 3 / 7 = the throughput build, 17 = the wave-per-polynomial build (one wave per polynomial, 16 points per lane), 12 = the generic
+    # 3 / 7 = the throughput build, 17 = the wave-per-polynomial build (one wave per polynomial, 16 points per lane, two bootstraps per workgroup; 30 in a lab build: one), 12 = the generic
     # kernel (an independent implementation); a lab build (FHES_LAB=1) adds the
     # retired ones: 1 the simple kernel, 5 / 6 priority policies, 8 three workgroups per CU, 20 / 21 / 25 switches of the latency build
     lab = os.environ.get("FHES_LAB") == "1"
-    variants = (12, 0, 2, 3, 7, 17) + ((1, 5, 6, 8, 20, 21, 23, 24, 25, 27) if lab else ())
+    variants = (12, 0, 2, 3, 7, 17) + ((1, 5, 6, 8, 20, 21, 23, 24, 25, 27, 30) if lab else ())
     try:
         for variant in variants:
             check(w.lib.fhes_set_kernel_variant(ctx, variant))
@@ -187,8 +187,8 @@ def test_all_blind_rotate_variants_agree(libs):
 
 
 def test_automatic_choice_at_a_full_round_of_1024_equals_the_throughput_build(libs):
-    """variant 0 hands launches whose last round of 1024 is full to the wave-per-polynomial build (engine.hip, launch_blind_rotate):
-    1024 bootstraps under 0, 3 and 17 are the same words, the first ones the oracle's, and all decrypt"""
+    """variant 0 hands a launch of 1024 to the wave-per-polynomial build (engine.hip, launch_blind_rotate: the cheaper of two step
+    functions of the launch size): 1024 bootstraps under 0, 3 and 17 are the same words, the first and last the oracle's, all decrypt"""
     w = world("default")
     ctx = w.ctx()
     count = 1024
