@@ -55,7 +55,7 @@ struct fhes_ctx {
   std::vector<double2 *> lab_bsk_e;   // lab (FHES_BSK_E_CANDIDATES): copies of the engine-layout key at other addresses
   unsigned long long *lat_stamps = nullptr;   // lab: phase stamps of the stamped latency build (variant 26)
   std::atomic<uint64_t> host_bytes_up{0}, host_bytes_down{0};   // ciphertext bytes moved over PCIe by arena upload / download
-  bool wpp_auto = true;     // classic 2_2 sets, N = 2048: the wave-per-polynomial build where its last round of 1024 is (nearly) full (FHES_WPP_AUTO=0: never)
+  bool wpp_auto = true;     // classic 2_2 sets, N = 2048: the wave-per-polynomial build wherever its rounds of 1024 are cheaper than the throughput build's of 512 (FHES_WPP_AUTO=0: never)
   int mb_split_max = 0;     // multi-bit sets: launches of at most this many bootstraps take the split form (bundles first, then the sequential kernel)
   bool mb_lat512 = false;   // multi-bit sets: one-per-CU launches take the 512-thread latency build (blind_rotate_mb_lat_kernel)
   int lat_max = 0;   // launches of at most this many bootstraps take the latency build of the classic blind rotate (0: never)
