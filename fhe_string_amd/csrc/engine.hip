@@ -592,11 +592,12 @@ static int launch_br_lat(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
 }
 
 // the wave-per-polynomial build of the classic blind rotate (kernel_br_wpp.hip.h): a bootstrap on 128 threads, four per CU
-template <int BL = 23, bool STAMP = false, int ABL = 0, int BOOTS = 1>
+template <int BL = 23, bool STAMP = false, int ABL = 0, int BOOTS = 1, bool TWL = false>
 static int launch_br_wpp(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d) {
-  if (BL == 23 && !STAMP && ABL == 0 && ctx->dims.pbs_base_log == 18) return launch_br_wpp<18, false, 0, BOOTS>(ctx, lane, d);
-  auto kern = dev::blind_rotate_wpp_kernel<BL, STAMP, ABL, BOOTS>;
-  constexpr size_t lds = dev::wpp_lds_bytes(BOOTS);
+  if (BL == 23 && !STAMP && ABL == 0 && !TWL && BOOTS <= 2 && ctx->dims.pbs_base_log == 18) return launch_br_wpp<18, false, 0, BOOTS>(ctx, lane, d);
+  auto kern = dev::blind_rotate_wpp_kernel<BL, STAMP, ABL, BOOTS, TWL>;
+  constexpr size_t lds = dev::wpp_lds_bytes(BOOTS, TWL);
+  static_assert(lds <= 160 * 1024, "one workgroup's LDS");
   if (int rc = ensure_dyn_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
   if (STAMP && !ctx->lat_stamps) {   // lab: stamps of the first 1024 workgroups, written to $FHES_LAT_STAMPS when the context goes away
     FHES_HIP(hipMalloc(&ctx->lat_stamps, (size_t)256 * 8 * dev::kLatStamps * 8));
@@ -793,8 +794,12 @@ static int launch_blind_rotate(fhes_ctx *ctx, Lane &lane, const dev::NodeDesc &d
   }
   if (variant == 0 || variant == 3 || variant == 7) return n2048 ? launch_br_v5<11, 2>(ctx, lane, d) : launch_br_v5<8, 2>(ctx, lane, d);
 #ifdef FHES_LAB
-  if (variant >= 27 && variant <= 30) {   // wave-per-polynomial build: phase stamps and timing-only ablations (WRONG results) of its one-bootstrap-per-workgroup form; 30: that form itself
+  if (variant >= 27 && variant <= 32) {   // wave-per-polynomial build: phase stamps and timing-only ablations (WRONG results) of its one-bootstrap-per-workgroup form; 30: that form itself
     if (!n2048 || ctx->dims.pbs_base_log != 23) return fail(FHES_ERR_UNSUPPORTED, "the lab builds exist for the default set only");
+    // FOUR bootstraps per workgroup (512 threads, one workgroup per CU): 31 with the untwist factors in LDS, 32 without -- written at the
+    // end of round 5 without a device in reach: compiled (no spills), NEVER RUN; scripts/r06_probe1.sh checks the bits first
+    if (variant == 31) return launch_br_wpp<23, false, 0, 4, true>(ctx, lane, d);
+    if (variant == 32) return launch_br_wpp<23, false, 0, 4, false>(ctx, lane, d);
     if (variant == 30) return launch_br_wpp<23, false, 0, 1>(ctx, lane, d);   // ONE bootstrap per workgroup, four workgroups per CU (the first form: 126 k against 136 k)
     if (variant == 28) return launch_br_wpp<23, false, 1>(ctx, lane, d);   // without the per-lane table requests
     if (variant == 29) return launch_br_wpp<23, false, 2>(ctx, lane, d);   // without any global load inside the loop
@@ -1353,7 +1358,7 @@ int fhes_set_kernel_variant(fhes_ctx *ctx, int32_t v) {
     return FHES_OK;
   }
   const bool wrong = v == 9 || v == 10 || v == 13 || v == 14 || v == 22 || v == 28 || v == 29;   // timing-only ablations
-  const bool lab = v == 1 || v == 5 || v == 6 || v == 8 || wrong || (v >= 20 && v <= 30);
+  const bool lab = v == 1 || v == 5 || v == 6 || v == 8 || wrong || (v >= 20 && v <= 32);
   if (wrong) {   // a developer has to ask for wrong results by name
     const char *e = getenv("FHES_DEV_ABLATIONS");
     if (!e || std::string(e) != "1")

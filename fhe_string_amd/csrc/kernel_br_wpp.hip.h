@@ -58,7 +58,8 @@ constexpr int kWppSlots = 1088;                                  // padded slots
 // two buffers (34 KB) | F: the twiddles of forward pass 2, [8][16 blocks] | I: those of inverse pass 2', [8][4] | J: three of inverse
 // pass 1', [3][64 lanes]  = 40 448 bytes: four workgroups per CU (160 KB)
 constexpr int kWppTabI = 8 * 16, kWppTabJ = kWppTabI + 8 * 4, kWppTabEnd = kWppTabJ + 3 * 64;   // in slots of 16 bytes, behind the buffers
-constexpr size_t wpp_lds_bytes(int boots) { return (size_t)(boots * 2 * kWppSlots + kWppTabEnd) * 16; }
+// (lab, TWL) T: the 1024 untwist factors behind the tables -- 16 KB that only fit with FOUR bootstraps per workgroup (161 792 bytes)
+constexpr size_t wpp_lds_bytes(int boots, bool twl = false) { return (size_t)(boots * 2 * kWppSlots + kWppTabEnd + (twl ? 1024 : 0)) * 16; }
 constexpr size_t kWppLdsBytes = wpp_lds_bytes(1);
 
 // forward pass over the four register bits (highest first).  t3: the stage of e3; t2: its successor's twiddle for the EVEN block
@@ -118,9 +119,12 @@ constexpr int kWppStampIter = 300;   // STAMP (lab): every wave records s_memtim
 // ABL (lab, timing only, WRONG results): 1 = the per-lane table requests replaced by a register constant; 2 = the GGSW rows as well
 // BOOTS (lab): bootstraps per workgroup -- 1: 128 threads, four workgroups per CU; 2: 256 threads, two workgroups per CU whose
 // four waves meet at both barriers (the throughput build's occupancy shape: do two workgroups in anti-phase overlap better than
-// eight free-running waves?)
-template <int BL, bool STAMP = false, int ABL = 0, int BOOTS = 1>
-__global__ __launch_bounds__(kWppThreads * BOOTS, 2) void blind_rotate_wpp_kernel(
+// eight free-running waves?); 4 (lab variants 31 / 32, NOT YET RUN on a device): 512 threads, ONE workgroup per CU, eight waves at
+// both barriers -- the tables are shared by four bootstraps, which leaves room for
+// TWL (lab): the untwist factors in an LDS table of the workgroup (the 16 requests per CMUX that are left in the loop cost 0.3 % of
+// the rate each, profiles/r05_probe28_wpp_ablations.txt)
+template <int BL, bool STAMP = false, int ABL = 0, int BOOTS = 1, bool TWL = false>
+__global__ __launch_bounds__(kWppThreads * BOOTS, BOOTS >= 4 ? 1 : 2) void blind_rotate_wpp_kernel(
     NodeDesc d, uint64_t *__restrict__ arena, int ct_stride, const uint64_t *__restrict__ ks_out, int ks_stride, int n_small,
     const double2 *__restrict__ bsk_e, const uint64_t *__restrict__ lut_polys,
     const double2 *__restrict__ twist_inv /* twist / (M * 2^64): torus_from_f64_pair */, const double2 *__restrict__ tw,
@@ -229,12 +233,15 @@ __global__ __launch_bounds__(kWppThreads * BOOTS, 2) void blind_rotate_wpp_kerne
       const int k = t >> 6, ll = t & 63;
       tabs[kWppTabJ + t] = tw[ll << (3 - k)];
     }
+    if (TWL)
+      for (int t = tid; t < M; t += kWppThreads * BOOTS) tabs[kWppTabEnd + t] = twist_inv[t];   // T[p]
   }
   __syncthreads();
   const double2 *tab0 = reinterpret_cast<const double2 *>(smem_raw) + BOOTS * 2 * kWppSlots;
   const double2 *tabF = tab0 + h4;               // + 16 k
   const double2 *tabI = tab0 + kWppTabI + q2;    // + 4 k
   const double2 *tabJ = tab0 + kWppTabJ + l;     // + 64 k
+  const double2 *tabT = tab0 + kWppTabEnd + l;   // + 64 e (TWL)
 
   // the per-lane twiddles of forward pass 3 stay in registers for the whole loop (6 entries: their requests are the scattered ones --
   // psi[512 + 8 l + ..] is 64 cache lines per request; more do not fit: a spilled constant is reloaded where it is used, latency and
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(kWppThreads * BOOTS, 2) void blind_rotate_wpp_kerne
     double2 tf[2][4];
     auto load_tf = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) tf[c & 1][k] = tab(rs_twi, lb, z + (unsigned)(64 * (4 * c + k) * 16));
+      for (int k = 0; k < 4; ++k) tf[c & 1][k] = TWL ? tabT[64 * (4 * c + k)] : tab(rs_twi, lb, z + (unsigned)(64 * (4 * c + k) * 16));
     };
     load_tf(0);
     load_tf(1);
