@@ -27,6 +27,9 @@
  * (/root/reference/src/lib.rs:50), so there is no reference-side table for them at all:
  * they are pinned by the same decrypted tables run under multi-bit keys.
  *
+ * Checked from outside by oracle/exact_pbs.py (round 5): the same bootstrap in exact integer arithmetic, no transform --
+ * integer stages bit for bit, every CMUX / multi-bit step within the rounding of the f64 FFT (tests/test_exact_pbs.py).
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library.  The product library (fhe_string_amd/csrc) never links it.
  *
