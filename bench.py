@@ -707,6 +707,13 @@ def main():
             os._exit(3)
 
     threading.Thread(target=watchdog, daemon=True).start()
+    if rank == 0:
+        # the headline, on STDERR, before the first collective of the sharded section: a process that dies there without a Python
+        # exception (a fault inside the communication library at world > 1, which no box of the pool has run yet) takes the JSON
+        # line with it -- the log then still says what was measured.  stdout keeps its ONE line, printed below.
+        sys.stderr.write("[bench] headline before the position-sharded section (the JSON line follows it): %s\n" % json.dumps(
+            {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step") if k in line}))
+        sys.stderr.flush()
     sharded = measure_sharded()
     done.set()
     if rank == 0:
