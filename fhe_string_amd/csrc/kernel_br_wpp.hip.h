@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kWppThreads * BOOTS, BOOTS >= 4 ? 1 : 2) void blind
   const __amdgpu_buffer_rsrc_t rs_psi = __builtin_amdgcn_make_buffer_rsrc((void *)psi, 0, (unsigned)(M * 16), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc((void *)tw, 0, (unsigned)(M / 2 * 16), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_twi = __builtin_amdgcn_make_buffer_rsrc((void *)twist_inv, 0, (unsigned)(M * 16), 0x00020000);
-  const unsigned h4b = (unsigned)h4 * 16u, q2b = (unsigned)q2 * 16u, lb = (unsigned)l * 16u;
+  const unsigned lb = (unsigned)l * 16u;
   double abl_c = 0.70710678;
   asm volatile("" : "+v"(abl_c));
   auto tab = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) __attribute__((always_inline)) {
