@@ -183,7 +183,7 @@ def test_shard_range_partitions():
             assert all(b - a <= chunk for a, b in parts) and all(a == min(r * chunk, n) for r, (a, b) in enumerate(parts))
 
 
-@pytest.mark.parametrize("world_size", [2, 3])   # 3: ragged shards (13 positions over 3 ranks; worlds 3 and 5 were also run by hand)
+@pytest.mark.parametrize("world_size", [2, 3, 8])   # 3: ragged shards (13 positions over 3 ranks); 8: the world of the scaling run -- segments of 2, the seventh rank's segment half outside the string, the eighth rank's EMPTY (world 5 was also run by hand)
 def test_sharded_operations_gloo_ranks_through_the_c_planner(world_size, libs):
     results = sorted(_spawn(_worker, n=world_size), key=lambda r: r["rank"])
     for r in results:
