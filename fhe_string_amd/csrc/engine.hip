@@ -871,6 +871,14 @@ int launch_pbs(fhes_ctx *ctx, Lane &lane, const DevNodeArrays &a, int32_t first,
   int32_t kMaxChunk = 16384;
   if (!fast_shape(ctx->p) || ctx->br_variant == 12)  // the generic kernel's global scratch: at most 1 GiB per launch
     kMaxChunk = (int32_t)std::max<size_t>(64, std::min<size_t>(16384, ((size_t)1 << 30) / gen_scratch_per_wg(ctx->dims)));
+#ifdef FHES_LAB   // FHES_LAUNCH_CHUNK=n (64..16384, read at every call): shorter launches -- scripts/r06_probe3.sh asks whether the g = 3
+                  // kernel's slow processes (L2 misses x 3.5) are workgroups drifting apart in LONG launches: a launch
+                  // boundary every few rounds brings them back together.  Same kernels on sub-ranges: the results cannot change.
+  if (const char *e = getenv("FHES_LAUNCH_CHUNK")) {
+    const long v = strtol(e, nullptr, 10);
+    if (v >= 64 && v <= 16384) kMaxChunk = std::min<int32_t>(kMaxChunk, (int32_t)v);
+  }
+#endif
   for (int32_t off = 0; off < (int32_t)total; off += kMaxChunk) {
     const int32_t c = std::min<int32_t>(kMaxChunk, (int32_t)total - off);
     int rc = ensure_ks_out(ctx, lane, c);
